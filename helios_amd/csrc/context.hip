@@ -1,0 +1,118 @@
+// Context, stream and device-memory entry points of the C-ABI (include/helios_hip.h sections 1-2).
+// Replaces pycuda.autoinit / gpuarray.to_gpu / .get() / cuda.mem_alloc of the reference
+// (source/quantities.py:463-665, source/computation.py:24).
+#include "hx_common.h"
+
+extern "C" {
+
+int hx_abi_version(void) { return 1; }
+
+int hx_create(int device_id, hx_context** out_ctx) {
+    if (!out_ctx) return HX_E_ARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -(int)e;
+    if (device_id < 0 || device_id >= n) return HX_E_ARG;
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return -(int)e;
+    hx_context* ctx = new hx_context();
+    ctx->device = device_id;
+    ctx->err[0] = 0;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return -(int)e;
+    }
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out_ctx = ctx;
+    return 0;
+}
+
+int hx_destroy(hx_context* ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int hx_sync(hx_context* ctx) {
+    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+const char* hx_last_error(hx_context* ctx) { return ctx ? ctx->err : "null context"; }
+
+int hx_device_name(hx_context* ctx, char* buf, int buflen) {
+    hipDeviceProp_t p;
+    HX_HIP(ctx, hipGetDeviceProperties(&p, ctx->device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return 0;
+}
+
+void* hx_stream(hx_context* ctx) { return (void*)ctx->stream; }
+
+int hx_timer_start(hx_context* ctx) {
+    HX_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+int hx_timer_stop_ms(hx_context* ctx, double* out_ms) {
+    HX_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *out_ms = ms;
+    return 0;
+}
+
+int hx_alloc(hx_context* ctx, size_t nbytes, void** out_dptr) {
+    HX_HIP(ctx, hipSetDevice(ctx->device));
+    if (nbytes == 0) nbytes = 8;
+    HX_HIP(ctx, hipMalloc(out_dptr, nbytes));
+    return 0;
+}
+
+int hx_free(hx_context* ctx, void* dptr) {
+    if (!dptr) return 0;
+    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    HX_HIP(ctx, hipFree(dptr));
+    return 0;
+}
+
+int hx_h2d(hx_context* ctx, void* dptr, const void* hptr, size_t nbytes) {
+    // the library never retains host pointers: pageable memory + async copy returns only after
+    // the source has been staged, and we additionally wait so that the caller may free at once
+    HX_HIP(ctx, hipMemcpyAsync(dptr, hptr, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hx_d2h(hx_context* ctx, void* hptr, const void* dptr, size_t nbytes) {
+    HX_HIP(ctx, hipMemcpyAsync(hptr, dptr, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hx_d2d(hx_context* ctx, void* dst, const void* src, size_t nbytes) {
+    HX_HIP(ctx, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int hx_memset0(hx_context* ctx, void* dptr, size_t nbytes) {
+    HX_HIP(ctx, hipMemsetAsync(dptr, 0, nbytes, ctx->stream));
+    return 0;
+}
+
+int hx_mem_info(hx_context* ctx, size_t* out_free, size_t* out_total) {
+    HX_HIP(ctx, hipSetDevice(ctx->device));
+    HX_HIP(ctx, hipMemGetInfo(out_free, out_total));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,63 @@
+// Internal definitions shared by the translation units of libhelios_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/helios_hip.h"
+
+struct hx_context {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    char err[512];
+};
+
+inline int hx_fail(hx_context* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define HX_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return hx_fail((ctx), -(int)e_, "%s failed: %s (%s:%d)", #call,                \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+// after a kernel launch
+#define HX_LAUNCH_CHECK(ctx) HX_HIP(ctx, hipGetLastError())
+
+#define HX_REQUIRE(ctx, cond, code, msg)                                                   \
+    do {                                                                                   \
+        if (!(cond)) return hx_fail((ctx), (code), "%s: %s", __func__, (msg));             \
+    } while (0)
+
+inline int hx_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// device-side physical constants: source/kernels.cu:36-41 (values are physical constants)
+#define HX_PI 3.141592653589793
+#define HX_HCONST 6.62607004e-27
+#define HX_CSPEED 29979245800.0
+#define HX_KBOLTZMANN 1.38064852e-16
+#define HX_STEFANBOLTZMANN 5.6703669999999995e-5
+#define HX_AMU 1.6605390666e-24
+
+// internal cross-translation-unit helpers (not exported through include/helios_hip.h)
+extern "C" int hx_internal_planck_star_row(hx_context* ctx, double* row, const double* lambda_edge,
+                                           const double* deltalambda, int nwave, double Tstar);
+extern "C" int hx_internal_fdir_noniso(hx_context* ctx, double* F_dir_wg, double* Fc_dir_wg,
+                                       const double* star, int star_stride,
+                                       const double* delta_tau_wg_upper,
+                                       const double* delta_tau_wg_lower, const double* z_lay,
+                                       double mu_star, double R_planet, double R_star, double a,
+                                       int dir_beam, int geom_zenith_corr, int ninterface, int nbin,
+                                       int ny);

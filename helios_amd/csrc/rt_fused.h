@@ -1,0 +1,96 @@
+// Host-side state of the fused fast path (hx_rt).  See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <string>
+#include <vector>
+
+#include "hx_common.h"
+
+namespace hx {
+
+// How the (bin x, Gauss point y, half-layer h) space is cut into wavefront tiles.
+//
+//   * k lanes cooperate on one spectral point (x,y); lane j owns LPL whole layers
+//     [j*LPL, (j+1)*LPL) = ROWS = 2*LPL half-layers, kept in registers for all sweeps;
+//   * a wavefront holds S = 64/k spectral points; lane = s*k + j;
+//   * a workgroup covers nxb bins x ypb Gauss points (G = nxb*ypb spectral points, NW wavefronts);
+//     nparts = ny/ypb workgroups share one bin and each writes a partial Gauss sum.
+struct TileGeom {
+    int k, LPL, ROWS, S;
+    int nxb, ypb, nparts, G, NW, threads;
+    int nblk_x;       // workgroups along x per column = ceil(nbin / nxb)
+    int nblk;         // workgroups per column = nblk_x * nparts
+    int nplane;       // coefficient planes per tile: alpha, beta, u', v' (+ dd, du with the beam)
+    size_t tile_rows; // ROWS
+    size_t coef_elems_per_col, flux_elems_per_col;  // doubles
+};
+
+struct Species {
+    double* pretab = nullptr;      // device, [t][p][x][y] flat (reference order), or null
+    double* scat_cross = nullptr;  // device [nbin], or null
+    double weight = 0.0;
+    int is_h2o = 0, is_cia = 0, in_mu = 1;
+    bool absorbing = false, scattering = false;
+};
+
+struct ProfileEntry {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace hx
+
+struct hx_rt {
+    hx_context* ctx;
+    hx_rt_dims d;
+    hx_rt_flags f;
+    std::vector<hx_rt_column> cols;
+    int X, Y, L, I, H, C, nsweep;
+    hx::TileGeom g;
+    bool have_grid = false, have_tables = false, have_planck = false, refreshed = false;
+    bool keep_down = false;
+    int nchunk;  // x-chunks of the totals reduction
+
+    // shared device arrays
+    double *interwave = nullptr, *deltawave = nullptr, *wave = nullptr, *gauss_y = nullptr,
+           *gauss_w = nullptr, *ktemp = nullptr, *kpress = nullptr;
+    double *opac_k = nullptr, *opac_scat_cross = nullptr, *opac_meanmass = nullptr;
+    double* planck_grid = nullptr;  // [(dim+1) * X]; row dim = stellar row of column 0
+    std::vector<hx::Species> species;
+    double *spec_lay = nullptr, *spec_int = nullptr;      // one species interpolated, [Y*X*I]
+    double *sc_spec_lay = nullptr, *sc_spec_int = nullptr;  // one species' scattering cross-sections
+
+    // per-column device arrays (column stride given in comments, in doubles)
+    hx_rt_column* colpar = nullptr;  // [C]
+    double *p_lay = nullptr, *p_int = nullptr, *dcol_u = nullptr, *dcol_l = nullptr;  // L, I, L, L
+    double *T_lay = nullptr, *T_int = nullptr;                                        // L+1, I
+    double *surf_albedo = nullptr, *starflux = nullptr, *Bstar = nullptr;             // X each
+    double *opac_wg_lay = nullptr, *opac_wg_int = nullptr;                            // Y*X*I each
+    double *scat_cross_lay = nullptr, *scat_cross_int = nullptr;                      // X*I each
+    double *mmm_lay = nullptr, *mmm_int = nullptr;                                    // I each
+    double *cl_abs_lay = nullptr, *cl_abs_int = nullptr, *cl_sc_lay = nullptr, *cl_sc_int = nullptr,
+           *cl_g0_lay = nullptr, *cl_g0_int = nullptr, *g0_tot_lay = nullptr, *g0_tot_int = nullptr;  // X*I
+    double *vmr_lay = nullptr, *vmr_int = nullptr;                                    // nspecies*I
+    double *delta_z = nullptr, *z_lay = nullptr;                                      // L
+    double *dtau_u = nullptr, *dtau_l = nullptr;                                      // Y*X*L (beam only)
+    double *F_dir_wg = nullptr, *Fc_dir_wg = nullptr;                                 // Y*X*I (beam only)
+    double* F_dir_band_n = nullptr;                                                   // [x][i], X*I
+    double* Bn = nullptr;       // node Planck [x][H+3]
+    double* coef = nullptr;     // coefficient tiles
+    double* Utile = nullptr;    // up-flux state tiles
+    double* Dtile = nullptr;    // down-flux tiles (only with keep_down)
+    double *U0 = nullptr, *boaK = nullptr, *Fdir0 = nullptr;  // per spectral point, Y*X
+    double* band_part = nullptr;  // [part][x][dir][i]
+    double *F_down_band_n = nullptr, *F_up_band_n = nullptr;  // [x][i]
+    double* tot_part = nullptr;  // [chunk][dir][i]
+    double *F_up_tot = nullptr, *F_down_tot = nullptr, *F_net = nullptr, *F_net_diff = nullptr;  // I
+    double *T_store = nullptr, *prefactor = nullptr;                                            // L+1
+    double *F_add_heat_lay = nullptr, *F_add_heat_sum = nullptr, *F_smooth = nullptr,
+           *F_smooth_sum = nullptr, *c_p_lay = nullptr;                                         // L
+    int *abort_flags = nullptr, *conv_count = nullptr, *done = nullptr, *iters_done = nullptr;  // L+1,1,1,1
+
+    // profiling
+    bool profiling = false;
+    std::vector<hx::ProfileEntry> prof;
+    std::vector<std::pair<std::string, std::pair<double, int>>> prof_acc;
+    std::vector<void*> allocs;
+};

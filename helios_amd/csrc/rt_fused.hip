@@ -1,0 +1,967 @@
+// Fused fast path (include/helios_hip.h section 4): device-resident state for a batch of
+// atmosphere columns, one call per opacity refresh and one per iteration.
+//
+// Replaces the body of Compute.radiation_loop (reference source/computation.py:851-984):
+//   refresh  = :860-879  (opacities, mean molecular mass, [species mixing], transmission, dz, beam)
+//   step     = :856-857 + :880-888 + :926-932 (T_int, Planck, 3*scat+1 sweeps, integrate, T step)
+#include "rt_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace hx;
+
+namespace {
+
+int rt_fail(hx_rt* rt, int code, const char* msg) { return hx_fail(rt->ctx, code, "%s", msg); }
+
+template <class T>
+int dev_alloc(hx_rt* rt, T** p, size_t n, bool zero = true) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess)
+        return hx_fail(rt->ctx, -(int)e, "hipMalloc of %zu bytes failed: %s", n * sizeof(T),
+                       hipGetErrorString(e));
+    if (zero) {
+        e = hipMemsetAsync(q, 0, n * sizeof(T), rt->ctx->stream);
+        if (e != hipSuccess) return hx_fail(rt->ctx, -(int)e, "hipMemset failed");
+    }
+    rt->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+
+#define RT_ALLOC(ptr, n)                        \
+    do {                                        \
+        int rc_ = dev_alloc(rt, &(ptr), (n));   \
+        if (rc_) return rc_;                    \
+    } while (0)
+
+int h2d(hx_rt* rt, void* dst, const void* src, size_t bytes) {
+    return hx_h2d(rt->ctx, dst, src, bytes);
+}
+
+bool choose_geometry(int L, int Y, int X, int dir_beam, TileGeom& g) {
+    int best_k = 0, best_lpl = 0, best_pad = 1 << 30;
+    for (int k = 8; k <= 64; k <<= 1) {
+        const int lpl = (L + k - 1) / k;
+        if (lpl > 8) continue;
+        const int pad = k * lpl - L;
+        if (pad < best_pad) {
+            best_pad = pad;
+            best_k = k;
+            best_lpl = lpl;
+        }
+    }
+    if (!best_k) return false;
+    g.k = best_k;
+    g.LPL = best_lpl;
+    g.ROWS = 2 * best_lpl;
+    g.S = 64 / g.k;
+    // Gauss points per workgroup: the largest divisor of ny with ypb*k <= 320 threads
+    g.ypb = 0;
+    for (int v = 1; v <= Y; v++)
+        if (Y % v == 0 && v * g.k <= 320) g.ypb = v;
+    if (!g.ypb) return false;
+    g.nparts = Y / g.ypb;
+    g.nxb = (g.ypb == Y) ? std::max(1, 320 / (g.ypb * g.k)) : 1;
+    g.nxb = std::min(g.nxb, X);
+    g.G = g.nxb * g.ypb;
+    g.NW = (g.G * g.k + 63) / 64;
+    g.threads = g.NW * 64;
+    g.nblk_x = (X + g.nxb - 1) / g.nxb;
+    g.nblk = g.nblk_x * g.nparts;
+    g.nplane = dir_beam ? 6 : 4;
+    g.tile_rows = g.ROWS;
+    g.coef_elems_per_col = (size_t)g.nblk * g.NW * g.nplane * g.ROWS * 64;
+    g.flux_elems_per_col = (size_t)g.nblk * g.NW * g.ROWS * 64;
+    return true;
+}
+
+KArgs make_args(hx_rt* rt) {
+    KArgs a;
+    memset(&a, 0, sizeof(a));
+    const TileGeom& g = rt->g;
+    a.X = rt->X; a.Y = rt->Y; a.L = rt->L; a.I = rt->I; a.H = rt->H; a.C = rt->C;
+    a.k = g.k; a.LPL = g.LPL; a.ROWS = g.ROWS; a.S = g.S; a.nxb = g.nxb; a.ypb = g.ypb;
+    a.nparts = g.nparts; a.G = g.G; a.NW = g.NW; a.nblk_x = g.nblk_x; a.nblk = g.nblk;
+    a.nplane = g.nplane; a.nchunk = rt->nchunk;
+    a.scat = rt->f.scat; a.dir_beam = rt->f.dir_beam; a.clouds = rt->f.clouds;
+    a.scat_corr = rt->f.scat_corr; a.nsweep = rt->nsweep; a.keep_down = rt->keep_down ? 1 : 0;
+    a.real_star = rt->f.real_star;
+    a.dim = rt->d.plancktable_dim; a.step = rt->d.plancktable_step;
+    a.epsi = rt->f.epsi; a.epsi2 = rt->f.epsi2; a.g_0 = rt->f.g_0; a.i2s = rt->f.i2s_transition;
+    a.w_0_limit = rt->f.w_0_limit; a.w_0_scat_limit = rt->f.w_0_scat_limit;
+    a.dtau_limit = rt->f.delta_tau_limit;
+    a.colpar = rt->colpar;
+    a.T_lay = rt->T_lay; a.p_lay = rt->p_lay; a.p_int = rt->p_int; a.dcol_u = rt->dcol_u;
+    a.dcol_l = rt->dcol_l; a.surf_albedo = rt->surf_albedo; a.Bstar = rt->Bstar;
+    a.planck_grid = rt->planck_grid;
+    a.opac_wg_lay = rt->opac_wg_lay; a.opac_wg_int = rt->opac_wg_int;
+    a.scat_cross_lay = rt->scat_cross_lay; a.scat_cross_int = rt->scat_cross_int;
+    a.mmm_lay = rt->mmm_lay; a.mmm_int = rt->mmm_int;
+    a.cl_abs_lay = rt->cl_abs_lay; a.cl_abs_int = rt->cl_abs_int; a.cl_sc_lay = rt->cl_sc_lay;
+    a.cl_sc_int = rt->cl_sc_int; a.g0_tot_lay = rt->g0_tot_lay; a.g0_tot_int = rt->g0_tot_int;
+    a.F_dir_wg = rt->F_dir_wg; a.Fc_dir_wg = rt->Fc_dir_wg; a.F_dir_band_n = rt->F_dir_band_n;
+    a.gauss_w = rt->gauss_w; a.deltawave = rt->deltawave;
+    a.T_int = rt->T_int; a.Bn = rt->Bn; a.coef = rt->coef; a.Utile = rt->Utile; a.Dtile = rt->Dtile;
+    a.U0 = rt->U0; a.boaK = rt->boaK; a.Fdir0 = rt->Fdir0; a.band_part = rt->band_part;
+    a.dtau_u = rt->dtau_u; a.dtau_l = rt->dtau_l;
+    a.F_down_band_n = rt->F_down_band_n; a.F_up_band_n = rt->F_up_band_n; a.tot_part = rt->tot_part;
+    a.F_up_tot = rt->F_up_tot; a.F_down_tot = rt->F_down_tot; a.F_net = rt->F_net;
+    a.coef_col = g.coef_elems_per_col; a.flux_col = g.flux_elems_per_col;
+    a.done = rt->done;
+    return a;
+}
+
+// ---- profiling helpers ------------------------------------------------------------------------
+struct ProfScope {
+    hx_rt* rt;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char* name;
+    ProfScope(hx_rt* r, const char* n) : rt(r), name(n) {
+        if (!rt->profiling) return;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, rt->ctx->stream);
+    }
+    ~ProfScope() {
+        if (!rt->profiling) return;
+        (void)hipEventRecord(e1, rt->ctx->stream);
+        rt->prof.push_back({name, e0, e1});
+        if (rt->prof.size() > 8192) flush(rt);
+    }
+    static void flush(hx_rt* rt) {
+        for (auto& p : rt->prof) {
+            (void)hipEventSynchronize(p.e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, p.e0, p.e1);
+            bool found = false;
+            for (auto& acc : rt->prof_acc)
+                if (acc.first == p.name) {
+                    acc.second.first += ms;
+                    acc.second.second += 1;
+                    found = true;
+                }
+            if (!found) rt->prof_acc.push_back({p.name, {ms, 1}});
+            (void)hipEventDestroy(p.e0);
+            (void)hipEventDestroy(p.e1);
+        }
+        rt->prof.clear();
+    }
+};
+
+template <int LPL>
+void launch_flux(hx_rt* rt, const KArgs& a) {
+    const TileGeom& g = rt->g;
+    const size_t shmem = ((size_t)g.nxb * (rt->H + 3) + (size_t)g.ypb * g.nxb * 2 * rt->I) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<LPL>), dim3(g.nblk, rt->C), dim3(g.threads), shmem,
+                       rt->ctx->stream, a);
+}
+template <int LPL>
+void launch_coef(hx_rt* rt, const KArgs& a) {
+    const TileGeom& g = rt->g;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<LPL>), dim3(g.nblk, rt->C), dim3(g.threads), 0,
+                       rt->ctx->stream, a);
+}
+
+#define DISPATCH_LPL(fn, rt, a)                   \
+    switch ((rt)->g.LPL) {                        \
+        case 1: fn<1>(rt, a); break;              \
+        case 2: fn<2>(rt, a); break;              \
+        case 3: fn<3>(rt, a); break;              \
+        case 4: fn<4>(rt, a); break;              \
+        case 5: fn<5>(rt, a); break;              \
+        case 6: fn<6>(rt, a); break;              \
+        case 7: fn<7>(rt, a); break;              \
+        default: fn<8>(rt, a); break;             \
+    }
+
+int set_flux_shmem_limits(hx_rt* rt) {
+    const TileGeom& g = rt->g;
+    const size_t shmem = ((size_t)g.nxb * (rt->H + 3) + (size_t)g.ypb * g.nxb * 2 * rt->I) * sizeof(double);
+    if (shmem > 160 * 1024) return rt_fail(rt, HX_E_UNSUPPORTED, "workgroup LDS demand exceeds 160 KiB");
+    if (shmem <= 64 * 1024) return 0;
+    const void* fns[8] = {(const void*)k_rt_flux<1>, (const void*)k_rt_flux<2>, (const void*)k_rt_flux<3>,
+                          (const void*)k_rt_flux<4>, (const void*)k_rt_flux<5>, (const void*)k_rt_flux<6>,
+                          (const void*)k_rt_flux<7>, (const void*)k_rt_flux<8>};
+    HX_HIP(rt->ctx, hipFuncSetAttribute(fns[rt->g.LPL - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)shmem));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hx_rt_struct_sizes(int* dims_size, int* flags_size, int* column_size) {
+    if (dims_size) *dims_size = (int)sizeof(hx_rt_dims);
+    if (flags_size) *flags_size = (int)sizeof(hx_rt_flags);
+    if (column_size) *column_size = (int)sizeof(hx_rt_column);
+    return 0;
+}
+
+int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* flags,
+                 const hx_rt_column* columns, hx_rt** out_rt) {
+    if (!ctx || !dims || !flags || !columns || !out_rt) return HX_E_ARG;
+    *out_rt = nullptr;
+    HX_REQUIRE(ctx, dims->nbin > 0 && dims->ny > 0 && dims->nlayer >= 2 && dims->ncol > 0, HX_E_ARG,
+               "bad dimensions");
+    HX_REQUIRE(ctx, dims->plancktable_dim >= 10 && dims->plancktable_step > 0, HX_E_ARG,
+               "bad Planck-table dimensions");
+    HX_HIP(ctx, hipSetDevice(ctx->device));
+    hx_rt* rt = new hx_rt();
+    rt->ctx = ctx;
+    rt->d = *dims;
+    rt->f = *flags;
+    rt->cols.assign(columns, columns + dims->ncol);
+    rt->X = dims->nbin; rt->Y = dims->ny; rt->L = dims->nlayer; rt->I = rt->L + 1; rt->H = 2 * rt->L;
+    rt->C = dims->ncol;
+    rt->nsweep = 3 * (flags->scat ? 1 : 0) + 1;  // computation.py:531-537 (iterative run type)
+    if (!choose_geometry(rt->L, rt->Y, rt->X, flags->dir_beam, rt->g) || 2 * rt->I > 1024) {
+        delete rt;
+        return hx_fail(ctx, HX_E_UNSUPPORTED,
+                       "fused path supports nlayer <= 511 and ny*k <= 320 tiles; use the per-stage API");
+    }
+    rt->nchunk = std::max(1, std::min(128, (rt->X + 63) / 64));
+    rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
+    int rc = set_flux_shmem_limits(rt);
+    if (rc) { delete rt; return rc; }
+
+    const size_t X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, C = rt->C, nc = X * Y;
+    RT_ALLOC(rt->interwave, X + 1); RT_ALLOC(rt->deltawave, X); RT_ALLOC(rt->wave, X);
+    RT_ALLOC(rt->gauss_y, Y); RT_ALLOC(rt->gauss_w, Y);
+    RT_ALLOC(rt->ktemp, dims->ntemp); RT_ALLOC(rt->kpress, dims->npress);
+    RT_ALLOC(rt->planck_grid, (size_t)(dims->plancktable_dim + 1) * X);
+    RT_ALLOC(rt->colpar, C);
+    RT_ALLOC(rt->p_lay, C * L); RT_ALLOC(rt->p_int, C * I); RT_ALLOC(rt->dcol_u, C * L);
+    RT_ALLOC(rt->dcol_l, C * L); RT_ALLOC(rt->T_lay, C * (L + 1)); RT_ALLOC(rt->T_int, C * I);
+    RT_ALLOC(rt->surf_albedo, C * X); RT_ALLOC(rt->starflux, C * X); RT_ALLOC(rt->Bstar, C * X);
+    RT_ALLOC(rt->opac_wg_lay, C * nc * I); RT_ALLOC(rt->opac_wg_int, C * nc * I);
+    RT_ALLOC(rt->scat_cross_lay, C * X * I); RT_ALLOC(rt->scat_cross_int, C * X * I);
+    RT_ALLOC(rt->mmm_lay, C * I); RT_ALLOC(rt->mmm_int, C * I);
+    RT_ALLOC(rt->cl_abs_lay, C * X * I); RT_ALLOC(rt->cl_abs_int, C * X * I);
+    RT_ALLOC(rt->cl_sc_lay, C * X * I); RT_ALLOC(rt->cl_sc_int, C * X * I);
+    if (flags->clouds) {
+        RT_ALLOC(rt->cl_g0_lay, C * X * I); RT_ALLOC(rt->cl_g0_int, C * X * I);
+    }
+    RT_ALLOC(rt->g0_tot_lay, C * X * I); RT_ALLOC(rt->g0_tot_int, C * X * I);
+    if (dims->nspecies > 0) {
+        RT_ALLOC(rt->vmr_lay, C * dims->nspecies * I); RT_ALLOC(rt->vmr_int, C * dims->nspecies * I);
+        RT_ALLOC(rt->spec_lay, nc * I); RT_ALLOC(rt->spec_int, nc * I);
+        RT_ALLOC(rt->sc_spec_lay, X * I); RT_ALLOC(rt->sc_spec_int, X * I);
+    }
+    RT_ALLOC(rt->delta_z, C * L); RT_ALLOC(rt->z_lay, C * L);
+    if (flags->dir_beam) {
+        RT_ALLOC(rt->dtau_u, C * nc * L); RT_ALLOC(rt->dtau_l, C * nc * L);
+        RT_ALLOC(rt->F_dir_wg, C * nc * I); RT_ALLOC(rt->Fc_dir_wg, C * nc * I);
+    }
+    RT_ALLOC(rt->F_dir_band_n, C * X * I);
+    RT_ALLOC(rt->Bn, C * X * (rt->H + 3));
+    RT_ALLOC(rt->coef, C * rt->g.coef_elems_per_col);
+    RT_ALLOC(rt->Utile, C * rt->g.flux_elems_per_col);
+    RT_ALLOC(rt->U0, C * nc); RT_ALLOC(rt->boaK, C * nc); RT_ALLOC(rt->Fdir0, C * nc);
+    RT_ALLOC(rt->band_part, C * rt->g.nparts * X * 2 * I);
+    RT_ALLOC(rt->F_down_band_n, C * X * I); RT_ALLOC(rt->F_up_band_n, C * X * I);
+    RT_ALLOC(rt->tot_part, C * rt->nchunk * 2 * I);
+    RT_ALLOC(rt->F_up_tot, C * I); RT_ALLOC(rt->F_down_tot, C * I); RT_ALLOC(rt->F_net, C * I);
+    RT_ALLOC(rt->F_net_diff, C * L);
+    RT_ALLOC(rt->T_store, C * (L + 1)); RT_ALLOC(rt->prefactor, C * (L + 1));
+    RT_ALLOC(rt->F_add_heat_lay, C * L); RT_ALLOC(rt->F_add_heat_sum, C * L);
+    RT_ALLOC(rt->F_smooth, C * L); RT_ALLOC(rt->F_smooth_sum, C * L); RT_ALLOC(rt->c_p_lay, C * L);
+    RT_ALLOC(rt->abort_flags, C * (L + 1)); RT_ALLOC(rt->conv_count, C); RT_ALLOC(rt->done, C);
+    RT_ALLOC(rt->iters_done, C);
+    rc = h2d(rt, rt->colpar, rt->cols.data(), C * sizeof(hx_rt_column));
+    if (rc) return rc;
+    *out_rt = rt;
+    return 0;
+}
+
+int hx_rt_destroy(hx_rt* rt) {
+    if (!rt) return 0;
+    (void)hipStreamSynchronize(rt->ctx->stream);
+    ProfScope::flush(rt);
+    for (void* p : rt->allocs) (void)hipFree(p);
+    delete rt;
+    return 0;
+}
+
+int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_deltawave,
+                   const double* opac_wave, const double* gauss_y, const double* gauss_weight,
+                   const double* ktemp, const double* kpress) {
+    int rc = 0;
+    rc |= h2d(rt, rt->interwave, opac_interwave, (rt->X + 1) * 8);
+    rc |= h2d(rt, rt->deltawave, opac_deltawave, rt->X * 8);
+    rc |= h2d(rt, rt->wave, opac_wave, rt->X * 8);
+    rc |= h2d(rt, rt->gauss_y, gauss_y, rt->Y * 8);
+    rc |= h2d(rt, rt->gauss_w, gauss_weight, rt->Y * 8);
+    rc |= h2d(rt, rt->ktemp, ktemp, rt->d.ntemp * 8);
+    rc |= h2d(rt, rt->kpress, kpress, rt->d.npress * 8);
+    rt->have_grid = rc == 0;
+    return rc;
+}
+
+int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opac_scat_cross,
+                              const double* opac_meanmass) {
+    HX_REQUIRE(rt->ctx, rt->d.nspecies == 0, HX_E_STATE, "object was created for on-the-fly mixing");
+    const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
+    if (!rt->opac_k) {
+        RT_ALLOC(rt->opac_k, ntp * rt->X * rt->Y);
+        RT_ALLOC(rt->opac_scat_cross, ntp * rt->X);
+        RT_ALLOC(rt->opac_meanmass, ntp);
+    }
+    int rc = 0;
+    rc |= h2d(rt, rt->opac_k, opac_k, ntp * rt->X * rt->Y * 8);
+    rc |= h2d(rt, rt->opac_scat_cross, opac_scat_cross, ntp * rt->X * 8);
+    rc |= h2d(rt, rt->opac_meanmass, opac_meanmass, ntp * 8);
+    rt->have_tables = rc == 0;
+    return rc;
+}
+
+int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const double* scat_cross,
+                      double weight, int is_h2o, int is_cia, int in_mu) {
+    HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
+    Species& sp = rt->species[s];
+    const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
+    sp.weight = weight; sp.is_h2o = is_h2o; sp.is_cia = is_cia; sp.in_mu = in_mu;
+    if (opacity_pretab) {
+        if (!sp.pretab) RT_ALLOC(sp.pretab, ntp * rt->X * rt->Y);
+        int rc = h2d(rt, sp.pretab, opacity_pretab, ntp * rt->X * rt->Y * 8);
+        if (rc) return rc;
+        sp.absorbing = true;
+    }
+    if (scat_cross) {
+        if (!sp.scat_cross) RT_ALLOC(sp.scat_cross, rt->X);
+        int rc = h2d(rt, sp.scat_cross, scat_cross, rt->X * 8);
+        if (rc) return rc;
+        sp.scattering = true;
+    }
+    if (is_h2o == 2) sp.scattering = true;  // H2O with computed Rayleigh cross-section
+    rt->have_tables = true;
+    return 0;
+}
+
+static int for_cols(hx_rt* rt, int col, int* c0, int* c1) {
+    if (col < 0) { *c0 = 0; *c1 = rt->C; return 0; }
+    if (col >= rt->C) return rt_fail(rt, HX_E_ARG, "column index out of range");
+    *c0 = col; *c1 = col + 1;
+    return 0;
+}
+
+int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const double* p_int,
+                             const double* T_lay, const double* surf_albedo,
+                             const double* starflux) {
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    const size_t L = rt->L, I = rt->I, X = rt->X;
+    for (int c = c0; c < c1; c++) {
+        std::vector<double> du(L), dl(L);
+        const double g = rt->cols[c].g;
+        for (size_t i = 0; i < L; i++) {  // host_functions.py:731-735
+            du[i] = (p_lay[i] - p_int[i + 1]) / g;
+            dl[i] = (p_int[i] - p_lay[i]) / g;
+        }
+        rc |= h2d(rt, rt->p_lay + c * L, p_lay, L * 8);
+        rc |= h2d(rt, rt->p_int + c * I, p_int, I * 8);
+        rc |= h2d(rt, rt->dcol_u + c * L, du.data(), L * 8);
+        rc |= h2d(rt, rt->dcol_l + c * L, dl.data(), L * 8);
+        rc |= h2d(rt, rt->T_lay + c * (L + 1), T_lay, (L + 1) * 8);
+        if (surf_albedo) rc |= h2d(rt, rt->surf_albedo + c * X, surf_albedo, X * 8);
+        if (starflux) rc |= h2d(rt, rt->starflux + c * X, starflux, X * 8);
+    }
+    return rc;
+}
+
+int hx_rt_set_column_vmr(hx_rt* rt, int col, const double* vmr_lay, const double* vmr_int) {
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    HX_REQUIRE(rt->ctx, rt->d.nspecies > 0, HX_E_STATE, "no species in a premixed object");
+    const size_t S = rt->d.nspecies, I = rt->I, L = rt->L;
+    // internal stride is I for both (layer rows use the first L entries)
+    std::vector<double> tmp(S * I, 0.0);
+    for (int c = c0; c < c1; c++) {
+        for (size_t s = 0; s < S; s++) std::copy(vmr_lay + s * L, vmr_lay + (s + 1) * L, tmp.begin() + s * I);
+        rc |= h2d(rt, rt->vmr_lay + c * S * I, tmp.data(), S * I * 8);
+        rc |= h2d(rt, rt->vmr_int + c * S * I, vmr_int, S * I * 8);
+    }
+    return rc;
+}
+
+int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
+                            const double* abs_cross_int, const double* scat_cross_lay,
+                            const double* scat_cross_int, const double* g_0_lay,
+                            const double* g_0_int) {
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    HX_REQUIRE(rt->ctx, rt->f.clouds == 1, HX_E_STATE, "object was created with clouds = 0");
+    const size_t XL = (size_t)rt->X * rt->L, XI = (size_t)rt->X * rt->I;
+    for (int c = c0; c < c1; c++) {
+        rc |= h2d(rt, rt->cl_abs_lay + c * XI, abs_cross_lay, XL * 8);
+        rc |= h2d(rt, rt->cl_abs_int + c * XI, abs_cross_int, XI * 8);
+        rc |= h2d(rt, rt->cl_sc_lay + c * XI, scat_cross_lay, XL * 8);
+        rc |= h2d(rt, rt->cl_sc_int + c * XI, scat_cross_int, XI * 8);
+        rc |= h2d(rt, rt->cl_g0_lay + c * XI, g_0_lay, XL * 8);
+        rc |= h2d(rt, rt->cl_g0_int + c * XI, g_0_int, XI * 8);
+    }
+    return rc;
+}
+
+int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
+                             const double* F_add_heat_sum) {
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    for (int c = c0; c < c1; c++) {
+        rc |= h2d(rt, rt->F_add_heat_lay + (size_t)c * rt->L, F_add_heat_lay, rt->L * 8);
+        rc |= h2d(rt, rt->F_add_heat_sum + (size_t)c * rt->L, F_add_heat_sum, rt->L * 8);
+    }
+    return rc;
+}
+
+int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    for (int c = c0; c < c1; c++) rc |= h2d(rt, rt->T_lay + (size_t)c * (rt->L + 1), T_lay, (rt->L + 1) * 8);
+    return rc;
+}
+
+int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    for (int c = c0; c < c1; c++) {
+        rt->cols[c].rad_convergence_limit = limit;
+        rc |= h2d(rt, &rt->colpar[c], &rt->cols[c], sizeof(hx_rt_column));
+    }
+    return rc;
+}
+
+
+int hx_rt_build_planck_table(hx_rt* rt, int energy_correction) {
+    HX_REQUIRE(rt->ctx, rt->have_grid, HX_E_STATE, "hx_rt_set_grid first");
+    hx_context* ctx = rt->ctx;
+    const int X = rt->X, dim = rt->d.plancktable_dim, step = rt->d.plancktable_step;
+    // rows 0..dim-1 depend on the wavelength grid only and are shared by all columns; row `dim`
+    // (stellar row of column 0) is kept for layout compatibility with the reference's table
+    int rc = hx_plancktable(ctx, rt->planck_grid, rt->interwave, rt->deltawave, X, rt->cols[0].T_star,
+                            dim, step);
+    if (rc) return rc;
+    for (int c = 0; c < rt->C; c++) {
+        const double Ts = rt->cols[c].T_star;
+        double* brow = rt->Bstar + (size_t)c * X;
+        double* sflux = rt->starflux + (size_t)c * X;
+        rc = hx_internal_planck_star_row(ctx, brow, rt->interwave, rt->deltawave, X, Ts);
+        if (rc) return rc;
+        // computation.py:65: only if energy_correction == 1 and T_star > 10
+        if (energy_correction == 1 && Ts > 10) {
+            // dim = 0: the "table" passed is just the stellar row
+            rc = hx_corr_inc_energy(ctx, brow, sflux, rt->deltawave, rt->f.real_star, X, Ts, 0);
+            if (rc) return rc;
+        }
+        if (rt->f.real_star == 1) {
+            // planckband_lay[star] = starflux / pi (kernels.cu:945)
+            std::vector<double> tmp(X);
+            rc = hx_d2h(ctx, tmp.data(), sflux, X * 8);
+            if (rc) return rc;
+            for (auto& v : tmp) v = v / HX_PI;
+            rc = h2d(rt, brow, tmp.data(), X * 8);
+            if (rc) return rc;
+        }
+        if (c == 0) {
+            rc = hx_d2d(ctx, rt->planck_grid + (size_t)dim * X, brow, X * 8);
+            if (rc) return rc;
+        }
+    }
+    rt->have_planck = true;
+    return 0;
+}
+
+static int read_done(hx_rt* rt, std::vector<int>& done) {
+    done.resize(rt->C);
+    return hx_d2h(rt->ctx, done.data(), rt->done, rt->C * sizeof(int));
+}
+
+int hx_rt_refresh(hx_rt* rt) {
+    hx_context* ctx = rt->ctx;
+    HX_REQUIRE(ctx, rt->have_grid && rt->have_tables && rt->have_planck, HX_E_STATE,
+               "set grid, tables and build the Planck table first");
+    const int X = rt->X, Y = rt->Y, L = rt->L, I = rt->I;
+    const size_t nc = (size_t)X * Y, wgI = nc * I, bandI = (size_t)X * I;
+    std::vector<int> done;
+    int rc = read_done(rt, done);
+    if (rc) return rc;
+    KArgs a = make_args(rt);
+    {   // interface temperatures (and node Planck values) of the CURRENT layer temperatures
+        ProfScope ps(rt, "rt_nodes");
+        dim3 grid(hx_cdiv(X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
+        k_rt_nodes<<<grid, 256, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    ProfScope ps_all(rt, "refresh_total");
+    for (int c = 0; c < rt->C; c++) {
+        if (done[c]) continue;
+        const double* T_lay = rt->T_lay + (size_t)c * (L + 1);
+        const double* T_int = rt->T_int + (size_t)c * I;
+        const double* p_lay = rt->p_lay + (size_t)c * L;
+        const double* p_int = rt->p_int + (size_t)c * I;
+        double* opl = rt->opac_wg_lay + c * wgI;
+        double* opi = rt->opac_wg_int + c * wgI;
+        double* scl = rt->scat_cross_lay + c * bandI;
+        double* sci = rt->scat_cross_int + c * bandI;
+        double* mml = rt->mmm_lay + (size_t)c * I;
+        double* mmi = rt->mmm_int + (size_t)c * I;
+        if (rt->d.nspecies == 0) {
+            ProfScope ps(rt, "opac_interpol");
+            rc = hx_opac_interpol(ctx, T_lay, rt->ktemp, p_lay, rt->kpress, rt->opac_k, opl,
+                                  rt->opac_scat_cross, scl, rt->d.npress, rt->d.ntemp, Y, X, L);
+            if (rc) return rc;
+            rc = hx_opac_interpol(ctx, T_int, rt->ktemp, p_int, rt->kpress, rt->opac_k, opi,
+                                  rt->opac_scat_cross, sci, rt->d.npress, rt->d.ntemp, Y, X, I);
+            if (rc) return rc;
+            rc = hx_meanmolmass_interpol(ctx, T_lay, rt->ktemp, mml, rt->opac_meanmass, p_lay, rt->kpress,
+                                         rt->d.npress, rt->d.ntemp, L);
+            if (rc) return rc;
+            rc = hx_meanmolmass_interpol(ctx, T_int, rt->ktemp, mmi, rt->opac_meanmass, p_int, rt->kpress,
+                                         rt->d.npress, rt->d.ntemp, I);
+            if (rc) return rc;
+        } else {
+            // on-the-fly mixing, computation.py:1454-1501 (tables stay resident on the device; the
+            // reference re-uploads every species table on every refresh)
+            const int S = rt->d.nspecies;
+            const double* vl = rt->vmr_lay + (size_t)c * S * I;
+            const double* vi = rt->vmr_int + (size_t)c * S * I;
+            {   // mean molecular mass from the mixing ratios (host_functions.py:913-959)
+                std::vector<double> w(S);
+                std::vector<int> inmu(S);
+                for (int s = 0; s < S; s++) { w[s] = rt->species[s].weight; inmu[s] = rt->species[s].in_mu; }
+                double* dw = nullptr; int* dm = nullptr;
+                HX_HIP(ctx, hipMalloc((void**)&dw, S * 8));
+                HX_HIP(ctx, hipMalloc((void**)&dm, S * 4));
+                h2d(rt, dw, w.data(), S * 8);
+                h2d(rt, dm, inmu.data(), S * 4);
+                k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vl, dw, dm, mml, S, I);
+                k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vi, dw, dm, mmi, S, I);
+                HX_LAUNCH_CHECK(ctx);
+                HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipFree(dw);
+                (void)hipFree(dm);
+            }
+            hx_memset0(ctx, opl, wgI * 8);
+            hx_memset0(ctx, opi, wgI * 8);
+            hx_memset0(ctx, scl, bandI * 8);
+            hx_memset0(ctx, sci, bandI * 8);
+            for (int s = 0; s < S; s++) {
+                const Species& sp = rt->species[s];
+                if (sp.absorbing) {
+                    {
+                        ProfScope ps(rt, "opac_species_interpol");
+                        rc = hx_opac_species_interpol(ctx, T_lay, rt->ktemp, p_lay, rt->kpress, sp.pretab,
+                                                      rt->spec_lay, rt->d.npress, rt->d.ntemp, Y, X, L);
+                        if (rc) return rc;
+                        rc = hx_opac_species_interpol(ctx, T_int, rt->ktemp, p_int, rt->kpress, sp.pretab,
+                                                      rt->spec_int, rt->d.npress, rt->d.ntemp, Y, X, I);
+                        if (rc) return rc;
+                    }
+                    ProfScope ps(rt, "add_to_mixed_opac");
+                    const int ro = (rt->f.kcoeff_mixing_ro && !sp.is_cia) ? 1 : 0;  // computation.py:1343
+                    const double mass = sp.weight * HX_AMU;
+                    rc = hx_add_to_mixed_opac(ctx, vl + (size_t)s * I, rt->spec_lay, opl, mml, rt->gauss_w,
+                                              rt->gauss_y, mass, s, ro, Y, X, L);
+                    if (rc) return rc;
+                    rc = hx_add_to_mixed_opac(ctx, vi + (size_t)s * I, rt->spec_int, opi, mmi, rt->gauss_w,
+                                              rt->gauss_y, mass, s, ro, Y, X, I);
+                    if (rc) return rc;
+                }
+                if (sp.scattering) {
+                    ProfScope ps(rt, "mixed_scat");
+                    if (sp.is_h2o) {
+                        const double mass = sp.weight * HX_AMU;
+                        rc = hx_calc_h2o_scat(ctx, T_lay, p_lay, rt->wave, rt->sc_spec_lay, vl + (size_t)s * I,
+                                              mass, X, L);
+                        if (rc) return rc;
+                        rc = hx_calc_h2o_scat(ctx, T_int, p_int, rt->wave, rt->sc_spec_int, vi + (size_t)s * I,
+                                              mass, X, I);
+                        if (rc) return rc;
+                    } else {
+                        // the reference tiles the [nbin] cross-section over the levels on the host
+                        // (read.py:1642-1645) and uploads it; here the broadcast happens on the device
+                        k_rt_tile_rows<<<dim3(hx_cdiv(X, 256), L), 256, 0, ctx->stream>>>(sp.scat_cross,
+                                                                                         rt->sc_spec_lay, X, L);
+                        k_rt_tile_rows<<<dim3(hx_cdiv(X, 256), I), 256, 0, ctx->stream>>>(sp.scat_cross,
+                                                                                         rt->sc_spec_int, X, I);
+                        HX_LAUNCH_CHECK(ctx);
+                    }
+                    rc = hx_add_to_mixed_scat(ctx, vl + (size_t)s * I, rt->sc_spec_lay, scl, X, L);
+                    if (rc) return rc;
+                    rc = hx_add_to_mixed_scat(ctx, vi + (size_t)s * I, rt->sc_spec_int, sci, X, I);
+                    if (rc) return rc;
+                }
+            }
+        }
+        if (rt->f.clouds) {
+            rc = hx_calc_total_g_0_of_gas_and_clouds(ctx, scl, rt->cl_g0_lay + c * bandI,
+                                                     rt->cl_sc_lay + c * bandI, rt->g0_tot_lay + c * bandI,
+                                                     rt->f.g_0, X, L);
+            if (rc) return rc;
+            rc = hx_calc_total_g_0_of_gas_and_clouds(ctx, sci, rt->cl_g0_int + c * bandI,
+                                                     rt->cl_sc_int + c * bandI, rt->g0_tot_int + c * bandI,
+                                                     rt->f.g_0, X, I);
+            if (rc) return rc;
+        }
+        rc = hx_calc_delta_z(ctx, T_lay, p_int, p_lay, mml, rt->delta_z + (size_t)c * L, rt->cols[c].g, L);
+        if (rc) return rc;
+    }
+    k_rt_height<<<rt->C, 64, 0, ctx->stream>>>(rt->p_lay, rt->delta_z, rt->z_lay, L, rt->f.planet_type_gas, (size_t)L);
+    HX_LAUNCH_CHECK(ctx);
+    if (rt->f.dir_beam) {
+        ProfScope ps(rt, "direct_beam");
+        k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, rt->C), 256, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
+        for (int c = 0; c < rt->C; c++) {
+            if (done[c]) continue;
+            const hx_rt_column& cp = rt->cols[c];
+            rc = hx_internal_fdir_noniso(ctx, rt->F_dir_wg + c * wgI, rt->Fc_dir_wg + c * wgI,
+                                         rt->Bstar + (size_t)c * X, 1, rt->dtau_u + c * nc * L,
+                                         rt->dtau_l + c * nc * L, rt->z_lay + (size_t)c * L, cp.mu_star,
+                                         cp.R_planet, cp.R_star, cp.a, rt->f.dir_beam,
+                                         rt->f.geom_zenith_corr, I, X, Y);
+            if (rc) return rc;
+            k_rt_fdir_band<<<dim3(hx_cdiv(X, 256), I), 256, 0, ctx->stream>>>(
+                rt->F_dir_wg + c * wgI, rt->F_dir_band_n + c * bandI, rt->gauss_w, X, Y, I);
+            HX_LAUNCH_CHECK(ctx);
+        }
+    }
+    {
+        ProfScope ps(rt, "rt_coef");
+        DISPATCH_LPL(launch_coef, rt, a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    rt->refreshed = true;
+    return 0;
+}
+
+static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
+    hx_context* ctx = rt->ctx;
+    KArgs a = make_args(rt);
+    if (!nodes_done) {
+        ProfScope ps(rt, "rt_nodes");
+        dim3 grid(hx_cdiv(rt->X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
+        k_rt_nodes<<<grid, 256, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "rt_flux");
+        DISPATCH_LPL(launch_flux, rt, a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "rt_totals_a");
+        const int thr = ((2 * rt->I + 63) / 64) * 64;
+        k_rt_totals_a<<<dim3(rt->nchunk, rt->C), thr, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "rt_totals_b");
+        TotalsBArgs q;
+        q.a = a;
+        memset(&q.rt, 0, sizeof(q.rt));
+        q.rt.F_net_diff = rt->F_net_diff;
+        q.rt.tlay = rt->T_lay;
+        q.rt.play = rt->p_lay;
+        q.rt.pint = rt->p_int;
+        q.rt.abrt = rt->abort_flags;
+        q.rt.T_store = rt->T_store;
+        q.rt.deltat_prefactor = rt->prefactor;
+        q.rt.F_add_heat_lay = rt->F_add_heat_lay;
+        q.rt.F_add_heat_sum = rt->F_add_heat_sum;
+        q.rt.F_smooth = rt->F_smooth;
+        q.rt.F_smooth_sum = rt->F_smooth_sum;
+        q.rt.c_p_lay = rt->c_p_lay;
+        q.rt.conv_count = rt->conv_count;
+        q.rt.itervalue = itervalue;
+        q.rt.nlayer = rt->L;
+        q.rt.smooth = rt->f.smooth;
+        q.rt.dim = rt->d.plancktable_dim;
+        q.rt.step = rt->d.plancktable_step;
+        q.step_temperature = step_temperature;
+        q.done_w = rt->done;
+        q.iters_done = rt->iters_done;
+        k_rt_totals_b<<<rt->C, 1024, 0, ctx->stream>>>(q);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    return 0;
+}
+
+int hx_rt_step(hx_rt* rt, int itervalue, int step_temperature) {
+    bool nodes_done = false;
+    if (itervalue % 10 == 0 || !rt->refreshed) {  // computation.py:860
+        int rc = hx_rt_refresh(rt);                // (also evaluates the nodes for this iteration)
+        if (rc) return rc;
+        nodes_done = true;
+    }
+    return rt_step_kernels(rt, itervalue, step_temperature, nodes_done);
+}
+
+int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
+    for (int n = 0; n < nsteps; n++) {
+        int rc = hx_rt_step(rt, itervalue + n, 1);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int hx_rt_converged_layers(hx_rt* rt, int* out_counts) {
+    return hx_d2h(rt->ctx, out_counts, rt->conv_count, rt->C * sizeof(int));
+}
+
+// ---- read-back in the reference's layouts ------------------------------------------------------
+namespace {
+
+int get_plain(hx_rt* rt, const void* dptr, size_t bytes, void* out, size_t out_bytes) {
+    if (bytes != out_bytes)
+        return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: buffer is %zu bytes, array has %zu", out_bytes, bytes);
+    return hx_d2h(rt->ctx, out, dptr, bytes);
+}
+
+// internal band layout [x][i] -> reference [x + X*i]
+int get_band(hx_rt* rt, const double* dptr, void* out, size_t out_bytes) {
+    const size_t X = rt->X, I = rt->I;
+    if (out_bytes != X * I * 8) return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: wrong buffer size");
+    std::vector<double> tmp(X * I);
+    int rc = hx_d2h(rt->ctx, tmp.data(), dptr, X * I * 8);
+    if (rc) return rc;
+    double* o = (double*)out;
+    for (size_t x = 0; x < X; x++)
+        for (size_t i = 0; i < I; i++) o[x + X * i] = tmp[x * I + i];
+    return 0;
+}
+
+// flux tiles -> reference wg layout.  `interface_nodes`: pick the even (interface) or odd (centre)
+// nodes; `up`: tile row r of lane j holds the flux at node h+1 (up) or h (down), h = j*ROWS + r.
+int get_flux_wg(hx_rt* rt, int col, const double* tiles, const double* bc, bool up, bool interface_nodes,
+                void* out, size_t out_bytes) {
+    const TileGeom& g = rt->g;
+    const size_t X = rt->X, Y = rt->Y, I = rt->I, nc = X * Y;
+    if (out_bytes != nc * I * 8) return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: wrong buffer size");
+    std::vector<double> t(g.flux_elems_per_col), b(nc);
+    int rc = hx_d2h(rt->ctx, t.data(), tiles + (size_t)col * g.flux_elems_per_col, t.size() * 8);
+    if (rc) return rc;
+    if (bc) {
+        rc = hx_d2h(rt->ctx, b.data(), bc + (size_t)col * nc, nc * 8);
+        if (rc) return rc;
+    }
+    double* o = (double*)out;
+    std::fill(o, o + nc * I, 0.0);
+    for (int blk = 0; blk < g.nblk; blk++) {
+        const int bx = blk % g.nblk_x, part = blk / g.nblk_x;
+        for (int s = 0; s < g.G; s++) {
+            const int xl = s / g.ypb, yl = s % g.ypb;
+            const size_t x = (size_t)bx * g.nxb + xl, y = (size_t)part * g.ypb + yl;
+            if (x >= X) continue;
+            const size_t c = y + Y * x;
+            for (int j = 0; j < g.k; j++) {
+                const int tid = s * g.k + j, wv = tid / 64, lane = tid % 64;
+                const double* tile = t.data() + ((size_t)blk * g.NW + wv) * g.ROWS * 64 + lane;
+                for (int r = 0; r < g.ROWS; r++) {
+                    const int h = j * g.ROWS + r;
+                    if (h >= rt->H) continue;
+                    const int node = up ? h + 1 : h;
+                    const bool is_int = (node % 2) == 0;
+                    if (is_int != interface_nodes) continue;
+                    o[c + nc * (node / 2)] = tile[(size_t)r * 64];
+                }
+            }
+            if (up && interface_nodes && bc) o[c] = b[c];  // U at node 0 = BOA boundary value
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes) {
+    HX_REQUIRE(rt->ctx, col >= 0 && col < rt->C, HX_E_ARG, "column index out of range");
+    const size_t X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, nc = X * Y, c = col;
+    const std::string n(name);
+    if (n == "T_lay") return get_plain(rt, rt->T_lay + c * (L + 1), (L + 1) * 8, out, out_bytes);
+    if (n == "T_int") return get_plain(rt, rt->T_int + c * I, I * 8, out, out_bytes);
+    if (n == "F_up_band") return get_band(rt, rt->F_up_band_n + c * X * I, out, out_bytes);
+    if (n == "F_down_band") return get_band(rt, rt->F_down_band_n + c * X * I, out, out_bytes);
+    if (n == "F_dir_band") return get_band(rt, rt->F_dir_band_n + c * X * I, out, out_bytes);
+    if (n == "F_up_tot") return get_plain(rt, rt->F_up_tot + c * I, I * 8, out, out_bytes);
+    if (n == "F_down_tot") return get_plain(rt, rt->F_down_tot + c * I, I * 8, out, out_bytes);
+    if (n == "F_net") return get_plain(rt, rt->F_net + c * I, I * 8, out, out_bytes);
+    if (n == "F_net_diff") return get_plain(rt, rt->F_net_diff + c * L, L * 8, out, out_bytes);
+    if (n == "abort") return get_plain(rt, rt->abort_flags + c * (L + 1), (L + 1) * 4, out, out_bytes);
+    if (n == "delta_t_prefactor") return get_plain(rt, rt->prefactor + c * (L + 1), (L + 1) * 8, out, out_bytes);
+    if (n == "T_store") return get_plain(rt, rt->T_store + c * (L + 1), (L + 1) * 8, out, out_bytes);
+    if (n == "delta_z_lay") return get_plain(rt, rt->delta_z + c * L, L * 8, out, out_bytes);
+    if (n == "z_lay") return get_plain(rt, rt->z_lay + c * L, L * 8, out, out_bytes);
+    if (n == "meanmolmass_lay") return get_plain(rt, rt->mmm_lay + c * I, L * 8, out, out_bytes);
+    if (n == "meanmolmass_int") return get_plain(rt, rt->mmm_int + c * I, I * 8, out, out_bytes);
+    if (n == "opac_wg_lay") return get_plain(rt, rt->opac_wg_lay + c * nc * I, nc * L * 8, out, out_bytes);
+    if (n == "opac_wg_int") return get_plain(rt, rt->opac_wg_int + c * nc * I, nc * I * 8, out, out_bytes);
+    if (n == "scat_cross_lay") return get_plain(rt, rt->scat_cross_lay + c * X * I, X * L * 8, out, out_bytes);
+    if (n == "scat_cross_int") return get_plain(rt, rt->scat_cross_int + c * X * I, X * I * 8, out, out_bytes);
+    if (n == "g_0_tot_lay") return get_plain(rt, rt->g0_tot_lay + c * X * I, X * L * 8, out, out_bytes);
+    if (n == "g_0_tot_int") return get_plain(rt, rt->g0_tot_int + c * X * I, X * I * 8, out, out_bytes);
+    if (n == "iters_done") return get_plain(rt, rt->iters_done + c, 4, out, out_bytes);
+    if (n == "done") return get_plain(rt, rt->done + c, 4, out, out_bytes);
+    if (n == "planckband_lay" || n == "planckband_int") {
+        // from the node array Bn[x][H+3]: layers = odd nodes, then star, surface; interfaces = even
+        const bool lay = n == "planckband_lay";
+        const size_t NN = rt->H + 3, per = lay ? L + 2 : I;
+        if (out_bytes != X * per * 8) return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: wrong buffer size");
+        std::vector<double> tmp(X * NN);
+        int rc = hx_d2h(rt->ctx, tmp.data(), rt->Bn + c * X * NN, X * NN * 8);
+        if (rc) return rc;
+        double* o = (double*)out;
+        for (size_t x = 0; x < X; x++) {
+            if (lay) {
+                for (size_t i = 0; i < L; i++) o[i + x * per] = tmp[x * NN + 2 * i + 1];
+                o[L + x * per] = tmp[x * NN + rt->H + 1];
+                o[L + 1 + x * per] = tmp[x * NN + rt->H + 2];
+            } else {
+                for (size_t i = 0; i < I; i++) o[i + x * per] = tmp[x * NN + 2 * i];
+            }
+        }
+        return 0;
+    }
+    if (n == "F_up_wg") return get_flux_wg(rt, col, rt->Utile, rt->U0, true, true, out, out_bytes);
+    if (n == "Fc_up_wg") return get_flux_wg(rt, col, rt->Utile, nullptr, true, false, out, out_bytes);
+    if (n == "F_down_wg" || n == "Fc_down_wg") {
+        HX_REQUIRE(rt->ctx, rt->keep_down && rt->Dtile, HX_E_STATE,
+                   "down-flux tiles are only kept after hx_rt_set_state(rt, col, \"keep_down\", ...)");
+        int rc = get_flux_wg(rt, col, rt->Dtile, nullptr, false, n == "F_down_wg", out, out_bytes);
+        if (rc || n != "F_down_wg") return rc;
+        // TOA boundary value D[H] is not a tile row: (1-dir_beam) f (R*/a)^2 pi B*  (kernels.cu:1601)
+        std::vector<double> bs(X);
+        rc = hx_d2h(rt->ctx, bs.data(), rt->Bstar + c * X, X * 8);
+        if (rc) return rc;
+        const hx_rt_column& cp = rt->cols[col];
+        double* o = (double*)out;
+        const double rs = cp.R_star / cp.a;
+        for (size_t x = 0; x < X; x++)
+            for (size_t y = 0; y < Y; y++)
+                o[y + Y * x + nc * L] = (1.0 - rt->f.dir_beam) * cp.f_factor * (rs * rs) * HX_PI * bs[x];
+        return 0;
+    }
+    if (n == "F_dir_wg" || n == "Fc_dir_wg") {
+        if (!rt->f.dir_beam) {
+            if (out_bytes != nc * I * 8) return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: wrong buffer size");
+            memset(out, 0, out_bytes);
+            return 0;
+        }
+        return get_plain(rt, (n == "F_dir_wg" ? rt->F_dir_wg : rt->Fc_dir_wg) + c * nc * I, nc * I * 8, out,
+                         out_bytes);
+    }
+    return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: unknown array name '%s'", name);
+}
+
+int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes) {
+    const std::string n(name);
+    if (n == "keep_down") {
+        if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "keep_down expects one int32");
+        const int v = *(const int*)in;
+        if (v && !rt->Dtile) RT_ALLOC(rt->Dtile, (size_t)rt->C * rt->g.flux_elems_per_col);
+        rt->keep_down = v != 0;
+        return 0;
+    }
+    int c0, c1, rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
+    const size_t L = rt->L;
+    for (int c = c0; c < c1; c++) {
+        if (n == "T_lay") {
+            if (in_bytes != (L + 1) * 8) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for T_lay");
+            rc |= h2d(rt, rt->T_lay + c * (L + 1), in, in_bytes);
+        } else if (n == "c_p_lay") {
+            if (in_bytes != L * 8) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for c_p_lay");
+            rc |= h2d(rt, rt->c_p_lay + c * L, in, in_bytes);
+        } else if (n == "delta_t_prefactor" || n == "T_store") {
+            if (in_bytes != (L + 1) * 8) return hx_fail(rt->ctx, HX_E_ARG, "wrong size");
+            rc |= h2d(rt, (n == "T_store" ? rt->T_store : rt->prefactor) + c * (L + 1), in, in_bytes);
+        } else if (n == "done") {
+            if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "done expects one int32");
+            rc |= h2d(rt, rt->done + c, in, 4);
+        } else {
+            return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_set_state: unknown name '%s'", name);
+        }
+    }
+    return rc;
+}
+
+int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
+    HX_REQUIRE(rt->ctx, col >= 0 && col < rt->C && out_dptr, HX_E_ARG, "bad arguments");
+    const size_t X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, nc = X * Y, c = col;
+    const std::string n(name);
+    void* p = nullptr;
+    if (n == "T_lay") p = rt->T_lay + c * (L + 1);
+    else if (n == "T_int") p = rt->T_int + c * I;
+    else if (n == "p_lay") p = rt->p_lay + c * L;
+    else if (n == "p_int") p = rt->p_int + c * I;
+    else if (n == "opac_wg_lay") p = rt->opac_wg_lay + c * nc * I;
+    else if (n == "opac_wg_int") p = rt->opac_wg_int + c * nc * I;
+    else if (n == "scat_cross_lay") p = rt->scat_cross_lay + c * X * I;
+    else if (n == "scat_cross_int") p = rt->scat_cross_int + c * X * I;
+    else if (n == "meanmolmass_lay") p = rt->mmm_lay + c * I;
+    else if (n == "meanmolmass_int") p = rt->mmm_int + c * I;
+    else if (n == "planck_grid") p = rt->planck_grid;
+    else if (n == "F_net") p = rt->F_net + c * I;
+    else if (n == "F_up_tot") p = rt->F_up_tot + c * I;
+    else if (n == "F_down_tot") p = rt->F_down_tot + c * I;
+    else if (n == "gauss_weight") p = rt->gauss_w;
+    else if (n == "gauss_y") p = rt->gauss_y;
+    else if (n == "opac_deltawave") p = rt->deltawave;
+    else if (n == "opac_interwave") p = rt->interwave;
+    else if (n == "abs_cross_all_clouds_lay") p = rt->cl_abs_lay + c * X * I;
+    else if (n == "delta_col_upper") p = rt->dcol_u + c * L;
+    else if (n == "delta_col_lower") p = rt->dcol_l + c * L;
+    else return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_device_ptr: unknown name '%s'", name);
+    *out_dptr = p;
+    return 0;
+}
+
+int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* refresh_alg,
+                        double* refresh_act) {
+    // algorithmic bytes per iteration and column
+    const double X = rt->X, Y = rt->Y, L = rt->L, S = rt->d.nspecies;
+    const double cl = rt->f.clouds ? 3.0 * (2 * L + 1) : 0.0;
+    const double BE = 8.0 * X * (3.0 * Y * (2 * L + 1) + (2 * L + 1) + 2.0 * (2 * L + 3) + 3.0 * (L + 1) + cl);
+    const double BT = 8.0 * Y * X * (2 * L + 1) * (S > 0 ? 4.0 * S + 1.0 : 5.0);
+    // what this implementation actually moves (per column)
+    const TileGeom& g = rt->g;
+    const double tiles = (double)g.nblk * g.NW * 64.0 * g.ROWS * 8.0;  // one plane
+    const double flux_k = tiles * (g.nplane + 2.0 + (rt->keep_down ? 1.0 : 0.0))   // coef + U read/write
+                          + 8.0 * X * (rt->H + 3) * 2.0                            // node Planck write+read
+                          + 8.0 * X * 4.0 * (L + 1) * g.nparts                     // band partials w + r
+                          + 8.0 * X * 2.0 * (L + 1)                                // band arrays
+                          + 8.0 * X * Y * 2.0;                                     // U0
+    const double premixed = 8.0 * Y * X * (2 * L + 1) * 5.0;
+    const double species = 8.0 * Y * X * (2 * L + 1) * S * (4.0 + 1.0 + 1.0 + 2.0);  // corners + spec w/r + mix r/w
+    const double coef_k = tiles * g.nplane + 8.0 * Y * X * (2 * L + 1);
+    if (step_alg) *step_alg = BE * rt->C;
+    if (step_act) *step_act = flux_k * rt->C;
+    if (refresh_alg) *refresh_alg = BT * rt->C;
+    if (refresh_act) *refresh_act = ((S > 0 ? species : premixed) + coef_k) * rt->C;
+    return 0;
+}
+
+int hx_rt_profile(hx_rt* rt, int enable) {
+    if (!enable) ProfScope::flush(rt);
+    rt->profiling = enable != 0;
+    return 0;
+}
+
+int hx_rt_profile_read(hx_rt* rt, const char* kernel, double* out_avg_ms, int* out_count) {
+    ProfScope::flush(rt);
+    for (auto& acc : rt->prof_acc)
+        if (acc.first == kernel) {
+            if (out_avg_ms) *out_avg_ms = acc.second.second ? acc.second.first / acc.second.second : 0.0;
+            if (out_count) *out_count = acc.second.second;
+            return 0;
+        }
+    if (out_avg_ms) *out_avg_ms = 0.0;
+    if (out_count) *out_count = 0;
+    return 0;
+}
+
+}  // extern "C"

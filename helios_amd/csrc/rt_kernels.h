@@ -1,0 +1,530 @@
+// Device kernels of the fused fast path.  Included by rt_fused.hip only.
+//
+// Unknowns of one spectral point (x,y) live on NODES n = 0..H (H = 2*nlayer): node 2i = interface i,
+// node 2i+1 = centre of layer i.  Half-layer h spans node h (bottom) .. h+1 (top).  With
+//   alpha = P/M, beta = -N/M, u' = K u / M, v' = K v / M,  K = 2 pi eps (1-w)/(E-w),
+//   u = (M+N) + q, v = -P - q, q = eps/(E(1-w g)) (P-M+N)/dtau   (u = v = (N+M-P)/2 if dtau < limit)
+// both sweeps of SURVEY.md 10.3 take the same form
+//   down:  D[h]   = alpha D[h+1] + beta U[h]   + u' B[h]   + v' B[h+1] + dd
+//   up  :  U[h+1] = alpha U[h]   + beta D[h+1] + u' B[h+1] + v' B[h]   + du
+// (B = Planck function at the node; dd/du = min(0, direct-beam term)/M).  The coefficient planes are
+// built once per opacity refresh (k_rt_coef) and streamed once per iteration (k_rt_flux), where
+// each lane keeps its 2*LPL half-layers in registers across all 3*scat+1 sweeps.
+#pragma once
+#include "rt_fused.h"
+#include "temp_step.h"
+#include "two_stream.h"
+
+namespace hx {
+
+struct KArgs {
+    int X, Y, L, I, H, C;
+    int k, LPL, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk;
+    int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
+    int dim, step;
+    double epsi, epsi2, g_0, i2s, w_0_limit, w_0_scat_limit, dtau_limit;
+    const hx_rt_column* colpar;
+    const double *T_lay, *p_lay, *p_int, *dcol_u, *dcol_l, *surf_albedo, *Bstar, *planck_grid;
+    const double *opac_wg_lay, *opac_wg_int, *scat_cross_lay, *scat_cross_int, *mmm_lay, *mmm_int;
+    const double *cl_abs_lay, *cl_abs_int, *cl_sc_lay, *cl_sc_int, *g0_tot_lay, *g0_tot_int;
+    const double *F_dir_wg, *Fc_dir_wg, *F_dir_band_n, *gauss_w, *deltawave;
+    double *T_int, *Bn, *coef, *Utile, *Dtile, *U0, *boaK, *Fdir0, *band_part;
+    double *dtau_u, *dtau_l;
+    double *F_down_band_n, *F_up_band_n, *tot_part, *F_up_tot, *F_down_tot, *F_net;
+    size_t coef_col, flux_col;  // per-column strides (doubles) of coef / Utile / Dtile
+    const int* done;
+};
+
+__device__ __forceinline__ double interface_T(const double* T, int i, int L) {
+    if (i == 0) return T[0] - 0.5 * (T[1] - T[0]);
+    if (i == L) return T[L - 1] + 0.5 * (T[L - 1] - T[L - 2]);
+    return T[i - 1] + 0.5 * (T[i] - T[i - 1]);
+}
+
+// ---- per iteration: interface temperatures + Planck function at every node ------------------
+// Bn[col][x][n], n in [0, H+3): nodes 0..H, then H+1 = stellar row, H+2 = surface (T_lay[L]).
+__global__ void __launch_bounds__(256) k_rt_nodes(KArgs a) {
+    __shared__ double tile[32][33];
+    const int col = blockIdx.z;
+    if (a.done[col]) return;
+    const int NN = a.H + 3;
+    const double* T = a.T_lay + (size_t)col * (a.L + 1);
+    const int x0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < a.I; i += blockDim.x)
+            a.T_int[(size_t)col * a.I + i] = interface_T(T, i, a.L);
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, x = x0 + tx;
+        if (n < NN && x < a.X) {
+            double v;
+            if (n == a.H + 1) {
+                v = a.Bstar[(size_t)col * a.X + x];
+            } else {
+                double Tn;
+                if (n == a.H + 2) Tn = T[a.L];
+                else if (n & 1) Tn = T[(n - 1) >> 1];
+                else Tn = interface_T(T, n >> 1, a.L);
+                v = planck_lookup(a.planck_grid, Tn, x, a.X, a.dim, a.step);
+            }
+            tile[r][tx] = v;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int x = x0 + r, n = n0 + tx;
+        if (n < NN && x < a.X) a.Bn[((size_t)col * a.X + x) * NN + n] = tile[tx][r];
+    }
+}
+
+// which spectral point / layer chunk a thread of a flux workgroup works on
+struct LaneMap {
+    int lane, wv, j, x, y, xl, yl;
+    bool valid;
+    size_t sp;        // y + Y*x
+    size_t tile;      // index of this lane's wavefront tile within the column
+};
+
+__device__ __forceinline__ LaneMap lane_map(const KArgs& a) {
+    LaneMap m;
+    const int tid = threadIdx.x;
+    m.lane = tid & 63;
+    m.wv = tid >> 6;
+    m.j = m.lane % a.k;
+    const int s_local = tid / a.k;
+    const int bx = blockIdx.x % a.nblk_x, part = blockIdx.x / a.nblk_x;
+    m.xl = s_local / a.ypb;
+    m.yl = s_local - m.xl * a.ypb;
+    m.x = bx * a.nxb + m.xl;
+    m.y = part * a.ypb + m.yl;
+    m.valid = s_local < a.G && m.x < a.X;
+    m.sp = (size_t)m.y + (size_t)a.Y * m.x;
+    m.tile = (size_t)blockIdx.x * a.NW + m.wv;
+    return m;
+}
+
+// ---- per refresh: compact coefficient tiles ---------------------------------------------------
+template <int LPL>
+__global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
+    constexpr int ROWS = 2 * LPL;
+    const int col = blockIdx.y;
+    if (a.done[col]) return;
+    const LaneMap m = lane_map(a);
+    const hx_rt_column cp = a.colpar[col];
+    const size_t nc = (size_t)a.Y * a.X;
+    const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
+    const double* opl = a.opac_wg_lay + col * wgI;
+    const double* opi = a.opac_wg_int + col * wgI;
+    const double* scl = a.scat_cross_lay + col * bandI;
+    const double* sci = a.scat_cross_int + col * bandI;
+    const double* mml = a.mmm_lay + (size_t)col * a.I;
+    const double* mmi = a.mmm_int + (size_t)col * a.I;
+    const double* dcu = a.dcol_u + (size_t)col * a.L;
+    const double* dcl = a.dcol_l + (size_t)col * a.L;
+    double* ctile = a.coef + col * a.coef_col + m.tile * (size_t)a.nplane * ROWS * 64 + m.lane;
+    const double nmu = -cp.mu_star;
+    for (int r = 0; r < ROWS; r++) {
+        const int h = m.j * ROWS + r;
+        double alpha = 1.0, beta = 0.0, up = 0.0, vp = 0.0, dd = 0.0, du = 0.0;
+        if (m.valid && h < a.H) {
+            const int i = h >> 1;
+            const bool lower = (h & 1) == 0;
+            // lower half averages (interface i, centre i); upper half (centre i, interface i+1)
+            const int ii = lower ? i : i + 1;
+            const size_t b_l = m.x + (size_t)a.X * i, b_i = m.x + (size_t)a.X * ii;
+            const size_t k_l = m.sp + nc * i, k_i = m.sp + nc * ii;
+            double g0 = a.g_0, ray = 0.0, csc = 0.0, cab = 0.0;
+            if (a.clouds == 1) {
+                const double* gl = a.g0_tot_lay + col * bandI;
+                const double* gi = a.g0_tot_int + col * bandI;
+                g0 = lower ? (gi[b_i] + gl[b_l]) / 2.0 : (gl[b_l] + gi[b_i]) / 2.0;
+                const double* al = a.cl_abs_lay + col * bandI;
+                const double* ai = a.cl_abs_int + col * bandI;
+                cab = lower ? (ai[b_i] + al[b_l]) / 2.0 : (al[b_l] + ai[b_i]) / 2.0;
+            }
+            if (a.scat == 1) {
+                ray = lower ? (sci[b_i] + scl[b_l]) / 2.0 : (scl[b_l] + sci[b_i]) / 2.0;
+                if (a.clouds == 1) {
+                    const double* sl = a.cl_sc_lay + col * bandI;
+                    const double* si = a.cl_sc_int + col * bandI;
+                    csc = lower ? (si[b_i] + sl[b_l]) / 2.0 : (sl[b_l] + si[b_i]) / 2.0;
+                }
+            }
+            const double kap = lower ? (opi[k_i] + opl[k_l]) / 2.0 : (opl[k_l] + opi[k_i]) / 2.0;
+            const double mu = lower ? (mmi[ii] + mml[i]) / 2.0 : (mml[i] + mmi[ii]) / 2.0;
+            const double dcol = lower ? dcl[i] : dcu[i];
+            const double w0 = single_scat_albedo(ray + csc, kap * mu + cab, a.w_0_limit);
+            const double dtau_gas = dcol * (kap + ray / mu);
+            const double dtau = dtau_gas + dcol * (cab + csc) / mu;
+            const Slab s = slab_coeffs(w0, dtau, g0, a.epsi, a.epsi2, cp.mu_star, a.scat_corr, a.i2s);
+            const double invM = 1.0 / s.M;
+            alpha = s.P * invM;
+            beta = -s.N * invM;
+            const double K = 2.0 * HX_PI * a.epsi * (1.0 - w0) / (s.E - w0);
+            double u, v;
+            if (dtau < a.dtau_limit) {
+                u = v = (s.N + s.M - s.P) / 2.0;
+            } else {
+                const double q = a.epsi / (s.E * (1.0 - w0 * g0)) * (s.P - s.M + s.N) / dtau;
+                u = (s.M + s.N) + q;
+                v = -s.P - q;
+            }
+            up = K * u * invM;
+            vp = K * v * invM;
+            if (a.dir_beam == 1) {
+                // beam at node h (bottom) and h+1 (top) of this half-layer
+                const double* Fd = a.F_dir_wg + col * wgI;
+                const double* Fc = a.Fc_dir_wg + col * wgI;
+                const double Fbot = lower ? Fd[m.sp + nc * i] : Fc[m.sp + nc * i];
+                const double Ftop = lower ? Fc[m.sp + nc * i] : Fd[m.sp + nc * (i + 1)];
+                const double dn = Fbot / nmu * (s.Gm * s.M + s.Gp * s.N) - Ftop / nmu * s.Gm * s.P;
+                const double upw = Ftop / nmu * (s.Gm * s.N + s.Gp * s.M) - Fbot / nmu * s.P * s.Gp;
+                dd = dmin(0.0, dn) * invM;
+                du = dmin(0.0, upw) * invM;
+            }
+            if (h == 0) {
+                a.boaK[col * nc + m.sp] = (1.0 - w0) / (s.E - w0);
+                a.Fdir0[col * nc + m.sp] = a.dir_beam == 1 ? (a.F_dir_wg + col * wgI)[m.sp] : 0.0;
+            }
+        }
+        ctile[(0 * ROWS + r) * 64] = alpha;
+        ctile[(1 * ROWS + r) * 64] = beta;
+        ctile[(2 * ROWS + r) * 64] = up;
+        ctile[(3 * ROWS + r) * 64] = vp;
+        if (a.nplane == 6) {
+            ctile[(4 * ROWS + r) * 64] = dd;
+            ctile[(5 * ROWS + r) * 64] = du;
+        }
+    }
+}
+
+// gas optical depths of the half-layers in the reference's layout (needed by the direct beam only)
+__global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
+    const int col = blockIdx.z, i = blockIdx.y;
+    const size_t nc = (size_t)a.Y * a.X;
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc || a.done[col]) return;
+    const int x = (int)(c / a.Y);
+    const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
+    const double* opl = a.opac_wg_lay + col * wgI;
+    const double* opi = a.opac_wg_int + col * wgI;
+    const double* scl = a.scat_cross_lay + col * bandI;
+    const double* sci = a.scat_cross_int + col * bandI;
+    const double* mml = a.mmm_lay + (size_t)col * a.I;
+    const double* mmi = a.mmm_int + (size_t)col * a.I;
+    const size_t b = x + (size_t)a.X * i, k = c + nc * i;
+    double ray_up = 0, ray_low = 0;
+    if (a.scat == 1) {
+        ray_up = (scl[b] + sci[b + a.X]) / 2.0;
+        ray_low = (sci[b] + scl[b]) / 2.0;
+    }
+    const double kap_up = (opl[k] + opi[k + nc]) / 2.0, kap_low = (opi[k] + opl[k]) / 2.0;
+    const double mu_up = (mml[i] + mmi[i + 1]) / 2.0, mu_low = (mmi[i] + mml[i]) / 2.0;
+    const size_t wgL = nc * a.L;
+    a.dtau_u[col * wgL + k] = a.dcol_u[(size_t)col * a.L + i] * (kap_up + ray_up / mu_up);
+    a.dtau_l[col * wgL + k] = a.dcol_l[(size_t)col * a.L + i] * (kap_low + ray_low / mu_low);
+}
+
+// ---- per iteration: all two-stream sweeps + Gauss quadrature ---------------------------------
+template <int LPL>
+__global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
+    constexpr int ROWS = 2 * LPL;
+    extern __shared__ __align__(16) double smem[];
+    const int col = blockIdx.y;
+    if (a.done[col]) return;
+    const LaneMap m = lane_map(a);
+    const int NN = a.H + 3;
+    double* sB = smem;                          // [nxb][NN]
+    double* stage = smem + (size_t)a.nxb * NN;  // [ypb][nxb][2][I]
+    const hx_rt_column cp = a.colpar[col];
+    const size_t nc = (size_t)a.Y * a.X;
+
+    // Planck function at the nodes of this workgroup's bins -> LDS
+    {
+        const int bx = blockIdx.x % a.nblk_x;
+        for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
+            const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
+            sB[t] = x < a.X ? a.Bn[((size_t)col * a.X + x) * NN + n] : 0.0;
+        }
+    }
+    // coefficient planes and up-flux state -> registers
+    const size_t toff = m.tile * (size_t)ROWS * 64 + m.lane;
+    const double* ctile = a.coef + col * a.coef_col + m.tile * (size_t)a.nplane * ROWS * 64 + m.lane;
+    double* utile = a.Utile + col * a.flux_col + toff;
+    double al[ROWS], be[ROWS], sd[ROWS], su[ROWS], Uo[ROWS], Do[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        al[r] = ctile[(0 * ROWS + r) * 64];
+        be[r] = ctile[(1 * ROWS + r) * 64];
+        sd[r] = ctile[(2 * ROWS + r) * 64];  // u' for now
+        su[r] = ctile[(3 * ROWS + r) * 64];  // v' for now
+        Uo[r] = utile[r * 64];
+    }
+    double U0 = 0.0, boaK = 0.0, Fdir0 = 0.0, albedo = 0.0;
+    if (m.valid && m.j == 0) {
+        U0 = a.U0[col * nc + m.sp];
+        boaK = a.boaK[col * nc + m.sp];
+        Fdir0 = a.Fdir0[col * nc + m.sp];
+        albedo = a.surf_albedo[(size_t)col * a.X + m.x];
+    }
+    __syncthreads();
+    const double* Bx = sB + (size_t)(m.valid ? m.xl : 0) * NN;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+        const int h = min(m.j * ROWS + r, a.H - 1);
+        const double Bb = Bx[h], Bt = Bx[h + 1], upc = sd[r], vpc = su[r];
+        sd[r] = upc * Bb + vpc * Bt;
+        su[r] = upc * Bt + vpc * Bb;
+    }
+    if (a.nplane == 6) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            sd[r] += ctile[(4 * ROWS + r) * 64];
+            su[r] += ctile[(5 * ROWS + r) * 64];
+        }
+    }
+    const double rs = cp.R_star / cp.a;
+    const double D_toa = (1.0 - a.dir_beam) * cp.f_factor * (rs * rs) * HX_PI * Bx[a.H + 1];
+    const double B_surf = Bx[a.H + 2];
+    const int k = a.k;
+
+    for (int sweep = 0; sweep < a.nsweep; sweep++) {
+        // ---------------- down: TOA -> BOA ----------------
+        {
+            double Ubelow = __shfl_up(Uo[ROWS - 1], 1, k);  // U at the bottom node of this chunk
+            if (m.j == 0) Ubelow = U0;
+            double A = 1.0, Bc = 0.0;
+#pragma unroll
+            for (int r = ROWS - 1; r >= 0; r--) {
+                const double Uh = r > 0 ? Uo[r - 1] : Ubelow;
+                const double t = fma(be[r], Uh, sd[r]);
+                Bc = fma(al[r], Bc, t);
+                A *= al[r];
+            }
+            // inclusive suffix composition over the k lanes of this spectral point
+            for (int d = 1; d < k; d <<= 1) {
+                const double A2 = __shfl_down(A, d, k), B2 = __shfl_down(Bc, d, k);
+                if (m.j + d < k) {
+                    Bc = fma(A, B2, Bc);
+                    A *= A2;
+                }
+            }
+            double Din = __shfl_down(fma(A, D_toa, Bc), 1, k);
+            if (m.j == k - 1) Din = D_toa;
+            double D = Din;
+#pragma unroll
+            for (int r = ROWS - 1; r >= 0; r--) {
+                const double Uh = r > 0 ? Uo[r - 1] : Ubelow;
+                D = tiny_abs(fma(al[r], D, fma(be[r], Uh, sd[r])));
+                Do[r] = D;
+            }
+        }
+        // ---------------- BOA boundary ----------------
+        if (m.j == 0) U0 = albedo * (Fdir0 + Do[0]) + (1.0 - albedo) * HX_PI * boaK * B_surf;
+        const double Ubc = __shfl(U0, 0, k);
+        // ---------------- up: BOA -> TOA ----------------
+        {
+            double Dabove = __shfl_down(Do[0], 1, k);  // D at the top node of this chunk
+            if (m.j == k - 1) Dabove = D_toa;
+            double A = 1.0, Bc = 0.0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
+                const double t = fma(be[r], Dh, su[r]);
+                Bc = fma(al[r], Bc, t);
+                A *= al[r];
+            }
+            for (int d = 1; d < k; d <<= 1) {
+                const double A2 = __shfl_up(A, d, k), B2 = __shfl_up(Bc, d, k);
+                if (m.j >= d) {
+                    Bc = fma(A, B2, Bc);
+                    A *= A2;
+                }
+            }
+            double Uin = __shfl_up(fma(A, Ubc, Bc), 1, k);
+            if (m.j == 0) Uin = Ubc;
+            double U = Uin;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
+                U = fma(al[r], U, fma(be[r], Dh, su[r]));
+                if (r & 1) U = tiny_abs(U);  // interface nodes only (reference quirk, kernels.cu:1763)
+                Uo[r] = U;
+            }
+        }
+    }
+
+    // state back to HBM
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) utile[r * 64] = Uo[r];
+    if (a.keep_down) {
+        double* dtile = a.Dtile + col * a.flux_col + toff;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) dtile[r * 64] = Do[r];
+    }
+    if (m.valid && m.j == 0) a.U0[col * nc + m.sp] = U0;
+
+    // Gauss quadrature of the interface fluxes: stage[yl][xl][dir][i], then sum over yl in order
+    const int I = a.I;
+    if (m.valid) {
+        const double w = 0.5 * a.gauss_w[m.y];
+        double* st = stage + ((size_t)m.yl * a.nxb + m.xl) * 2 * I;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int h = m.j * ROWS + r;
+            if (h < a.H) {
+                if ((r & 1) == 0) st[h >> 1] = w * Do[r];           // D at interface h/2
+                else st[I + ((h + 1) >> 1)] = w * Uo[r];            // U at interface (h+1)/2
+            }
+        }
+        if (m.j == 0) st[I + 0] = w * U0;
+        if (m.j * ROWS <= a.H - 1 && a.H - 1 < (m.j + 1) * ROWS) st[a.L] = w * D_toa;
+    }
+    __syncthreads();
+    {
+        const int bx = blockIdx.x % a.nblk_x, part = blockIdx.x / a.nblk_x;
+        for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
+            const int xl = t / (2 * I), rest = t - xl * 2 * I, x = bx * a.nxb + xl;
+            if (x >= a.X) continue;
+            double s = 0.0;
+            for (int yl = 0; yl < a.ypb; yl++) s += stage[((size_t)yl * a.nxb + xl) * 2 * I + rest];
+            a.band_part[(((size_t)col * a.nparts + part) * a.X + x) * 2 * I + rest] = s;
+        }
+    }
+}
+
+// ---- per iteration: band fluxes (sum of Gauss-point partials) and chunked wavelength totals ---
+__global__ void __launch_bounds__(1024) k_rt_totals_a(KArgs a) {
+    const int col = blockIdx.y, chunk = blockIdx.x;
+    if (a.done[col]) return;
+    const int I = a.I, t = threadIdx.x;
+    if (t >= 2 * I) return;
+    const int dir = t / I, i = t - dir * I;
+    const int per = (a.X + a.nchunk - 1) / a.nchunk;
+    const int x0 = chunk * per, x1 = min(a.X, x0 + per);
+    double* band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
+    const double* fdir = a.F_dir_band_n + (size_t)col * a.X * I;
+    double acc = 0.0;
+    for (int x = x0; x < x1; x++) {
+        double v = 0.0;
+        for (int p = 0; p < a.nparts; p++)
+            v += a.band_part[(((size_t)col * a.nparts + p) * a.X + x) * 2 * I + t];
+        band[(size_t)x * I + i] = v;
+        acc += (dir == 0 ? fdir[(size_t)x * I + i] + v : v) * a.deltawave[x];
+    }
+    a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
+}
+
+struct TotalsBArgs {
+    KArgs a;
+    RadTempArgs rt;  // pointers of column 0; strides applied below
+    int step_temperature;
+    int* done_w;
+    int* iters_done;
+    size_t sL, sL1, sI;
+};
+
+__global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
+    const KArgs& a = q.a;
+    const int col = blockIdx.x;
+    if (a.done[col]) return;
+    const int I = a.I, L = a.L;
+    double* up = a.F_up_tot + (size_t)col * I;
+    double* down = a.F_down_tot + (size_t)col * I;
+    double* net = a.F_net + (size_t)col * I;
+    for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < a.nchunk; c++) s += a.tot_part[(((size_t)col * a.nchunk + c) * 2) * I + t];
+        if (t < I) down[t] = s; else up[t - I] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < I; i += blockDim.x) net[i] = up[i] - down[i];
+    __syncthreads();
+    if (!q.step_temperature) return;
+    const hx_rt_column cp = a.colpar[col];
+    if (q.rt.itervalue < cp.foreplay) return;
+    RadTempArgs r = q.rt;
+    r.F_down_tot = down;
+    r.F_net = net;
+    r.F_net_diff += (size_t)col * L;
+    r.tlay += (size_t)col * (L + 1);
+    r.play += (size_t)col * L;
+    r.pint += (size_t)col * I;
+    r.abrt += (size_t)col * (L + 1);
+    r.T_store += (size_t)col * (L + 1);
+    r.deltat_prefactor += (size_t)col * (L + 1);
+    r.F_add_heat_lay += (size_t)col * L;
+    r.F_add_heat_sum += (size_t)col * L;
+    r.F_smooth += (size_t)col * L;
+    r.F_smooth_sum += (size_t)col * L;
+    r.c_p_lay += (size_t)col * L;
+    r.meanmolmass_lay = a.mmm_lay + (size_t)col * I;
+    r.conv_count += col;
+    r.foreplay = cp.foreplay;
+    r.g = cp.g;
+    r.physical_tstep = cp.physical_tstep;
+    r.local_limit = cp.rad_convergence_limit;
+    r.adapt_interval = cp.adapt_interval;
+    r.F_intern = cp.F_intern;
+    r.no_atmo = cp.no_atmo;
+    rad_temp_step(r, threadIdx.x, blockDim.x);
+    __syncthreads();
+    if (threadIdx.x == 0 && *r.conv_count == L + 1) {
+        q.done_w[col] = 1;  // the reference leaves radiation_loop once every flag is set
+        q.iters_done[col] = r.itervalue + 1;
+    }
+}
+
+// altitude of the layer centres from the layer thicknesses (host_functions.py:673-698), one thread
+__global__ void k_rt_height(const double* __restrict__ p_lay, const double* __restrict__ dz,
+                            double* __restrict__ z, int L, int gas, size_t stride) {
+    const int col = blockIdx.x;
+    p_lay += col * stride; dz += col * stride; z += col * stride;
+    if (threadIdx.x != 0) return;
+    if (gas) {
+        int i0 = 0;
+        for (int i = 0; i < L; i++) if (p_lay[i] >= 1e7) i0 = i;
+        z[i0] = 0.0;
+        for (int i = i0 + 1; i < L; i++) z[i] = z[i - 1] + 0.5 * dz[i - 1] + 0.5 * dz[i];
+        for (int i = i0 - 1; i >= 0; i--) z[i] = z[i + 1] - 0.5 * dz[i + 1] - 0.5 * dz[i];
+    } else {
+        z[0] = 0.5 * dz[0];
+        for (int i = 1; i < L; i++) z[i] = z[i - 1] + 0.5 * dz[i - 1] + 0.5 * dz[i];
+    }
+}
+
+// mean molecular mass from the species' mixing ratios (host_functions.py:927-959)
+__global__ void k_rt_meanmolmass(const double* __restrict__ vmr, const double* __restrict__ weight,
+                                 const int* __restrict__ in_mu, double* __restrict__ out, int nspecies,
+                                 int nlev) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlev) return;
+    double num = 0.0, tot = 0.0;
+    for (int s = 0; s < nspecies; s++)
+        if (in_mu[s]) {
+            num += vmr[(size_t)s * nlev + i] * weight[s];
+            tot += vmr[(size_t)s * nlev + i];
+        }
+    out[i] = num / tot * HX_AMU;
+}
+
+// F_dir_band_n[x][i] = sum_y w_y/2 F_dir_wg[y + Y x + Y X i]
+__global__ void __launch_bounds__(256) k_rt_fdir_band(const double* __restrict__ F_dir_wg,
+                                                      double* __restrict__ out,
+                                                      const double* __restrict__ gauss_w, int X, int Y,
+                                                      int I) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (x >= X) return;
+    double s = 0.0;
+    for (int y = 0; y < Y; y++) s += 0.5 * gauss_w[y] * F_dir_wg[(size_t)y + (size_t)Y * x + (size_t)Y * X * i];
+    out[(size_t)x * I + i] = s;
+}
+
+// broadcast a scalar-per-bin cross-section to all levels: out[x + X*i] = src[x]
+__global__ void __launch_bounds__(256) k_rt_tile_rows(const double* __restrict__ src,
+                                                      double* __restrict__ out, int X, int nlev) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (x < X) out[x + (size_t)X * i] = src[x];
+}
+
+}  // namespace hx

@@ -1,0 +1,262 @@
+// Per-stage entry points, part 1: Planck table, incident-energy correction, temperature / Planck /
+// opacity-table interpolation.  Layouts are the reference's; thread maps are chosen so that a
+// wavefront's 64 lanes touch consecutive addresses (the reference puts x on threadIdx.x although y is
+// the fastest index of its wg arrays).
+#include "two_stream.h"
+
+using namespace hx;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Planck table: tab[x + r*nbin] = (D/dlambda) * sum_{n=1}^{199} [Phi_n(y_top) - Phi_n(y_bot)]
+// (kernels.cu:95-105, :362-416).  One thread per (x, row); x fastest.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double planck_term(int n, double y1, double y2) {
+    const double dn = n;
+    return exp(-dn * y2) * ((y2 * y2 * y2) / dn + 3.0 * (y2 * y2) / (dn * dn) +
+                            6.0 * y2 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn)) -
+           exp(-dn * y1) * ((y1 * y1 * y1) / dn + 3.0 * (y1 * y1) / (dn * dn) +
+                            6.0 * y1 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn));
+}
+
+__global__ void __launch_bounds__(256)
+k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
+              const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T, int step) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (x >= nbin) return;
+    const double T = (r < nrow_T) ? (double)(r * step + 1) : Tstar;
+    double acc = 0.0;
+    if (T > 0.01) {
+        const double kh = HX_KBOLTZMANN / HX_HCONST;
+        const double D = 2.0 * (kh * kh * kh * HX_KBOLTZMANN * (T * T * T * T)) / (HX_CSPEED * HX_CSPEED);
+        double y_top = HX_HCONST * HX_CSPEED / (lambda_edge[x + 1] * HX_KBOLTZMANN * T);
+        double y_bot = HX_HCONST * HX_CSPEED / (lambda_edge[x] * HX_KBOLTZMANN * T);
+        if (y_bot < y_top) {
+            const double s = y_top;
+            y_top = y_bot;
+            y_bot = s;
+        }
+        for (int n = 1; n < 200; n++) acc += D * planck_term(n, y_bot, y_top);
+    }
+    grid[x + (size_t)r * nbin] = acc / dlambda[x];
+}
+
+// incident-energy correction (kernels.cu:420-468): ONE block sums dlambda*F over all bins in a
+// fixed order (the reference lets every thread redo the whole sum), then rescales.
+__global__ void __launch_bounds__(1024)
+k_corr_inc_energy(double* __restrict__ spec, const double* __restrict__ dlambda, int realstar,
+                  int nbin, double Tstar) {
+    __shared__ double part[1024];
+    double s = 0.0;
+    for (int x = threadIdx.x; x < nbin; x += blockDim.x)
+        s += realstar == 1 ? dlambda[x] * spec[x] : dlambda[x] * HX_PI * spec[x];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    const double corr = HX_STEFANBOLTZMANN * pow(Tstar, 4.0) / part[0];
+    for (int x = threadIdx.x; x < nbin; x += blockDim.x) spec[x] *= corr;
+}
+
+__global__ void k_temp_inter(const double* __restrict__ tlay, double* __restrict__ tint, int ni) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ni) return;
+    if (i == 0)
+        tint[i] = tlay[i] - 0.5 * (tlay[i + 1] - tlay[i]);
+    else if (i == ni - 1)
+        tint[i] = tlay[i - 1] + 0.5 * (tlay[i - 1] - tlay[i - 2]);
+    else
+        tint[i] = tlay[i - 1] + 0.5 * (tlay[i] - tlay[i - 1]);
+}
+
+// Planck interpolation.  The table is x-fastest, the outputs are level-fastest ([i + x*stride]):
+// a 32x32 tile goes through LDS so that both the table reads and the output writes are coalesced.
+template <bool LAYER>
+__global__ void __launch_bounds__(256)
+k_planck_interpol(const double* __restrict__ temp, double* __restrict__ out,
+                  const double* __restrict__ planck_grid, const double* __restrict__ starflux,
+                  int realstar, int nlev_out, int nlayer, int nbin, int dim, int step) {
+    __shared__ double tile[32][33];
+    const int x0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, x = x0 + tx;
+        if (i < nlev_out && x < nbin) {
+            double v;
+            if (LAYER && i == nlayer) {
+                v = realstar == 1 ? starflux[x] / HX_PI : planck_grid[x + (size_t)dim * nbin];
+            } else {
+                const double T = (LAYER && i == nlayer + 1) ? temp[nlayer] : temp[i];
+                v = planck_lookup(planck_grid, T, x, nbin, dim, step);
+            }
+            tile[r][tx] = v;
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int x = x0 + r, i = i0 + tx;
+        if (i < nlev_out && x < nbin) out[i + (size_t)x * nlev_out] = tile[tx][r];
+    }
+}
+
+// k-table look-up (premixed: kernels.cu:524-610, per species: :3209-3259).  One thread per
+// (c = y + ny*x, level): the four table corners and the output are contiguous in c.
+template <bool SPECIES>
+__global__ void __launch_bounds__(256)
+k_opac_interpol(const double* __restrict__ temp, const double* __restrict__ opactemp,
+                const double* __restrict__ press, const double* __restrict__ opacpress,
+                const double* __restrict__ ktable, double* __restrict__ opac,
+                const double* __restrict__ crosstable, double* __restrict__ scat_cross, int npress,
+                int ntemp, int ny, int nbin, int nlev) {
+    const int i = blockIdx.y;
+    const size_t nc = (size_t)ny * nbin;
+    const TPIndex k = locate_tp(temp[i], press[i], opactemp, ntemp, opacpress, npress, !SPECIES, false);
+    const size_t sp = nc, st = nc * npress;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nc;
+         c += (size_t)gridDim.x * blockDim.x) {
+        opac[c + nc * i] =
+            blend_tp(ktable[c + sp * k.pdown + st * k.tdown], ktable[c + sp * k.pup + st * k.tdown],
+                     ktable[c + sp * k.pdown + st * k.tup], ktable[c + sp * k.pup + st * k.tup], k,
+                     SPECIES);
+        if (!SPECIES && c < (size_t)nbin) {
+            const size_t x = c, cp = nbin, ct = (size_t)nbin * npress;
+            scat_cross[x + (size_t)nbin * i] = blend_tp(
+                crosstable[x + cp * k.pdown + ct * k.tdown], crosstable[x + cp * k.pup + ct * k.tdown],
+                crosstable[x + cp * k.pdown + ct * k.tup], crosstable[x + cp * k.pup + ct * k.tup], k,
+                false);
+        }
+    }
+}
+
+// scalar tables (mean molecular mass :649, kappa :703, c_p :761)
+__global__ void k_scalar_table(const double* __restrict__ temp, const double* __restrict__ tgrid,
+                               const double* __restrict__ press, const double* __restrict__ pgrid,
+                               double* __restrict__ out, const double* __restrict__ table, int npress,
+                               int ntemp, int nlev, int log_t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlev) return;
+    const TPIndex k = locate_tp(temp[i], press[i], tgrid, ntemp, pgrid, npress, true, log_t != 0);
+    out[i] = blend_tp(table[k.pdown + npress * k.tdown], table[k.pup + npress * k.tdown],
+                      table[k.pdown + npress * k.tup], table[k.pup + npress * k.tup], k, false);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hx_plancktable(hx_context* ctx, double* planck_grid, const double* lambda_edge,
+                   const double* deltalambda, int nwave, double Tstar, int dim, int step) {
+    HX_REQUIRE(ctx, nwave > 0 && dim >= 10 && step > 0, HX_E_ARG, "bad dimensions");
+    const int nrow_T = 10 * (dim / 10);  // the reference fills rows in ten launches of dim/10
+    dim3 grid(hx_cdiv(nwave, 256), nrow_T + 1);
+    k_plancktable<<<grid, 256, 0, ctx->stream>>>(planck_grid, lambda_edge, deltalambda, nwave, Tstar,
+                                                 nrow_T, step);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// internal (not part of the C-ABI): the stellar row only, for per-column stars of a batch
+int hx_internal_planck_star_row(hx_context* ctx, double* row, const double* lambda_edge,
+                                const double* deltalambda, int nwave, double Tstar) {
+    k_plancktable<<<dim3(hx_cdiv(nwave, 256), 1), 256, 0, ctx->stream>>>(row, lambda_edge, deltalambda,
+                                                                        nwave, Tstar, 0, 1);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_corr_inc_energy(hx_context* ctx, double* planck_grid, double* starflux,
+                       const double* deltalambda, int realstar, int nwave, double Tstar, int dim) {
+    double* spec = realstar == 1 ? starflux : planck_grid + (size_t)dim * nwave;
+    k_corr_inc_energy<<<1, 1024, 0, ctx->stream>>>(spec, deltalambda, realstar, nwave, Tstar);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_temp_inter(hx_context* ctx, const double* tlay, double* tint, int numinterfaces,
+                  int itervalue) {
+    (void)itervalue;
+    HX_REQUIRE(ctx, numinterfaces >= 3, HX_E_ARG, "needs at least 2 layers");
+    k_temp_inter<<<hx_cdiv(numinterfaces, 64), 64, 0, ctx->stream>>>(tlay, tint, numinterfaces);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_planck_interpol_layer(hx_context* ctx, const double* temp, double* planckband_lay,
+                             const double* planck_grid, const double* starflux, int realstar,
+                             int numlayers, int nwave, int dim, int step) {
+    dim3 grid(hx_cdiv(nwave, 32), hx_cdiv(numlayers + 2, 32));
+    k_planck_interpol<true><<<grid, 256, 0, ctx->stream>>>(temp, planckband_lay, planck_grid, starflux,
+                                                          realstar, numlayers + 2, numlayers, nwave,
+                                                          dim, step);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_planck_interpol_interface(hx_context* ctx, const double* temp, double* planckband_int,
+                                 const double* planck_grid, int numinterfaces, int nwave, int dim,
+                                 int step) {
+    dim3 grid(hx_cdiv(nwave, 32), hx_cdiv(numinterfaces, 32));
+    k_planck_interpol<false><<<grid, 256, 0, ctx->stream>>>(temp, planckband_int, planck_grid, nullptr,
+                                                           0, numinterfaces, -5, nwave, dim, step);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_opac_interpol(hx_context* ctx, const double* temp, const double* opactemp,
+                     const double* press, const double* opacpress, const double* ktable,
+                     double* opac, const double* crosstable, double* scat_cross, int npress,
+                     int ntemp, int ny, int nbin, int nlay_or_nint) {
+    const long long nc = (long long)ny * nbin;
+    dim3 grid((unsigned)min((long long)hx_cdiv(nc, 256), 4096LL), nlay_or_nint);
+    k_opac_interpol<false><<<grid, 256, 0, ctx->stream>>>(temp, opactemp, press, opacpress, ktable,
+                                                         opac, crosstable, scat_cross, npress, ntemp,
+                                                         ny, nbin, nlay_or_nint);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_opac_species_interpol(hx_context* ctx, const double* temp, const double* opactemp,
+                             const double* press, const double* opacpress,
+                             const double* opac_opacity_pretab, double* opac_spec_wg, int npress,
+                             int ntemp, int ny, int nbin, int nlay_or_nint) {
+    const long long nc = (long long)ny * nbin;
+    dim3 grid((unsigned)min((long long)hx_cdiv(nc, 256), 4096LL), nlay_or_nint);
+    k_opac_interpol<true><<<grid, 256, 0, ctx->stream>>>(temp, opactemp, press, opacpress,
+                                                        opac_opacity_pretab, opac_spec_wg, nullptr,
+                                                        nullptr, npress, ntemp, ny, nbin, nlay_or_nint);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_meanmolmass_interpol(hx_context* ctx, const double* temp, const double* opactemp,
+                            double* meanmolmass, const double* opac_meanmass, const double* press,
+                            const double* opacpress, int npress, int ntemp, int ninterface) {
+    k_scalar_table<<<hx_cdiv(ninterface, 64), 64, 0, ctx->stream>>>(
+        temp, opactemp, press, opacpress, meanmolmass, opac_meanmass, npress, ntemp, ninterface, 0);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_kappa_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
+                      const double* press, const double* entr_press, double* kappa,
+                      const double* entr_kappa, int entr_npress, int entr_ntemp, int nlay_or_nint) {
+    k_scalar_table<<<hx_cdiv(nlay_or_nint, 64), 64, 0, ctx->stream>>>(
+        temp, entr_temp, press, entr_press, kappa, entr_kappa, entr_npress, entr_ntemp, nlay_or_nint, 0);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_cp_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
+                   const double* press, const double* entr_press, double* cp_lay,
+                   const double* entr_cp, int entr_npress, int entr_ntemp, int nlayer) {
+    k_scalar_table<<<hx_cdiv(nlayer, 64), 64, 0, ctx->stream>>>(
+        temp, entr_temp, press, entr_press, cp_lay, entr_cp, entr_npress, entr_ntemp, nlayer, 1);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+}  // extern "C"

@@ -10,11 +10,13 @@ def port_impl():
 class RefImpl(object):
     """the reference's own kernels (oracle/_ref) behind the oracle's signatures"""
 
-    def __init__(self):
-        import oracle
-        if oracle.ref is None:
-            raise RuntimeError("oracle/_ref/libhelios_ref.so not built")
-        self.r = oracle.ref
+    def __init__(self, backend=None):
+        if backend is None:
+            import oracle
+            if oracle.ref is None:
+                raise RuntimeError("oracle/_ref/libhelios_ref.so not built")
+            backend = oracle.ref
+        self.r = backend
         r = self.r
         # identical argument lists
         self.planck_table = r.plancktable
@@ -83,3 +85,52 @@ class RefImpl(object):
 
     def integrate_beamflux(self, F_dir_tot, F_dir_band, deltalambda, nbin, ninterface):
         self.r.integrate_beamflux(F_dir_tot, F_dir_band, deltalambda, np.zeros(1), nbin, ninterface)
+
+
+class HipBackend(object):
+    """libhelios_hip.so's per-stage entry points (hx_<kernel>, reference argument order) called with
+    numpy arrays: every array argument is uploaded, the kernel runs on the GPU, and every array is
+    downloaded again into the caller's numpy array (so in/out semantics match the CPU checkers)."""
+
+    def __init__(self, ctx=None):
+        import ctypes
+        from helios_amd import _lib
+        from helios_amd.device import Context
+        self.ctx = ctx or Context(0)
+        self._l = _lib.lib()
+        self._protos = _lib.prototypes()
+        self._ct = ctypes
+
+    def __getattr__(self, name):
+        ct = self._ct
+        hx_name = "hx_" + {"integrate_flux_double": "integrate_flux"}.get(name, name)
+        if hx_name not in self._protos:
+            raise AttributeError(name)
+        fn = getattr(self._l, hx_name)
+        _res, argtypes, argnames = self._protos[hx_name]
+
+        def call(*args):
+            if len(args) != len(argtypes) - 1:
+                raise TypeError("%s expects %d arguments, got %d" % (hx_name, len(argtypes) - 1, len(args)))
+            conv, arrays = [self.ctx.handle], []
+            for a, t in zip(args, argtypes[1:]):
+                if isinstance(a, np.ndarray):
+                    d = self.ctx.to_gpu(a)
+                    arrays.append((a, d))
+                    conv.append(ct.cast(d.ptr, t))
+                elif a is None:
+                    conv.append(None)
+                else:
+                    conv.append(a)
+            self.ctx.check(fn(*conv), hx_name)
+            for a, d in arrays:
+                if a.flags.writeable:
+                    a[...] = d.get()
+                d.free()
+
+        call.__name__ = hx_name
+        return call
+
+
+def hip_impl(ctx=None):
+    return RefImpl(HipBackend(ctx))

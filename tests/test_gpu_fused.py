@@ -1,0 +1,119 @@
+"""GPU parity of the fused fast path (hx_rt_*: coefficient tiles + register-resident sweeps) against
+the CPU oracle chain, the golden vectors, and -- at BASELINE.json's full size -- against the per-stage
+HIP kernels and physical invariants."""
+import numpy as np
+import pytest
+
+import cases
+import golden_checks as gc
+import fused_helpers as fh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from helios_amd.device import Context
+    c = Context(0)
+    yield c
+
+
+FUSED_CONFIGS = {
+    "default": dict(),
+    "noscat": dict(scat=0),
+    "dirbeam": dict(dir_beam=1, albedo=0.3),
+    "dirbeam_zenith": dict(dir_beam=1, geom_zenith_corr=1, zenith_deg=80.0),
+    "clouds_g0": dict(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2),
+    "thin_top": dict(thin_top=True, nlayer=12),
+    "ny1": dict(ny=1, nbin=17),
+    "L100": dict(nbin=24, nlayer=100),          # k=16, LPL=7: the BASELINE shape
+    "L105": dict(nbin=12, nlayer=105),          # the reference's default layer count
+    "L50": dict(nbin=21, nlayer=50, clouds=1),  # k=8, two bins per workgroup
+    "L200": dict(nbin=7, nlayer=200, dir_beam=1),  # k=32, two Gauss-point partials per bin
+    "L33_ny16": dict(nbin=9, nlayer=33, ny=16),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FUSED_CONFIGS))
+def test_fused_vs_oracle(ctx, port, name):
+    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    for n_iter, rtol in ((1, 1e-9), (12, 1e-7)):
+        o = fh.run_oracle(port, c0, n_iter)
+        f = fh.run_fused(ctx, c0, n_iter)
+        fh.compare(f, o, c0, rtol=rtol)
+
+
+@pytest.mark.parametrize("name", [n for n in gc.CHAIN_NAMES if not n.startswith("iso")])
+def test_fused_golden(ctx, name):
+    """the fused path against the reference-generated golden vectors (non-isothermal configs)"""
+    c, z = gc.load_chain(name)
+    for n_iter, prefix, rtol in ((1, "it1.", 1e-9), (12, "it12.", 1e-7)):
+        f = fh.run_fused(ctx, c, n_iter)
+        want = {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+        want["delta_t_prefactor"] = want["deltat_prefactor"]
+        L = c.nlayer
+        want["opac_wg_lay"] = want["opac_wg_lay"][:c.ny * c.nbin * L]
+        keys = [k for k in fh.FUSED_KEYS if k in want]
+        fh.compare(f, want, c, rtol=rtol, keys=keys)
+
+
+def test_fused_batch_of_columns(ctx, port):
+    """three columns with different temperature profiles in one batch == three single runs"""
+    c0 = cases.make_case(nbin=11, nlayer=14)
+    Ts = [c0.T_lay, c0.T_lay * 1.1, c0.T_lay * 0.8 + 50.0]
+    outs = fh.run_fused(ctx, c0, 11, ncol=3, col=[0, 1, 2], T_per_col=Ts)
+    for T, f in zip(Ts, outs):
+        c = c0.copy()
+        c.T_lay = T.copy()
+        o = fh.run_oracle(port, c, 11)
+        fh.compare(f, o, c0, rtol=1e-7)
+
+
+def test_fused_stops_at_convergence(ctx, port):
+    """a column whose every layer satisfies the criterion is frozen on the device exactly where the
+    reference's loop would exit (computation.py:938), however late the host looks"""
+    c0 = cases.make_case(nbin=9, nlayer=8)
+    c0.rad_convergence_limit = 0.9    # absurdly loose: converges on the first step
+    from helios_amd.rt import batch_from_case
+    rt = batch_from_case(ctx, c0)
+    rt.build_planck_table(1)
+    rt.run(0, 7)
+    assert rt.get("done")[0] == 1 and rt.get("iters_done")[0] == 1
+    T7 = rt.get("T_lay")
+    rt.close()
+    o = fh.run_oracle(port, c0, 1)
+    np.testing.assert_allclose(T7, o["T_lay"], rtol=1e-9)
+    assert o["abort"].sum() == c0.nlayer + 1
+
+
+def test_fused_full_size_vs_stage_kernels(ctx):
+    """BASELINE config 2 (10 000 bins x 100 layers x 20 Gauss points): the fused path against the
+    per-stage HIP kernels on the same device-resident inputs, plus invariants"""
+    from helios_amd.rt import batch_from_case
+    from impls import hip_impl
+    c0 = cases.make_case(nbin=10000, nlayer=100, ntemp=6, npress=5, plancktable_dim=800,
+                         plancktable_step=5)
+    n_iter = 3
+    rt = batch_from_case(ctx, c0)
+    rt.build_planck_table(1)
+    rt.run(0, n_iter)
+    f = {k: rt.get(k) for k in ("T_lay", "F_up_band", "F_down_band", "F_net", "F_up_tot", "F_down_tot",
+                                "planckband_lay", "opac_wg_int", "F_up_wg")}
+    rt.close()
+    hip = hip_impl(ctx)
+    c = c0.copy()
+    s = cases.alloc_state(c)
+    cases.setup_planck(hip, c, s)
+    cases.radiation_iterations(hip, c, s, n_iter)
+    scale = np.abs(s.F_down_wg).max()
+    np.testing.assert_allclose(f["opac_wg_int"], s.opac_wg_int, rtol=1e-12)
+    np.testing.assert_allclose(f["planckband_lay"], s.planckband_lay, rtol=1e-9, atol=1e-13 * s.planckband_lay.max())
+    np.testing.assert_allclose(f["F_up_wg"], s.F_up_wg, rtol=1e-8, atol=1e-13 * scale)
+    for k in ("F_up_band", "F_down_band", "F_up_tot", "F_down_tot"):
+        np.testing.assert_allclose(f[k], s[k], rtol=1e-9, atol=1e-13 * scale, err_msg=k)
+    np.testing.assert_allclose(f["T_lay"], c.T_lay, rtol=1e-8)
+    # invariants: non-negative fluxes; TOA down-flux = f (R*/a)^2 sigma T*^4 after the energy correction
+    assert f["F_up_band"].min() >= 0 and f["F_down_band"].min() >= 0
+    from helios_amd import phys_const as pc
+    toa = c0.f_factor * (c0.R_star / c0.a) ** 2 * 5.6703669999999995e-5 * c0.T_star ** 4
+    np.testing.assert_allclose(f["F_down_tot"][-1], toa, rtol=1e-10)

@@ -1,0 +1,87 @@
+"""GPU parity, per-stage entry points (hx_<kernel>) of libhelios_hip.so, called through the C-ABI:
+against the committed golden vectors (from the reference's kernels) and against the CPU oracle."""
+import numpy as np
+import pytest
+
+import cases
+import golden_checks as gc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from impls import hip_impl
+    return hip_impl()
+
+
+@pytest.mark.parametrize("name", gc.CHAIN_NAMES)
+def test_stage_chain_golden(hip, name):
+    # libm differences (OCML vs glibc exp/log10/pow, <= 1-2 ulp) enter here: 1e-10 after one
+    # iteration, 1e-7 after twelve (tolerance of the north star: 1e-6 on fluxes)
+    gc.check_chain(hip, name, rtol1=1e-10, rtol12=1e-7)
+
+
+def test_mixing_golden(hip):
+    gc.check_mixing(hip, rtol=1e-11)
+
+
+@pytest.mark.parametrize("cfg", [dict(nbin=37, nlayer=23), dict(nbin=70, nlayer=50, clouds=1, g_0=0.2, dir_beam=1),
+                                 dict(nbin=33, nlayer=17, iso=1, dir_beam=1, geom_zenith_corr=1, zenith_deg=75.0)])
+def test_stage_chain_vs_oracle(hip, port, cfg):
+    c0 = cases.make_case(**cfg)
+    out = []
+    for impl in (hip, port):
+        c = c0.copy()
+        s = cases.alloc_state(c)
+        cases.setup_planck(impl, c, s)
+        cases.radiation_iterations(impl, c, s, 3)
+        out.append((c, s))
+    (ch, sh), (cp, sp) = out
+    scale = max(np.abs(sp.F_down_wg).max(), np.abs(sp.F_dir_wg).max())
+    np.testing.assert_allclose(sh.planck_grid, sp.planck_grid, rtol=1e-11, atol=1e-280)
+    for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "meanmolmass_lay", "planckband_lay"):
+        np.testing.assert_allclose(sh[k], sp[k], rtol=1e-11, atol=1e-13 * np.abs(sp[k]).max(), err_msg=k)
+    for k in ("F_down_wg", "F_up_wg", "F_dir_wg", "F_down_band", "F_up_band"):
+        np.testing.assert_allclose(sh[k], sp[k], rtol=1e-8, atol=1e-13 * scale, err_msg=k)
+    np.testing.assert_allclose(sh.F_net, sp.F_net, rtol=1e-8, atol=1e-12 * np.abs(sp.F_up_tot).max())
+    np.testing.assert_allclose(ch.T_lay, cp.T_lay, rtol=1e-8)
+
+
+def test_post_loop_diagnostics_vs_oracle(hip, port):
+    c0 = cases.make_case(clouds=1, g_0=0.2, nbin=21, nlayer=11)
+    res = []
+    for impl in (hip, port):
+        c = c0.copy()
+        s = cases.alloc_state(c)
+        cases.setup_planck(impl, c, s)
+        cases.radiation_iterations(impl, c, s, 1)
+        X, Y, L, I = c.nbin, c.ny, c.nlayer, c.ninterface
+        impl.integrate_optdepth_transmission_noniso(
+            s.trans_wg_upper, s.trans_wg_lower, s.trans_band, s.delta_tau_wg_upper,
+            s.delta_tau_wg_lower, s.delta_tau_band, c.gauss_weight, s.delta_tau_all_clouds,
+            s.delta_tau_all_clouds_upper, s.delta_tau_all_clouds_lower, X, L, Y)
+        impl.calc_contr_func_noniso(s.trans_wg_upper, s.trans_wg_lower, s.trans_weight_band,
+                                    s.contr_func_band, c.gauss_weight, s.planckband_lay, c.epsi, X, L, Y)
+        pm = [np.zeros(L) for _ in range(4)]
+        impl.calc_mean_opacities(pm[0], pm[1], pm[2], pm[3], s.opac_wg_lay, c.abs_cross_all_clouds_lay,
+                                 s.meanmolmass_lay, s.planckband_lay, c.opac_interwave,
+                                 c.opac_deltawave, c.T_lay, c.gauss_weight, c.gauss_y, s.opac_band_lay,
+                                 L, X, Y, c.T_star)
+        impl.integrate_beamflux(s.F_dir_tot, s.F_dir_band, c.opac_deltawave, X, I)
+        res.append((s, pm))
+    (sh, ph), (sp, pp) = res
+    for k in ("trans_band", "delta_tau_band", "delta_tau_all_clouds", "trans_weight_band",
+              "contr_func_band", "opac_band_lay", "F_dir_tot"):
+        np.testing.assert_allclose(sh[k], sp[k], rtol=1e-10, atol=1e-13 * np.abs(sp[k]).max(), err_msg=k)
+    for a, b in zip(ph, pp):
+        np.testing.assert_allclose(a, b, rtol=1e-9)
+
+
+def test_random_overlap_requires_ny20(hip):
+    from helios_amd._lib import HeliosHipError
+    ny, nbin, nlev = 8, 4, 3
+    n = ny * nbin * nlev
+    with pytest.raises(HeliosHipError):
+        hip.add_to_mixed_opac(np.ones(nlev), np.ones(n), np.ones(n), np.ones(nlev), np.ones(ny),
+                              np.linspace(0.1, 0.9, ny), 1.0, 1, 1, ny, nbin, nlev)
