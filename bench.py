@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rad-conv iterations/s x (lambda-bins x layers) on BASELINE.json's config 2
+(single column per GPU, 10 000 bins x 100 layers x 20 Gauss points, premixed corr-k table,
+isotropic scattering, fp64), synthetic tables per SURVEY.md section 8(d).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the radiation_loop body (reference source/computation.py:851-984): interface
+temperatures, Planck interpolation, every-10th-iteration opacity/transmission refresh, 3*scat+1
+two-stream sweeps, flux integration, temperature step -- all through libhelios_hip.so (hx_rt_step).
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, columns sharded
+(weak scaling: one column per GPU), no collective on the iteration path; the output spectra are
+gathered over RCCL once after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (nbin, nlayer, ny, ntemp, npress)
+    "c2": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20,
+               desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
+    "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20,
+               desc="BASELINE config 1 shape: 300 bins x 50 layers, premixed"),
+}
+
+
+def build_case(w, seed):
+    """synthetic column + premixed table; attribute names follow the reference's Store"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helios_amd import phys_const as pc
+    from helios_amd import synthetic as syn
+
+    class C(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+
+    rng = np.random.default_rng(seed)
+    c = C()
+    c.nbin, c.nlayer, c.ny, c.ntemp, c.npress = w["nbin"], w["nlayer"], w["ny"], w["ntemp"], w["npress"]
+    c.ninterface = c.nlayer + 1
+    c.iso, c.scat, c.dir_beam, c.clouds, c.scat_corr, c.geom_zenith_corr = 0, 1, 0, 0, 0, 0
+    c.g_0, c.epsi, c.epsi2, c.i2s_transition = 0.0, 0.5, 0.5, 0.1
+    c.w_0_limit, c.w_0_scat_limit, c.delta_tau_limit = 1.0 - 1e-10, 1e-3, 1e-4
+    c.f_factor, c.mu_star = 0.5, float(np.cos(np.pi - np.pi / 3.0))
+    c.g, c.R_planet, c.R_star, c.a = 1000.0, pc.R_JUP, pc.R_SUN, 0.05 * pc.AU
+    c.T_star, c.real_star = 5000.0, 0
+    c.F_intern = pc.SIGMA_SB * 100.0 ** 4
+    c.plancktable_dim, c.plancktable_step = 8000, 2
+    c.rad_convergence_limit, c.adapt_interval, c.foreplay, c.smooth = 1e-8, 20, 0, 0
+    c.physical_tstep, c.no_atmo = 0.0, 0
+    c.opac_interwave, c.opac_wave, c.opac_deltawave = syn.wavelength_grid(c.nbin)
+    c.gauss_y, c.gauss_weight = syn.gauss_points(c.ny)
+    c.ktemp, c.kpress = syn.tp_grid(c.ntemp, c.npress)
+    c.opac_k = syn.ktable(rng, c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+    c.opac_scat_cross = syn.rayleigh_table(c.opac_wave, c.ntemp, c.npress)
+    c.opac_meanmass = syn.meanmass_table(c.ntemp, c.npress)
+    c.p_lay, c.p_int = syn.pressure_levels(1e9, 1e-1, c.nlayer)
+    T_eff = c.f_factor ** 0.25 * (c.R_star / c.a) ** 0.5 * c.T_star
+    c.T_lay = np.ones(c.nlayer + 1) * max(T_eff, 500.0)       # host_functions.py:164-176
+    c.surf_albedo = np.zeros(c.nbin)
+    c.starflux = np.zeros(c.nbin)
+    c.c_p_lay = np.full(c.nlayer, 3.5 * pc.R_UNIV)
+    return c
+
+
+def cpu_baseline(w, seed):
+    """the CPU oracle (oracle/helios_oracle.c, OpenMP over bins) on a bounded sample of the same
+    workload: the first `nb` bins, 20 iterations from iteration 0 (2 refreshes + 20 flux solves)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    import oracle
+    nb = min(w["nbin"], 2000)
+    ws = dict(w)
+    ws["nbin"] = nb
+    c = build_case(ws, seed)
+    cc = cases.Case(c)
+    cc.z_lay = np.zeros(c.nlayer)
+    cc.T_int = np.zeros(c.nlayer + 1)
+    for k in ("F_add_heat_lay", "F_add_heat_sum", "F_smooth", "F_smooth_sum"):
+        cc[k] = np.zeros(c.nlayer)
+    for nm, n in (("lay", c.nlayer), ("int", c.nlayer + 1)):
+        for p in ("abs_cross_all_clouds_", "scat_cross_all_clouds_", "g_0_all_clouds_"):
+            cc[p + nm] = np.zeros(n * nb)
+    cc.delta_colmass = (c.p_int[:-1] - c.p_int[1:]) / c.g
+    cc.delta_col_upper = (c.p_lay - c.p_int[1:]) / c.g
+    cc.delta_col_lower = (c.p_int[:-1] - c.p_lay) / c.g
+    # a coarse Planck table keeps the (untimed) set-up short; the timed part does not depend on it
+    cc.plancktable_dim, cc.plancktable_step = 800, 20
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    oracle.port.set_num_threads(threads)
+    s = cases.alloc_state(cc)
+    cases.setup_planck(oracle.port, cc, s)
+    n_it = 20
+    t0 = time.perf_counter()
+    cases.radiation_iterations(oracle.port, cc, s, n_it)
+    dt = time.perf_counter() - t0
+    return dict(value=n_it / dt * nb * c.nlayer, unit="bin*layer*iterations/s", cores=threads, kind="port",
+                sample="%d of %d bins x %d layers x %d Gauss points, %d iterations from iteration 0 "
+                       "(2 opacity refreshes), oracle/helios_oracle.c with OpenMP over bins, %.1f s"
+                       % (nb, w["nbin"], c.nlayer, c.ny, n_it, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--columns-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from helios_amd.device import Context
+    from helios_amd.rt import batch_from_case
+
+    w = WORKLOADS[args.workload]
+    seed = 20240 + 2
+    c = build_case(w, seed)
+    ctx = Context(local_rank)
+    ncol = args.columns_per_gpu
+    rt = batch_from_case(ctx, c, ncol=ncol)
+    # every column of a sweep differs (here: internal temperature -> different T-P trajectories)
+    if ncol > 1 or world > 1:
+        for i in range(ncol):
+            gi = rank * ncol + i
+            rt.set_temperatures(i, c.T_lay * (1.0 + 0.01 * gi))
+    rt.build_planck_table(1)
+    ctx.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    # warm-up: W untimed steps starting at iteration 0 (includes the first refresh)
+    rt.run(0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    rt.run(args.warmup, args.steps)
+    ev_ms = ctx.timer_stop_ms()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    done = [int(rt.get("done", i)[0]) for i in range(ncol)]
+
+    # per-kernel timing of the dominant kernel: a separate short pass with HIP events on the stream
+    roofline = None
+    tm = rt.traffic_model()
+    if args.profile_steps > 0:
+        it0 = args.warmup + args.steps
+        it0 += (-it0) % 10 + 1                      # start right after a refresh boundary
+        rt.run(args.warmup + args.steps, it0 - (args.warmup + args.steps))
+        ctx.synchronize()
+        rt.profile(True)
+        rt.run(it0, min(args.profile_steps, 9))     # E-iterations only
+        rt.profile(False)
+        flux_ms, nflux = rt.profile_read("rt_flux")
+        if nflux:
+            achieved = tm["step_algorithmic"] / (flux_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(args.workload, {}).get("rt_flux_hbm_bytes_per_launch")
+            roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
+                            frac=achieved / 8000.0, traffic=traffic,
+                            algorithmic_bytes_per_launch=tm["step_algorithmic"],
+                            actual_bytes_model_per_launch=tm["step_actual"], avg_launch_ms=flux_ms,
+                            launches_timed=nflux)
+
+    # the path's only exchange: gather the emission spectra of all columns once, after the run
+    gather_ms = None
+    spec = np.stack([rt.get("F_up_band", i)[-c.nbin:] for i in range(ncol)])
+    if dist is not None:
+        tg = time.perf_counter()
+        mine = torch.from_numpy(spec).cuda()
+        out = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        spec = torch.cat(out).cpu().numpy()
+
+    total_cols = ncol * world
+    value = args.steps / dt * c.nbin * c.nlayer * total_cols
+    line = {
+        "metric": "rad-conv iterations/sec x (lambda-bins x layers)",
+        "value": value, "unit": "bin*layer*iterations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": w["desc"], "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
+                   "opacity_table_TP_grid": [c.ntemp, c.npress], "columns_per_gpu": ncol,
+                   "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 4,
+                   "parallelism": "columns sharded, %d per GPU" % ncol},
+        "iterations_per_s_per_column": args.steps / dt,
+        "stream_event_ms_per_step": ev_ms / args.steps,
+        "columns_converged_during_run": int(sum(done)),
+        "spectra_gather_ms": gather_ms,
+        "spectrum_checksum": float(np.sum(spec)),
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(w, seed)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line))
+    rt.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

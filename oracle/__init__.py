@@ -89,3 +89,10 @@ def _load_ref():
 
 port = _load_port()
 ref = _load_ref()
+# tiny test problems + hundreds of OpenMP threads (or a CPU quota below the visible core count) make
+# every parallel region crawl: default to at most 8 threads; bench.py's cpu_baseline sets its own.
+try:
+    _ncpu = len(os.sched_getaffinity(0))
+except AttributeError:
+    _ncpu = os.cpu_count() or 1
+port.set_num_threads(max(1, min(8, _ncpu)))

@@ -31,14 +31,16 @@ def load_chain(name):
     return c, z
 
 
-def check_chain(impl, name, rtol1=1e-11, rtol12=1e-8, check_planck_table=True):
+def check_chain(impl, name, rtol1=1e-11, rtol12=1e-8, check_planck_table=True, planck_rtol=1e-11):
     """`rtol1`: tolerance after one iteration (every stage run once on identical inputs);
     `rtol12`: after 12 iterations, where last-bit differences have been fed back 12 times."""
     c, z = load_chain(name)
     s = cases.alloc_state(c)
     if check_planck_table:
         cases.setup_planck(impl, c, s)
-        _close(s.planck_grid, z["planck_grid"], rtol=1e-11, atol=1e-290, name="planck_grid")
+        # Phi_n(y_top) - Phi_n(y_bot) cancels in the Rayleigh-Jeans tail (kernels.cu:103-104): 1-ulp
+        # differences between libm exp() implementations are amplified to ~1e-10 there
+        _close(s.planck_grid, z["planck_grid"], rtol=planck_rtol, atol=1e-290, name="planck_grid")
     s.planck_grid[:] = z["planck_grid"]
     cases.radiation_iterations(impl, c, s, 1)
     _compare(c, s, z, "it1.", rtol1)
