@@ -95,9 +95,27 @@ def cpu_baseline(w, seed):
     cc.delta_col_lower = (c.p_int[:-1] - c.p_lay) / c.g
     # a coarse Planck table keeps the (untimed) set-up short; the timed part does not depend on it
     cc.plancktable_dim, cc.plancktable_step = 800, 20
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    s = cases.alloc_state(cc)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    oracle.port.set_num_threads(min(ncpu, 32))
+    cases.setup_planck(oracle.port, cc, s)
+    # the visible core count can exceed what the container may actually use (CPU quota): time one
+    # flux sweep at a few thread counts and keep the fastest
+    cases.interpolate_temperatures_and_planck(oracle.port, cc, s)
+    cases.refresh_premixed(oracle.port, cc, s)
+    best = (1e30, 1)
+    for th in sorted(set(t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu)):
+        oracle.port.set_num_threads(th)
+        cases.flux_sweeps(oracle.port, cc, s, 1)
+        t1 = time.perf_counter()
+        cases.flux_sweeps(oracle.port, cc, s, 2)
+        el = time.perf_counter() - t1
+        if el < best[0]:
+            best = (el, th)
+    threads = best[1]
     oracle.port.set_num_threads(threads)
     s = cases.alloc_state(cc)
+    cc.T_lay = c.T_lay.copy()
     cases.setup_planck(oracle.port, cc, s)
     n_it = 20
     t0 = time.perf_counter()
@@ -105,8 +123,9 @@ def cpu_baseline(w, seed):
     dt = time.perf_counter() - t0
     return dict(value=n_it / dt * nb * c.nlayer, unit="bin*layer*iterations/s", cores=threads, kind="port",
                 sample="%d of %d bins x %d layers x %d Gauss points, %d iterations from iteration 0 "
-                       "(2 opacity refreshes), oracle/helios_oracle.c with OpenMP over bins, %.1f s"
-                       % (nb, w["nbin"], c.nlayer, c.ny, n_it, dt))
+                       "(2 opacity refreshes), oracle/helios_oracle.c with OpenMP over bins (%d of %d visible "
+                       "cores: fastest of a thread-count probe), %.1f s"
+                       % (nb, w["nbin"], c.nlayer, c.ny, n_it, threads, ncpu, dt))
 
 
 def main():

@@ -9,17 +9,18 @@ namespace hx {
 
 // How the (bin x, Gauss point y, half-layer h) space is cut into wavefront tiles.
 //
-//   * k lanes cooperate on one spectral point (x,y); lane j owns LPL whole layers
-//     [j*LPL, (j+1)*LPL) = ROWS = 2*LPL half-layers, kept in registers for all sweeps;
+//   * k lanes cooperate on one spectral point (x,y); lane j owns the ROWS half-layers
+//     [j*ROWS, (j+1)*ROWS), kept in registers for all sweeps;
 //   * a wavefront holds S = 64/k spectral points; lane = s*k + j;
 //   * a workgroup covers nxb bins x ypb Gauss points (G = nxb*ypb spectral points, NW wavefronts);
 //     nparts = ny/ypb workgroups share one bin and each writes a partial Gauss sum.
 struct TileGeom {
-    int k, LPL, ROWS, S;
+    int k, ROWS, S;
     int nxb, ypb, nparts, G, NW, threads;
     int nblk_x;       // workgroups along x per column = ceil(nbin / nxb)
     int nblk;         // workgroups per column = nblk_x * nparts
-    int nplane;       // coefficient planes per tile: alpha, beta, u', v' (+ dd, du with the beam)
+    int nplane;       // coefficient planes per tile: alpha, beta, u' [, v'] [, dd, du]
+    int has_vp, pl_vp, pl_dd;
     size_t tile_rows; // ROWS
     size_t coef_elems_per_col, flux_elems_per_col;  // doubles
 };

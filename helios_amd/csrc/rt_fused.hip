@@ -42,37 +42,44 @@ int h2d(hx_rt* rt, void* dst, const void* src, size_t bytes) {
     return hx_h2d(rt->ctx, dst, src, bytes);
 }
 
-bool choose_geometry(int L, int Y, int X, int dir_beam, TileGeom& g) {
-    int best_k = 0, best_lpl = 0, best_pad = 1 << 30;
+bool choose_geometry(int L, int Y, int X, int dir_beam, int scat_corr, TileGeom& g) {
+    const int H = 2 * L;
+    int best_k = 0, best_rows = 0, best_pad = 1 << 30;
     for (int k = 8; k <= 64; k <<= 1) {
-        const int lpl = (L + k - 1) / k;
-        if (lpl > 8) continue;
-        const int pad = k * lpl - L;
+        const int rows = (H + k - 1) / k;
+        if (rows > 16) continue;
+        const int pad = k * rows - H;
         if (pad < best_pad) {
             best_pad = pad;
             best_k = k;
-            best_lpl = lpl;
+            best_rows = rows;
         }
     }
     if (!best_k) return false;
     g.k = best_k;
-    g.LPL = best_lpl;
-    g.ROWS = 2 * best_lpl;
+    g.ROWS = best_rows;
     g.S = 64 / g.k;
-    // Gauss points per workgroup: the largest divisor of ny with ypb*k <= 320 threads
+    // workgroup size cap: HELIOS_RT_MAXTHREADS (tuning knob), default 320
+    int max_threads = 320;
+    if (const char* e = getenv("HELIOS_RT_MAXTHREADS")) max_threads = std::max(64, std::min(320, atoi(e)));
+    // Gauss points per workgroup: the largest divisor of ny with ypb*k <= max_threads
     g.ypb = 0;
     for (int v = 1; v <= Y; v++)
-        if (Y % v == 0 && v * g.k <= 320) g.ypb = v;
+        if (Y % v == 0 && v * g.k <= max_threads) g.ypb = v;
     if (!g.ypb) return false;
     g.nparts = Y / g.ypb;
-    g.nxb = (g.ypb == Y) ? std::max(1, 320 / (g.ypb * g.k)) : 1;
+    g.nxb = (g.ypb == Y) ? std::max(1, max_threads / (g.ypb * g.k)) : 1;
     g.nxb = std::min(g.nxb, X);
     g.G = g.nxb * g.ypb;
     g.NW = (g.G * g.k + 63) / 64;
     g.threads = g.NW * 64;
     g.nblk_x = (X + g.nxb - 1) / g.nxb;
     g.nblk = g.nblk_x * g.nparts;
-    g.nplane = dir_beam ? 6 : 4;
+    // planes: alpha, beta, u' always; v' only when E != 1 can occur; dd, du only with the beam
+    g.has_vp = scat_corr ? 1 : 0;
+    g.pl_vp = 3;
+    g.pl_dd = 3 + g.has_vp;
+    g.nplane = 3 + g.has_vp + (dir_beam ? 2 : 0);
     g.tile_rows = g.ROWS;
     g.coef_elems_per_col = (size_t)g.nblk * g.NW * g.nplane * g.ROWS * 64;
     g.flux_elems_per_col = (size_t)g.nblk * g.NW * g.ROWS * 64;
@@ -84,9 +91,11 @@ KArgs make_args(hx_rt* rt) {
     memset(&a, 0, sizeof(a));
     const TileGeom& g = rt->g;
     a.X = rt->X; a.Y = rt->Y; a.L = rt->L; a.I = rt->I; a.H = rt->H; a.C = rt->C;
-    a.k = g.k; a.LPL = g.LPL; a.ROWS = g.ROWS; a.S = g.S; a.nxb = g.nxb; a.ypb = g.ypb;
+    a.k = g.k; a.LPL = 0; a.ROWS = g.ROWS; a.S = g.S; a.nxb = g.nxb; a.ypb = g.ypb;
     a.nparts = g.nparts; a.G = g.G; a.NW = g.NW; a.nblk_x = g.nblk_x; a.nblk = g.nblk;
     a.nplane = g.nplane; a.nchunk = rt->nchunk;
+    a.has_vp = g.has_vp; a.pl_vp = g.pl_vp; a.pl_dd = g.pl_dd;
+    a.Kconst = 2.0 * HX_PI * rt->f.epsi;
     a.scat = rt->f.scat; a.dir_beam = rt->f.dir_beam; a.clouds = rt->f.clouds;
     a.scat_corr = rt->f.scat_corr; a.nsweep = rt->nsweep; a.keep_down = rt->keep_down ? 1 : 0;
     a.real_star = rt->f.real_star;
@@ -152,22 +161,22 @@ struct ProfScope {
     }
 };
 
-template <int LPL>
+template <int ROWS>
 void launch_flux(hx_rt* rt, const KArgs& a) {
     const TileGeom& g = rt->g;
     const size_t shmem = ((size_t)g.nxb * (rt->H + 3) + (size_t)g.ypb * g.nxb * 2 * rt->I) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<LPL>), dim3(g.nblk, rt->C), dim3(g.threads), shmem,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk, rt->C), dim3(g.threads), shmem,
                        rt->ctx->stream, a);
 }
-template <int LPL>
+template <int ROWS>
 void launch_coef(hx_rt* rt, const KArgs& a) {
     const TileGeom& g = rt->g;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<LPL>), dim3(g.nblk, rt->C), dim3(g.threads), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<ROWS>), dim3(g.nblk, rt->C), dim3(g.threads), 0,
                        rt->ctx->stream, a);
 }
 
-#define DISPATCH_LPL(fn, rt, a)                   \
-    switch ((rt)->g.LPL) {                        \
+#define DISPATCH_ROWS(fn, rt, a)                  \
+    switch ((rt)->g.ROWS) {                       \
         case 1: fn<1>(rt, a); break;              \
         case 2: fn<2>(rt, a); break;              \
         case 3: fn<3>(rt, a); break;              \
@@ -175,7 +184,15 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
         case 5: fn<5>(rt, a); break;              \
         case 6: fn<6>(rt, a); break;              \
         case 7: fn<7>(rt, a); break;              \
-        default: fn<8>(rt, a); break;             \
+        case 8: fn<8>(rt, a); break;              \
+        case 9: fn<9>(rt, a); break;              \
+        case 10: fn<10>(rt, a); break;            \
+        case 11: fn<11>(rt, a); break;            \
+        case 12: fn<12>(rt, a); break;            \
+        case 13: fn<13>(rt, a); break;            \
+        case 14: fn<14>(rt, a); break;            \
+        case 15: fn<15>(rt, a); break;            \
+        default: fn<16>(rt, a); break;            \
     }
 
 int set_flux_shmem_limits(hx_rt* rt) {
@@ -183,10 +200,13 @@ int set_flux_shmem_limits(hx_rt* rt) {
     const size_t shmem = ((size_t)g.nxb * (rt->H + 3) + (size_t)g.ypb * g.nxb * 2 * rt->I) * sizeof(double);
     if (shmem > 160 * 1024) return rt_fail(rt, HX_E_UNSUPPORTED, "workgroup LDS demand exceeds 160 KiB");
     if (shmem <= 64 * 1024) return 0;
-    const void* fns[8] = {(const void*)k_rt_flux<1>, (const void*)k_rt_flux<2>, (const void*)k_rt_flux<3>,
-                          (const void*)k_rt_flux<4>, (const void*)k_rt_flux<5>, (const void*)k_rt_flux<6>,
-                          (const void*)k_rt_flux<7>, (const void*)k_rt_flux<8>};
-    HX_HIP(rt->ctx, hipFuncSetAttribute(fns[rt->g.LPL - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
+    const void* fns[16] = {(const void*)k_rt_flux<1>, (const void*)k_rt_flux<2>, (const void*)k_rt_flux<3>,
+                           (const void*)k_rt_flux<4>, (const void*)k_rt_flux<5>, (const void*)k_rt_flux<6>,
+                           (const void*)k_rt_flux<7>, (const void*)k_rt_flux<8>, (const void*)k_rt_flux<9>,
+                           (const void*)k_rt_flux<10>, (const void*)k_rt_flux<11>, (const void*)k_rt_flux<12>,
+                           (const void*)k_rt_flux<13>, (const void*)k_rt_flux<14>, (const void*)k_rt_flux<15>,
+                           (const void*)k_rt_flux<16>};
+    HX_HIP(rt->ctx, hipFuncSetAttribute(fns[rt->g.ROWS - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)shmem));
     return 0;
 }
@@ -219,12 +239,12 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     rt->X = dims->nbin; rt->Y = dims->ny; rt->L = dims->nlayer; rt->I = rt->L + 1; rt->H = 2 * rt->L;
     rt->C = dims->ncol;
     rt->nsweep = 3 * (flags->scat ? 1 : 0) + 1;  // computation.py:531-537 (iterative run type)
-    if (!choose_geometry(rt->L, rt->Y, rt->X, flags->dir_beam, rt->g) || 2 * rt->I > 1024) {
+    if (!choose_geometry(rt->L, rt->Y, rt->X, flags->dir_beam, flags->scat_corr, rt->g)) {
         delete rt;
         return hx_fail(ctx, HX_E_UNSUPPORTED,
-                       "fused path supports nlayer <= 511 and ny*k <= 320 tiles; use the per-stage API");
+                       "fused path supports nlayer <= 512; use the per-stage API");
     }
-    rt->nchunk = std::max(1, std::min(128, (rt->X + 63) / 64));
+    rt->nchunk = std::max(1, std::min(256, (rt->X + 15) / 16));
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
     int rc = set_flux_shmem_limits(rt);
     if (rc) { delete rt; return rc; }
@@ -632,7 +652,7 @@ int hx_rt_refresh(hx_rt* rt) {
     }
     {
         ProfScope ps(rt, "rt_coef");
-        DISPATCH_LPL(launch_coef, rt, a);
+        DISPATCH_ROWS(launch_coef, rt, a);
         HX_LAUNCH_CHECK(ctx);
     }
     rt->refreshed = true;
@@ -650,13 +670,12 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
     }
     {
         ProfScope ps(rt, "rt_flux");
-        DISPATCH_LPL(launch_flux, rt, a);
+        DISPATCH_ROWS(launch_flux, rt, a);
         HX_LAUNCH_CHECK(ctx);
     }
     {
         ProfScope ps(rt, "rt_totals_a");
-        const int thr = ((2 * rt->I + 63) / 64) * 64;
-        k_rt_totals_a<<<dim3(rt->nchunk, rt->C), thr, 0, ctx->stream>>>(a);
+        k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
     }
     {

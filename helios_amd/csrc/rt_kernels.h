@@ -9,7 +9,9 @@
 //   up  :  U[h+1] = alpha U[h]   + beta D[h+1] + u' B[h+1] + v' B[h]   + du
 // (B = Planck function at the node; dd/du = min(0, direct-beam term)/M).  The coefficient planes are
 // built once per opacity refresh (k_rt_coef) and streamed once per iteration (k_rt_flux), where
-// each lane keeps its 2*LPL half-layers in registers across all 3*scat+1 sweeps.
+// each lane keeps its ROWS half-layers in registers across all 3*scat+1 sweeps.
+// Since u + v = M + N - P in both branches, v' = K (1 - alpha - beta) - u'; without the improved
+// two-stream correction E == 1 and K = 2 pi eps is a constant, so the v' plane is not stored then.
 #pragma once
 #include "rt_fused.h"
 #include "temp_step.h"
@@ -21,6 +23,8 @@ struct KArgs {
     int X, Y, L, I, H, C;
     int k, LPL, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk;
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
+    int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
+    double Kconst;             // 2 pi eps: source prefactor when E == 1 (scat_corr == 0)
     int dim, step;
     double epsi, epsi2, g_0, i2s, w_0_limit, w_0_scat_limit, dtau_limit;
     const hx_rt_column* colpar;
@@ -104,9 +108,8 @@ __device__ __forceinline__ LaneMap lane_map(const KArgs& a) {
 }
 
 // ---- per refresh: compact coefficient tiles ---------------------------------------------------
-template <int LPL>
+template <int ROWS>
 __global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
-    constexpr int ROWS = 2 * LPL;
     const int col = blockIdx.y;
     if (a.done[col]) return;
     const LaneMap m = lane_map(a);
@@ -190,10 +193,10 @@ __global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
         ctile[(0 * ROWS + r) * 64] = alpha;
         ctile[(1 * ROWS + r) * 64] = beta;
         ctile[(2 * ROWS + r) * 64] = up;
-        ctile[(3 * ROWS + r) * 64] = vp;
-        if (a.nplane == 6) {
-            ctile[(4 * ROWS + r) * 64] = dd;
-            ctile[(5 * ROWS + r) * 64] = du;
+        if (a.has_vp) ctile[(a.pl_vp * ROWS + r) * 64] = vp;
+        if (a.dir_beam == 1) {
+            ctile[(a.pl_dd * ROWS + r) * 64] = dd;
+            ctile[((a.pl_dd + 1) * ROWS + r) * 64] = du;
         }
     }
 }
@@ -226,9 +229,8 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 }
 
 // ---- per iteration: all two-stream sweeps + Gauss quadrature ---------------------------------
-template <int LPL>
+template <int ROWS>
 __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
-    constexpr int ROWS = 2 * LPL;
     extern __shared__ __align__(16) double smem[];
     const int col = blockIdx.y;
     if (a.done[col]) return;
@@ -257,8 +259,14 @@ __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
         al[r] = ctile[(0 * ROWS + r) * 64];
         be[r] = ctile[(1 * ROWS + r) * 64];
         sd[r] = ctile[(2 * ROWS + r) * 64];  // u' for now
-        su[r] = ctile[(3 * ROWS + r) * 64];  // v' for now
         Uo[r] = utile[r * 64];
+    }
+    if (a.has_vp) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) su[r] = ctile[(a.pl_vp * ROWS + r) * 64];  // v' for now
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) su[r] = a.Kconst * ((1.0 - al[r]) - be[r]) - sd[r];
     }
     double U0 = 0.0, boaK = 0.0, Fdir0 = 0.0, albedo = 0.0;
     if (m.valid && m.j == 0) {
@@ -276,11 +284,11 @@ __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
         sd[r] = upc * Bb + vpc * Bt;
         su[r] = upc * Bt + vpc * Bb;
     }
-    if (a.nplane == 6) {
+    if (a.dir_beam == 1) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
-            sd[r] += ctile[(4 * ROWS + r) * 64];
-            su[r] += ctile[(5 * ROWS + r) * 64];
+            sd[r] += ctile[(a.pl_dd * ROWS + r) * 64];
+            su[r] += ctile[((a.pl_dd + 1) * ROWS + r) * 64];
         }
     }
     const double rs = cp.R_star / cp.a;
@@ -348,7 +356,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
             for (int r = 0; r < ROWS; r++) {
                 const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
                 U = fma(al[r], U, fma(be[r], Dh, su[r]));
-                if (r & 1) U = tiny_abs(U);  // interface nodes only (reference quirk, kernels.cu:1763)
+                if ((m.j * ROWS + r) & 1) U = tiny_abs(U);  // interface nodes only (reference quirk, kernels.cu:1763)
                 Uo[r] = U;
             }
         }
@@ -373,7 +381,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
         for (int r = 0; r < ROWS; r++) {
             const int h = m.j * ROWS + r;
             if (h < a.H) {
-                if ((r & 1) == 0) st[h >> 1] = w * Do[r];           // D at interface h/2
+                if ((h & 1) == 0) st[h >> 1] = w * Do[r];           // D at interface h/2
                 else st[I + ((h + 1) >> 1)] = w * Uo[r];            // U at interface (h+1)/2
             }
         }
@@ -394,25 +402,28 @@ __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
 }
 
 // ---- per iteration: band fluxes (sum of Gauss-point partials) and chunked wavelength totals ---
-__global__ void __launch_bounds__(1024) k_rt_totals_a(KArgs a) {
+// grid (nchunk, C), 256 threads.  Thread t owns the (dir, i) slots t, t+256, ... (< 2I) and walks the
+// bins of its chunk: consecutive threads read consecutive addresses of band_part[part][x][dir][i].
+__global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
     const int col = blockIdx.y, chunk = blockIdx.x;
     if (a.done[col]) return;
-    const int I = a.I, t = threadIdx.x;
-    if (t >= 2 * I) return;
-    const int dir = t / I, i = t - dir * I;
+    const int I = a.I;
     const int per = (a.X + a.nchunk - 1) / a.nchunk;
     const int x0 = chunk * per, x1 = min(a.X, x0 + per);
-    double* band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
     const double* fdir = a.F_dir_band_n + (size_t)col * a.X * I;
-    double acc = 0.0;
-    for (int x = x0; x < x1; x++) {
-        double v = 0.0;
-        for (int p = 0; p < a.nparts; p++)
-            v += a.band_part[(((size_t)col * a.nparts + p) * a.X + x) * 2 * I + t];
-        band[(size_t)x * I + i] = v;
-        acc += (dir == 0 ? fdir[(size_t)x * I + i] + v : v) * a.deltawave[x];
+    for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
+        const int dir = t / I, i = t - dir * I;
+        double* band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
+        double acc = 0.0;
+        for (int x = x0; x < x1; x++) {
+            double v = 0.0;
+            for (int p = 0; p < a.nparts; p++)
+                v += a.band_part[(((size_t)col * a.nparts + p) * a.X + x) * 2 * I + t];
+            band[(size_t)x * I + i] = v;
+            acc += (dir == 0 ? fdir[(size_t)x * I + i] + v : v) * a.deltawave[x];
+        }
+        a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
     }
-    a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
 }
 
 struct TotalsBArgs {
@@ -432,12 +443,22 @@ __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
     double* up = a.F_up_tot + (size_t)col * I;
     double* down = a.F_down_tot + (size_t)col * I;
     double* net = a.F_net + (size_t)col * I;
-    for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
+    // chunk partials -> totals: 4 segments of chunks per (dir, i) slot, combined in a fixed order
+    __shared__ double seg[4][256];
+    for (int t0 = 0; t0 < 2 * I; t0 += 256) {
+        const int t = t0 + (threadIdx.x & 255), sgm = threadIdx.x >> 8;
+        const int cper = (a.nchunk + 3) / 4, c0 = sgm * cper, c1 = min(a.nchunk, c0 + cper);
         double s = 0.0;
-        for (int c = 0; c < a.nchunk; c++) s += a.tot_part[(((size_t)col * a.nchunk + c) * 2) * I + t];
-        if (t < I) down[t] = s; else up[t - I] = s;
+        if (t < 2 * I)
+            for (int c = c0; c < c1; c++) s += a.tot_part[(((size_t)col * a.nchunk + c) * 2) * I + t];
+        seg[sgm][threadIdx.x & 255] = s;
+        __syncthreads();
+        if (sgm == 0 && t < 2 * I) {
+            const double tot = ((seg[0][threadIdx.x] + seg[1][threadIdx.x]) + seg[2][threadIdx.x]) + seg[3][threadIdx.x];
+            if (t < I) down[t] = tot; else up[t - I] = tot;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int i = threadIdx.x; i < I; i += blockDim.x) net[i] = up[i] - down[i];
     __syncthreads();
     if (!q.step_temperature) return;

@@ -19,7 +19,7 @@ def hip():
 def test_stage_chain_golden(hip, name):
     # libm differences (OCML vs glibc exp/log10/pow, <= 1-2 ulp) enter here: 1e-10 after one
     # iteration, 1e-7 after twelve (tolerance of the north star: 1e-6 on fluxes)
-    gc.check_chain(hip, name, rtol1=1e-10, rtol12=1e-7, planck_rtol=1e-9)
+    gc.check_chain(hip, name, rtol1=1e-10, rtol12=1e-7, planck_rtol=1e-8)
 
 
 def test_mixing_golden(hip):
@@ -39,7 +39,7 @@ def test_stage_chain_vs_oracle(hip, port, cfg):
         out.append((c, s))
     (ch, sh), (cp, sp) = out
     scale = max(np.abs(sp.F_down_wg).max(), np.abs(sp.F_dir_wg).max())
-    np.testing.assert_allclose(sh.planck_grid, sp.planck_grid, rtol=1e-9, atol=1e-280)
+    np.testing.assert_allclose(sh.planck_grid, sp.planck_grid, rtol=1e-8, atol=1e-280)
     for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "meanmolmass_lay", "planckband_lay"):
         np.testing.assert_allclose(sh[k], sp[k], rtol=1e-11, atol=1e-13 * np.abs(sp[k]).max(), err_msg=k)
     for k in ("F_down_wg", "F_up_wg", "F_dir_wg", "F_down_band", "F_up_band"):
