@@ -45,9 +45,12 @@ int h2d(hx_rt* rt, void* dst, const void* src, size_t bytes) {
 bool choose_geometry(int L, int Y, int X, int dir_beam, int scat_corr, TileGeom& g) {
     const int H = 2 * L;
     int best_k = 0, best_rows = 0, best_pad = 1 << 30;
+    int force_k = 0;
+    if (const char* e = getenv("HELIOS_RT_K")) force_k = atoi(e);  // tuning knob
     for (int k = 8; k <= 64; k <<= 1) {
         const int rows = (H + k - 1) / k;
         if (rows > 16) continue;
+        if (force_k && k != force_k) continue;
         const int pad = k * rows - H;
         if (pad < best_pad) {
             best_pad = pad;
@@ -59,17 +62,27 @@ bool choose_geometry(int L, int Y, int X, int dir_beam, int scat_corr, TileGeom&
     g.k = best_k;
     g.ROWS = best_rows;
     g.S = 64 / g.k;
-    // workgroup size cap: HELIOS_RT_MAXTHREADS (tuning knob), default 320
-    int max_threads = 320;
+    // Workgroup shape.  Single-wavefront workgroups measured fastest on MI355X (8 independent
+    // wavefronts per CU drift out of phase, so loads of one overlap the sweeps of another);
+    // HELIOS_RT_MAXTHREADS is a tuning knob (64..320).
+    int max_threads = 64;
     if (const char* e = getenv("HELIOS_RT_MAXTHREADS")) max_threads = std::max(64, std::min(320, atoi(e)));
-    // Gauss points per workgroup: the largest divisor of ny with ypb*k <= max_threads
+    // ypb = Gauss points per pass (a divisor of ny), nxb = bins per workgroup: fill the lanes
     g.ypb = 0;
-    for (int v = 1; v <= Y; v++)
-        if (Y % v == 0 && v * g.k <= max_threads) g.ypb = v;
+    double best_util = -1.0;
+    for (int v = 1; v <= Y; v++) {
+        if (Y % v != 0 || v * g.k > max_threads) continue;
+        const int nx = std::min(std::max(1, max_threads / (v * g.k)), X);
+        const int lanes = nx * v * g.k;
+        const double util = (double)lanes / (((lanes + 63) / 64) * 64);
+        if (util >= best_util) {
+            best_util = util;
+            g.ypb = v;
+            g.nxb = nx;
+        }
+    }
     if (!g.ypb) return false;
     g.nparts = Y / g.ypb;
-    g.nxb = (g.ypb == Y) ? std::max(1, max_threads / (g.ypb * g.k)) : 1;
-    g.nxb = std::min(g.nxb, X);
     g.G = g.nxb * g.ypb;
     g.NW = (g.G * g.k + 63) / 64;
     g.threads = g.NW * 64;
@@ -161,17 +174,23 @@ struct ProfScope {
     }
 };
 
+size_t flux_shmem_bytes(hx_rt* rt) {
+    const TileGeom& g = rt->g;
+    return ((size_t)g.nxb * (rt->H + 3) + (size_t)g.nxb * 2 * rt->I + (size_t)g.ypb * g.nxb * 2 * rt->I) *
+           sizeof(double);
+}
+
 template <int ROWS>
 void launch_flux(hx_rt* rt, const KArgs& a) {
     const TileGeom& g = rt->g;
-    const size_t shmem = ((size_t)g.nxb * (rt->H + 3) + (size_t)g.ypb * g.nxb * 2 * rt->I) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk, rt->C), dim3(g.threads), shmem,
+    const size_t shmem = flux_shmem_bytes(rt);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                        rt->ctx->stream, a);
 }
 template <int ROWS>
 void launch_coef(hx_rt* rt, const KArgs& a) {
     const TileGeom& g = rt->g;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<ROWS>), dim3(g.nblk, rt->C), dim3(g.threads), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<ROWS>), dim3(g.nblk_x, g.nparts, rt->C), dim3(g.threads), 0,
                        rt->ctx->stream, a);
 }
 
@@ -196,8 +215,7 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
     }
 
 int set_flux_shmem_limits(hx_rt* rt) {
-    const TileGeom& g = rt->g;
-    const size_t shmem = ((size_t)g.nxb * (rt->H + 3) + (size_t)g.ypb * g.nxb * 2 * rt->I) * sizeof(double);
+    const size_t shmem = flux_shmem_bytes(rt);
     if (shmem > 160 * 1024) return rt_fail(rt, HX_E_UNSUPPORTED, "workgroup LDS demand exceeds 160 KiB");
     if (shmem <= 64 * 1024) return 0;
     const void* fns[16] = {(const void*)k_rt_flux<1>, (const void*)k_rt_flux<2>, (const void*)k_rt_flux<3>,
@@ -244,7 +262,7 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
         return hx_fail(ctx, HX_E_UNSUPPORTED,
                        "fused path supports nlayer <= 512; use the per-stage API");
     }
-    rt->nchunk = std::max(1, std::min(256, (rt->X + 15) / 16));
+    rt->nchunk = std::max(1, std::min(512, (rt->X + 31) / 32));
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
     int rc = set_flux_shmem_limits(rt);
     if (rc) { delete rt; return rc; }
@@ -282,7 +300,6 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     RT_ALLOC(rt->coef, C * rt->g.coef_elems_per_col);
     RT_ALLOC(rt->Utile, C * rt->g.flux_elems_per_col);
     RT_ALLOC(rt->U0, C * nc); RT_ALLOC(rt->boaK, C * nc); RT_ALLOC(rt->Fdir0, C * nc);
-    RT_ALLOC(rt->band_part, C * rt->g.nparts * X * 2 * I);
     RT_ALLOC(rt->F_down_band_n, C * X * I); RT_ALLOC(rt->F_up_band_n, C * X * I);
     RT_ALLOC(rt->tot_part, C * rt->nchunk * 2 * I);
     RT_ALLOC(rt->F_up_tot, C * I); RT_ALLOC(rt->F_down_tot, C * I); RT_ALLOC(rt->F_net, C * I);
@@ -771,7 +788,7 @@ int get_flux_wg(hx_rt* rt, int col, const double* tiles, const double* bc, bool 
     double* o = (double*)out;
     std::fill(o, o + nc * I, 0.0);
     for (int blk = 0; blk < g.nblk; blk++) {
-        const int bx = blk % g.nblk_x, part = blk / g.nblk_x;
+        const int bx = blk / g.nparts, part = blk % g.nparts;
         for (int s = 0; s < g.G; s++) {
             const int xl = s / g.ypb, yl = s % g.ypb;
             const size_t x = (size_t)bx * g.nxb + xl, y = (size_t)part * g.ypb + yl;
@@ -824,6 +841,8 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
     if (n == "g_0_tot_lay") return get_plain(rt, rt->g0_tot_lay + c * X * I, X * L * 8, out, out_bytes);
     if (n == "g_0_tot_int") return get_plain(rt, rt->g0_tot_int + c * X * I, X * I * 8, out, out_bytes);
     if (n == "iters_done") return get_plain(rt, rt->iters_done + c, 4, out, out_bytes);
+    if (n == "planck_grid")
+        return get_plain(rt, rt->planck_grid, (size_t)(rt->d.plancktable_dim + 1) * X * 8, out, out_bytes);
     if (n == "done") return get_plain(rt, rt->done + c, 4, out, out_bytes);
     if (n == "planckband_lay" || n == "planckband_int") {
         // from the node array Bn[x][H+3]: layers = odd nodes, then star, surface; interfaces = even
@@ -951,8 +970,7 @@ int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* r
     const double tiles = (double)g.nblk * g.NW * 64.0 * g.ROWS * 8.0;  // one plane
     const double flux_k = tiles * (g.nplane + 2.0 + (rt->keep_down ? 1.0 : 0.0))   // coef + U read/write
                           + 8.0 * X * (rt->H + 3) * 2.0                            // node Planck write+read
-                          + 8.0 * X * 4.0 * (L + 1) * g.nparts                     // band partials w + r
-                          + 8.0 * X * 2.0 * (L + 1)                                // band arrays
+                          + 8.0 * X * 2.0 * (L + 1) * 2.0                          // band arrays w + r
                           + 8.0 * X * Y * 2.0;                                     // U0
     const double premixed = 8.0 * Y * X * (2 * L + 1) * 5.0;
     const double species = 8.0 * Y * X * (2 * L + 1) * S * (4.0 + 1.0 + 1.0 + 2.0);  // corners + spec w/r + mix r/w

@@ -89,30 +89,30 @@ struct LaneMap {
     size_t tile;      // index of this lane's wavefront tile within the column
 };
 
-__device__ __forceinline__ LaneMap lane_map(const KArgs& a) {
+// workgroup bx covers bins [bx*nxb, (bx+1)*nxb) and walks the nparts groups of ypb Gauss points
+__device__ __forceinline__ LaneMap lane_map(const KArgs& a, int bx, int part) {
     LaneMap m;
     const int tid = threadIdx.x;
     m.lane = tid & 63;
     m.wv = tid >> 6;
     m.j = m.lane % a.k;
     const int s_local = tid / a.k;
-    const int bx = blockIdx.x % a.nblk_x, part = blockIdx.x / a.nblk_x;
     m.xl = s_local / a.ypb;
     m.yl = s_local - m.xl * a.ypb;
     m.x = bx * a.nxb + m.xl;
     m.y = part * a.ypb + m.yl;
     m.valid = s_local < a.G && m.x < a.X;
     m.sp = (size_t)m.y + (size_t)a.Y * m.x;
-    m.tile = (size_t)blockIdx.x * a.NW + m.wv;
+    m.tile = ((size_t)bx * a.nparts + part) * a.NW + m.wv;
     return m;
 }
 
 // ---- per refresh: compact coefficient tiles ---------------------------------------------------
 template <int ROWS>
 __global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
-    const int col = blockIdx.y;
+    const int col = blockIdx.z;
     if (a.done[col]) return;
-    const LaneMap m = lane_map(a);
+    const LaneMap m = lane_map(a, blockIdx.x, blockIdx.y);
     const hx_rt_column cp = a.colpar[col];
     const size_t nc = (size_t)a.Y * a.X;
     const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
@@ -229,199 +229,204 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 }
 
 // ---- per iteration: all two-stream sweeps + Gauss quadrature ---------------------------------
+// grid (nblk_x, C).  A workgroup owns nxb bins and walks their ny/ypb groups of Gauss points one
+// after the other, so the Gauss sum of a bin is completed inside the workgroup (fixed order).
 template <int ROWS>
 __global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = blockIdx.y;
     if (a.done[col]) return;
-    const LaneMap m = lane_map(a);
-    const int NN = a.H + 3;
-    double* sB = smem;                          // [nxb][NN]
-    double* stage = smem + (size_t)a.nxb * NN;  // [ypb][nxb][2][I]
+    const int bx = blockIdx.x;
+    const int NN = a.H + 3, I = a.I;
+    double* sB = smem;                               // [nxb][NN]  Planck function at the nodes
+    double* acc = sB + (size_t)a.nxb * NN;           // [nxb][2][I] band fluxes being accumulated
+    double* stage = acc + (size_t)a.nxb * 2 * I;     // [ypb][nxb][2][I]
     const hx_rt_column cp = a.colpar[col];
     const size_t nc = (size_t)a.Y * a.X;
-
-    // Planck function at the nodes of this workgroup's bins -> LDS
-    {
-        const int bx = blockIdx.x % a.nblk_x;
-        for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
-            const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
-            sB[t] = x < a.X ? a.Bn[((size_t)col * a.X + x) * NN + n] : 0.0;
-        }
-    }
-    // coefficient planes and up-flux state -> registers
-    const size_t toff = m.tile * (size_t)ROWS * 64 + m.lane;
-    const double* ctile = a.coef + col * a.coef_col + m.tile * (size_t)a.nplane * ROWS * 64 + m.lane;
-    double* utile = a.Utile + col * a.flux_col + toff;
-    double al[ROWS], be[ROWS], sd[ROWS], su[ROWS], Uo[ROWS], Do[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        al[r] = ctile[(0 * ROWS + r) * 64];
-        be[r] = ctile[(1 * ROWS + r) * 64];
-        sd[r] = ctile[(2 * ROWS + r) * 64];  // u' for now
-        Uo[r] = utile[r * 64];
-    }
-    if (a.has_vp) {
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) su[r] = ctile[(a.pl_vp * ROWS + r) * 64];  // v' for now
-    } else {
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) su[r] = a.Kconst * ((1.0 - al[r]) - be[r]) - sd[r];
-    }
-    double U0 = 0.0, boaK = 0.0, Fdir0 = 0.0, albedo = 0.0;
-    if (m.valid && m.j == 0) {
-        U0 = a.U0[col * nc + m.sp];
-        boaK = a.boaK[col * nc + m.sp];
-        Fdir0 = a.Fdir0[col * nc + m.sp];
-        albedo = a.surf_albedo[(size_t)col * a.X + m.x];
-    }
-    __syncthreads();
-    const double* Bx = sB + (size_t)(m.valid ? m.xl : 0) * NN;
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int h = min(m.j * ROWS + r, a.H - 1);
-        const double Bb = Bx[h], Bt = Bx[h + 1], upc = sd[r], vpc = su[r];
-        sd[r] = upc * Bb + vpc * Bt;
-        su[r] = upc * Bt + vpc * Bb;
-    }
-    if (a.dir_beam == 1) {
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            sd[r] += ctile[(a.pl_dd * ROWS + r) * 64];
-            su[r] += ctile[((a.pl_dd + 1) * ROWS + r) * 64];
-        }
-    }
-    const double rs = cp.R_star / cp.a;
-    const double D_toa = (1.0 - a.dir_beam) * cp.f_factor * (rs * rs) * HX_PI * Bx[a.H + 1];
-    const double B_surf = Bx[a.H + 2];
     const int k = a.k;
 
-    for (int sweep = 0; sweep < a.nsweep; sweep++) {
-        // ---------------- down: TOA -> BOA ----------------
-        {
-            double Ubelow = __shfl_up(Uo[ROWS - 1], 1, k);  // U at the bottom node of this chunk
-            if (m.j == 0) Ubelow = U0;
-            double A = 1.0, Bc = 0.0;
-#pragma unroll
-            for (int r = ROWS - 1; r >= 0; r--) {
-                const double Uh = r > 0 ? Uo[r - 1] : Ubelow;
-                const double t = fma(be[r], Uh, sd[r]);
-                Bc = fma(al[r], Bc, t);
-                A *= al[r];
-            }
-            // inclusive suffix composition over the k lanes of this spectral point
-            for (int d = 1; d < k; d <<= 1) {
-                const double A2 = __shfl_down(A, d, k), B2 = __shfl_down(Bc, d, k);
-                if (m.j + d < k) {
-                    Bc = fma(A, B2, Bc);
-                    A *= A2;
-                }
-            }
-            double Din = __shfl_down(fma(A, D_toa, Bc), 1, k);
-            if (m.j == k - 1) Din = D_toa;
-            double D = Din;
-#pragma unroll
-            for (int r = ROWS - 1; r >= 0; r--) {
-                const double Uh = r > 0 ? Uo[r - 1] : Ubelow;
-                D = tiny_abs(fma(al[r], D, fma(be[r], Uh, sd[r])));
-                Do[r] = D;
-            }
-        }
-        // ---------------- BOA boundary ----------------
-        if (m.j == 0) U0 = albedo * (Fdir0 + Do[0]) + (1.0 - albedo) * HX_PI * boaK * B_surf;
-        const double Ubc = __shfl(U0, 0, k);
-        // ---------------- up: BOA -> TOA ----------------
-        {
-            double Dabove = __shfl_down(Do[0], 1, k);  // D at the top node of this chunk
-            if (m.j == k - 1) Dabove = D_toa;
-            double A = 1.0, Bc = 0.0;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
-                const double t = fma(be[r], Dh, su[r]);
-                Bc = fma(al[r], Bc, t);
-                A *= al[r];
-            }
-            for (int d = 1; d < k; d <<= 1) {
-                const double A2 = __shfl_up(A, d, k), B2 = __shfl_up(Bc, d, k);
-                if (m.j >= d) {
-                    Bc = fma(A, B2, Bc);
-                    A *= A2;
-                }
-            }
-            double Uin = __shfl_up(fma(A, Ubc, Bc), 1, k);
-            if (m.j == 0) Uin = Ubc;
-            double U = Uin;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
-                U = fma(al[r], U, fma(be[r], Dh, su[r]));
-                if ((m.j * ROWS + r) & 1) U = tiny_abs(U);  // interface nodes only (reference quirk, kernels.cu:1763)
-                Uo[r] = U;
-            }
-        }
+    for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
+        const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
+        sB[t] = x < a.X ? a.Bn[((size_t)col * a.X + x) * NN + n] : 0.0;
     }
+    for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) acc[t] = 0.0;
+    __syncthreads();
 
-    // state back to HBM
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) utile[r * 64] = Uo[r];
-    if (a.keep_down) {
-        double* dtile = a.Dtile + col * a.flux_col + toff;
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) dtile[r * 64] = Do[r];
-    }
-    if (m.valid && m.j == 0) a.U0[col * nc + m.sp] = U0;
-
-    // Gauss quadrature of the interface fluxes: stage[yl][xl][dir][i], then sum over yl in order
-    const int I = a.I;
-    if (m.valid) {
-        const double w = 0.5 * a.gauss_w[m.y];
-        double* st = stage + ((size_t)m.yl * a.nxb + m.xl) * 2 * I;
+    for (int part = 0; part < a.nparts; part++) {
+        const LaneMap m = lane_map(a, bx, part);
+        // coefficient planes and up-flux state -> registers
+        const size_t toff = m.tile * (size_t)ROWS * 64 + m.lane;
+        const double* ctile = a.coef + col * a.coef_col + m.tile * (size_t)a.nplane * ROWS * 64 + m.lane;
+        double* utile = a.Utile + col * a.flux_col + toff;
+        double al[ROWS], be[ROWS], sd[ROWS], su[ROWS], Uo[ROWS], Do[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
-            const int h = m.j * ROWS + r;
-            if (h < a.H) {
-                if ((h & 1) == 0) st[h >> 1] = w * Do[r];           // D at interface h/2
-                else st[I + ((h + 1) >> 1)] = w * Uo[r];            // U at interface (h+1)/2
+            al[r] = ctile[(0 * ROWS + r) * 64];
+            be[r] = ctile[(1 * ROWS + r) * 64];
+            sd[r] = ctile[(2 * ROWS + r) * 64];  // u' for now
+            Uo[r] = utile[r * 64];
+        }
+        if (a.has_vp) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) su[r] = ctile[(a.pl_vp * ROWS + r) * 64];  // v' for now
+        } else {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) su[r] = a.Kconst * ((1.0 - al[r]) - be[r]) - sd[r];
+        }
+        double U0 = 0.0, boaK = 0.0, Fdir0 = 0.0, albedo = 0.0;
+        if (m.valid && m.j == 0) {
+            U0 = a.U0[col * nc + m.sp];
+            boaK = a.boaK[col * nc + m.sp];
+            Fdir0 = a.Fdir0[col * nc + m.sp];
+            albedo = a.surf_albedo[(size_t)col * a.X + m.x];
+        }
+        const double* Bx = sB + (size_t)(m.valid ? m.xl : 0) * NN;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int h = min(m.j * ROWS + r, a.H - 1);
+            const double Bb = Bx[h], Bt = Bx[h + 1], upc = sd[r], vpc = su[r];
+            sd[r] = upc * Bb + vpc * Bt;
+            su[r] = upc * Bt + vpc * Bb;
+        }
+        if (a.dir_beam == 1) {
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                sd[r] += ctile[(a.pl_dd * ROWS + r) * 64];
+                su[r] += ctile[((a.pl_dd + 1) * ROWS + r) * 64];
             }
         }
-        if (m.j == 0) st[I + 0] = w * U0;
-        if (m.j * ROWS <= a.H - 1 && a.H - 1 < (m.j + 1) * ROWS) st[a.L] = w * D_toa;
-    }
-    __syncthreads();
-    {
-        const int bx = blockIdx.x % a.nblk_x, part = blockIdx.x / a.nblk_x;
-        for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
-            const int xl = t / (2 * I), rest = t - xl * 2 * I, x = bx * a.nxb + xl;
-            if (x >= a.X) continue;
-            double s = 0.0;
-            for (int yl = 0; yl < a.ypb; yl++) s += stage[((size_t)yl * a.nxb + xl) * 2 * I + rest];
-            a.band_part[(((size_t)col * a.nparts + part) * a.X + x) * 2 * I + rest] = s;
+        const double rs = cp.R_star / cp.a;
+        const double D_toa = (1.0 - a.dir_beam) * cp.f_factor * (rs * rs) * HX_PI * Bx[a.H + 1];
+        const double B_surf = Bx[a.H + 2];
+
+        for (int sweep = 0; sweep < a.nsweep; sweep++) {
+            // ---------------- down: TOA -> BOA ----------------
+            {
+                double Ubelow = __shfl_up(Uo[ROWS - 1], 1, k);  // U at the bottom node of this chunk
+                if (m.j == 0) Ubelow = U0;
+                double A = 1.0, Bc = 0.0;
+#pragma unroll
+                for (int r = ROWS - 1; r >= 0; r--) {
+                    const double Uh = r > 0 ? Uo[r - 1] : Ubelow;
+                    const double t = fma(be[r], Uh, sd[r]);
+                    Bc = fma(al[r], Bc, t);
+                    A *= al[r];
+                }
+                // inclusive suffix composition over the k lanes of this spectral point
+                for (int d = 1; d < k; d <<= 1) {
+                    const double A2 = __shfl_down(A, d, k), B2 = __shfl_down(Bc, d, k);
+                    if (m.j + d < k) {
+                        Bc = fma(A, B2, Bc);
+                        A *= A2;
+                    }
+                }
+                double Din = __shfl_down(fma(A, D_toa, Bc), 1, k);
+                if (m.j == k - 1) Din = D_toa;
+                double D = Din;
+#pragma unroll
+                for (int r = ROWS - 1; r >= 0; r--) {
+                    const double Uh = r > 0 ? Uo[r - 1] : Ubelow;
+                    D = tiny_abs(fma(al[r], D, fma(be[r], Uh, sd[r])));
+                    Do[r] = D;
+                }
+            }
+            // ---------------- BOA boundary ----------------
+            if (m.j == 0) U0 = albedo * (Fdir0 + Do[0]) + (1.0 - albedo) * HX_PI * boaK * B_surf;
+            const double Ubc = __shfl(U0, 0, k);
+            // ---------------- up: BOA -> TOA ----------------
+            {
+                double Dabove = __shfl_down(Do[0], 1, k);  // D at the top node of this chunk
+                if (m.j == k - 1) Dabove = D_toa;
+                double A = 1.0, Bc = 0.0;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
+                    const double t = fma(be[r], Dh, su[r]);
+                    Bc = fma(al[r], Bc, t);
+                    A *= al[r];
+                }
+                for (int d = 1; d < k; d <<= 1) {
+                    const double A2 = __shfl_up(A, d, k), B2 = __shfl_up(Bc, d, k);
+                    if (m.j >= d) {
+                        Bc = fma(A, B2, Bc);
+                        A *= A2;
+                    }
+                }
+                double Uin = __shfl_up(fma(A, Ubc, Bc), 1, k);
+                if (m.j == 0) Uin = Ubc;
+                double U = Uin;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
+                    U = fma(al[r], U, fma(be[r], Dh, su[r]));
+                    if ((m.j * ROWS + r) & 1) U = tiny_abs(U);  // interface nodes only (reference quirk, kernels.cu:1763)
+                    Uo[r] = U;
+                }
+            }
         }
+
+        // state back to HBM
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) utile[r * 64] = Uo[r];
+        if (a.keep_down) {
+            double* dtile = a.Dtile + col * a.flux_col + toff;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) dtile[r * 64] = Do[r];
+        }
+        if (m.valid && m.j == 0) a.U0[col * nc + m.sp] = U0;
+
+        // Gauss quadrature of the interface fluxes: stage[yl][xl][dir][i], summed over yl in order
+        if (m.valid) {
+            const double w = 0.5 * a.gauss_w[m.y];
+            double* st = stage + ((size_t)m.yl * a.nxb + m.xl) * 2 * I;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int h = m.j * ROWS + r;
+                if (h < a.H) {
+                    if ((h & 1) == 0) st[h >> 1] = w * Do[r];           // D at interface h/2
+                    else st[I + ((h + 1) >> 1)] = w * Uo[r];            // U at interface (h+1)/2
+                }
+            }
+            if (m.j == 0) st[I + 0] = w * U0;
+            if (m.j * ROWS <= a.H - 1 && a.H - 1 < (m.j + 1) * ROWS) st[a.L] = w * D_toa;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
+            const int xl = t / (2 * I), rest = t - xl * 2 * I;
+            double s = acc[t];
+            for (int yl = 0; yl < a.ypb; yl++) s += stage[((size_t)yl * a.nxb + xl) * 2 * I + rest];
+            acc[t] = s;
+        }
+        __syncthreads();
+    }
+    // band fluxes of this workgroup's bins, internal layout [x][i]
+    for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
+        const int xl = t / (2 * I), rest = t - xl * 2 * I, x = bx * a.nxb + xl;
+        if (x >= a.X) continue;
+        const int dir = rest / I, i = rest - dir * I;
+        (dir == 0 ? a.F_down_band_n : a.F_up_band_n)[((size_t)col * a.X + x) * I + i] = acc[t];
     }
 }
 
-// ---- per iteration: band fluxes (sum of Gauss-point partials) and chunked wavelength totals ---
+// ---- per iteration: wavelength totals, level 1 ---------------------------------------------------
 // grid (nchunk, C), 256 threads.  Thread t owns the (dir, i) slots t, t+256, ... (< 2I) and walks the
-// bins of its chunk: consecutive threads read consecutive addresses of band_part[part][x][dir][i].
+// bins of its chunk; consecutive threads read consecutive addresses of the [x][i] band arrays.
 __global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
     const int col = blockIdx.y, chunk = blockIdx.x;
     if (a.done[col]) return;
     const int I = a.I;
     const int per = (a.X + a.nchunk - 1) / a.nchunk;
     const int x0 = chunk * per, x1 = min(a.X, x0 + per);
-    const double* fdir = a.F_dir_band_n + (size_t)col * a.X * I;
+    const double* __restrict__ fdir = a.F_dir_band_n + (size_t)col * a.X * I;
+    const double* __restrict__ dl = a.deltawave;
     for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
         const int dir = t / I, i = t - dir * I;
-        double* band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
+        const double* __restrict__ band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
         double acc = 0.0;
-        for (int x = x0; x < x1; x++) {
-            double v = 0.0;
-            for (int p = 0; p < a.nparts; p++)
-                v += a.band_part[(((size_t)col * a.nparts + p) * a.X + x) * 2 * I + t];
-            band[(size_t)x * I + i] = v;
-            acc += (dir == 0 ? fdir[(size_t)x * I + i] + v : v) * a.deltawave[x];
-        }
+        if (dir == 0)
+            for (int x = x0; x < x1; x++) acc += (fdir[(size_t)x * I + i] + band[(size_t)x * I + i]) * dl[x];
+        else
+            for (int x = x0; x < x1; x++) acc += band[(size_t)x * I + i] * dl[x];
         a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
     }
 }

@@ -179,6 +179,7 @@ class RTBatch(object):
             "F_up_wg": (wg, np.float64), "F_down_wg": (wg, np.float64), "Fc_up_wg": (wg, np.float64),
             "Fc_down_wg": (wg, np.float64), "F_dir_wg": (wg, np.float64), "Fc_dir_wg": (wg, np.float64),
             "iters_done": (1, np.int32), "done": (1, np.int32),
+            "planck_grid": ((self.dims.plancktable_dim + 1) * X, np.float64),
         }
         return table[name]
 

@@ -25,7 +25,7 @@ def run_oracle(port, c0, n_iter, planck_grid=None):
     return out
 
 
-def run_fused(ctx, c0, n_iter, ncol=1, keys=FUSED_KEYS, col=0, T_per_col=None):
+def run_fused(ctx, c0, n_iter, ncol=1, keys=FUSED_KEYS, col=0, T_per_col=None, with_planck_grid=False):
     from helios_amd.rt import batch_from_case
     rt = batch_from_case(ctx, c0, ncol=ncol)
     try:
@@ -36,8 +36,12 @@ def run_fused(ctx, c0, n_iter, ncol=1, keys=FUSED_KEYS, col=0, T_per_col=None):
         rt.build_planck_table(1 if c0.T_star > 10 else 0)
         rt.run(0, n_iter)
         if isinstance(col, int):
-            return {k: rt.get(k, col) for k in keys}
-        return [{k: rt.get(k, cc) for k in keys} for cc in col]
+            out = {k: rt.get(k, col) for k in keys}
+        else:
+            out = [{k: rt.get(k, cc) for k in keys} for cc in col]
+        if with_planck_grid:
+            return out, rt.get("planck_grid")
+        return out
     finally:
         rt.close()
 
