@@ -1,0 +1,361 @@
+"""Input side of the driver surface: parameter file + command line, opacity tables, star, albedo, kappa.
+
+Counterpart of the reference's `Read` (source/read.py).  Option names, defaults and derived settings
+follow param.dat / read.py:210-988; every option can be overridden on the command line
+with the reference's single-dash flags (`-number_of_layers 50`).  File formats:
+
+  * opacity tables / stellar spectra: the reference reads HDF5 through h5py (read.py:1041-1103,
+    :1195-1236).  h5py is optional here; the same dataset names are also accepted from a `.npz` archive
+    (numpy), which is what the synthetic-table generator writes.
+  * `opacity mixing = synthetic` (extension): build the seeded synthetic tables of SURVEY.md 8(d)
+    in memory -- used by bench.py and the tests, since the real tables cannot be downloaded here.
+"""
+import argparse
+import os
+
+import numpy as np
+
+from . import host_functions as hsfunc
+from . import phys_const as pc
+from . import synthetic as syn
+
+# (param.dat key, attribute, command-line flag, default) for the options that reach the hot path
+_OPTIONS = [
+    ("name", "name", "name", "0"),
+    ("output directory", "output_path", "output_directory", "./output/"),
+    ("planet type", "planet_type", "planet_type", "gas"),
+    ("TOA pressure [10^-6 bar]", "p_toa", "toa_pressure", "1e-1"),
+    ("BOA pressure [10^-6 bar]", "p_boa", "boa_pressure", "1e9"),
+    ("run type", "run_type", "run_type", "iterative"),
+    ("post-proc. --> path to temperature file", "temp_path", "path_to_temperature_file", "./output/0/0_tp.dat"),
+    ("scattering", "scat", "scattering", "yes"),
+    ("direct irradiation beam", "dir_beam", "direct_irradiation_beam", "no"),
+    ("no  --> f factor", "f_factor", "f_factor", "0.5"),
+    ("yes --> stellar zenith angle [deg]", "zenith_angle", "stellar_zenith_angle", "60"),
+    ("internal temperature [K]", "T_intern", "internal_temperature", "30"),
+    ("surface albedo", "input_surf_albedo", "surface_albedo", "0.0"),
+    ("opacity mixing", "opacity_mixing", "opacity_mixing", "premixed"),
+    ("premixed   --> path to opacity file", "ktable_path", "path_to_opacity_file", "./input/r50_kdistr_solar_eq.h5"),
+    ("convective adjustment", "convection", "convective_adjustment", "yes"),
+    ("kappa value", "input_kappa_value", "kappa_value", "0.285714"),
+    ("stellar spectral model", "stellar_model", "stellar_spectral_model", "blackbody"),
+    ("planet", "planet", "planet", "manual"),
+    ("manual --> surface gravity [cm s^-2 or log10 (cm s^-2)]", "g", "surface_gravity", "1000"),
+    ("manual --> orbital distance [AU]", "a", "orbital_distance", "0.05"),
+    ("manual --> radius planet [R_Jup]", "R_planet", "radius_planet", "1"),
+    ("manual --> radius star [R_Sun]", "R_star", "radius_star", "1"),
+    ("manual --> temperature star [K]", "T_star", "temperature_star", "5000"),
+    ("number of cloud decks", "nr_cloud_decks", "number_of_cloud_decks", "0"),
+    ("debugging feedback", "debug", "debugging_feedback", "no"),
+    ("precision", "prec", "precision", "double"),
+    ("number of layers", "nlayer", "number_of_layers", "automatic"),
+    ("isothermal layers", "iso_input", "isothermal_layers", "automatic"),
+    ("adaptive interval", "adapt_interval", "adaptive_interval", "20"),
+    ("TP profile smoothing", "smooth", "tp_profile_smoothing", "no"),
+    ("improved two stream correction", "scat_corr", "improved_two_stream_correction", "no"),
+    ("yes --> I2S transition point", "i2s_transition", "i2s_transition_point", "0.1"),
+    ("asymmetry factor g_0", "g_0", "asymmetry_factor_g_0", "0"),
+    ("diffusivity factor", "diffusivity", "diffusivity_factor", "2"),
+    ("second Eddington coefficient", "epsi2", "second_eddington_coefficient", "0.5"),
+    ("geometric zenith angle correction", "zenith_correction", "geometric_zenith_angle_correction", "automatic"),
+    ("flux calculation method", "flux_calc_method", "flux_calculation_method", "iteration"),
+    ("on-the-fly --> k coefficients mixing method", "kcoeff_mixing", "k_coefficients_mixing_method", "RO"),
+    ("energy budget correction", "energy_corr", "energy_budget_correction", "automatic"),
+    ("convective damping parameter", "input_dampara", "convective_damping_parameter", "automatic"),
+    ("plancktable dimension and stepsize", "plancktable", None, "8000 2"),
+    ("maximum number of iterations", "max_nr_iterations", "maximum_number_of_iterations", "100000"),
+    ("radiative equilibrium criterion", "rad_convergence_limit", "radiative_equilibrium_criterion", "1e-8"),
+    ("relax radiative criterion at", "crit_relaxation_numbers", None, "1e4 2e4"),
+    ("number of prerun timesteps", "foreplay", "number_of_prerun_timesteps", "0"),
+    ("physical timestep [s]", "physical_tstep", "physical_timestep", "no"),
+    ("number --> runtime limit [s]", "runtime_limit", "runtime_limit", "86400"),
+    ("include additional heating", "add_heating", "include_additional_heating", "no"),
+    # extensions for synthetic inputs (not in the reference)
+    ("synthetic --> bins layers-are-set-above ntemp npress seed", "synthetic_spec", "synthetic", "300 30 20 20241"),
+]
+
+
+def _yes_no(v):
+    if v in ("yes", "no"):
+        return np.int32(1 if v == "yes" else 0)
+    raise IOError("ERROR: expected 'yes' or 'no', got %r" % (v,))
+
+
+class Species(object):
+    """one entry of the on-the-fly species list (reference source/read.py `Species`, :1324-1443)"""
+
+    def __init__(self, name="", absorbing="no", scattering="no", weight=None, source_for_vmr="constant",
+                 mixing_ratio=None):
+        self.name = name
+        self.absorbing = absorbing            # "yes" / "no"
+        self.scattering = scattering          # "yes" / "no"
+        self.weight = weight                  # molar weight [g/mol]
+        self.source_for_vmr = source_for_vmr  # "constant", "file" or "FastChem"
+        self.mixing_ratio = mixing_ratio
+        self.fc_name = None
+        self.vmr_pretab = None                # [ntemp * npress] for FastChem-tabulated species
+        self.vmr_layer = []
+        self.vmr_interface = []
+        self.opacity_pretab = None            # flat k-table [y + ny*x + ny*nbin*p + ny*nbin*npress*t]
+        self.scat_cross_sect_pretab = None    # [nbin]
+        self.scat_cross_sect_layer = []       # tiled to [nbin * nlayer] (read.py:1642-1645)
+        self.scat_cross_sect_interface = []
+
+
+class _Cloud(object):
+    """minimal stand-in for source/clouds.py's Cloud: the hot path only needs the six cloud arrays"""
+    nr_cloud_decks = 0
+
+    def cloud_pre_processing(self, quant):
+        n_l, n_i = int(quant.nlayer) * int(quant.nbin), int(quant.ninterface) * int(quant.nbin)
+        for stem in ("abs_cross_all_clouds", "scat_cross_all_clouds", "g_0_all_clouds"):
+            if len(np.atleast_1d(getattr(quant, stem + "_lay"))) != n_l:
+                setattr(quant, stem + "_lay", np.zeros(n_l))
+                setattr(quant, stem + "_int", np.zeros(n_i))
+
+
+class Read(object):
+    """reads the parameter file, the command line and the input tables"""
+
+    def __init__(self):
+        self.param_file = "param.dat"
+        self.output_path = "./output/"
+        self.ktable_path = None
+        self.temp_path = None
+        self.stellar_model = "blackbody"
+        self.input_surf_albedo = "0.0"
+        self.synthetic_spec = None
+        self.cloud = _Cloud()
+
+    # ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _parse_param_file(path):
+        """'key = value   [allowed values] (CL: Y)' lines; everything right of the value is comment"""
+        out = {}
+        if not os.path.exists(path):
+            return out
+        with open(path) as f:
+            for line in f:
+                if "=" not in line or line.lstrip().startswith(("#", "===")):
+                    continue
+                key, rest = line.split("=", 1)
+                rest = rest.split("[", 1)[0].split("(CL:", 1)[0].strip()
+                if rest:
+                    out[key.strip()] = rest
+        return out
+
+    def read_param_file_and_command_line(self, quant, cloud=None, argv=None):
+        parser = argparse.ArgumentParser(description="command-line parameters (same flags as HELIOS)")
+        parser.add_argument("-parameter_file", required=False)
+        for _key, _attr, flag, _default in _OPTIONS:
+            if flag:
+                parser.add_argument("-" + flag, required=False)
+        args, _unknown = parser.parse_known_args(argv)
+        if args.parameter_file:
+            self.param_file = args.parameter_file
+        file_vals = self._parse_param_file(self.param_file)
+        val = {}
+        for key, attr, flag, default in _OPTIONS:
+            v = file_vals.get(key, default)
+            if flag and getattr(args, flag) is not None:
+                v = getattr(args, flag)
+            val[attr] = v
+
+        f64, i32 = np.float64, np.int32
+        quant.name = val["name"]
+        self.output_path = val["output_path"]
+        quant.planet_type = val["planet_type"]
+        quant.p_toa, quant.p_boa = f64(val["p_toa"]), f64(val["p_boa"])
+        quant.run_type = val["run_type"]
+        self.temp_path = val["temp_path"]
+        quant.scat = _yes_no(val["scat"])
+        quant.dir_beam = _yes_no(val["dir_beam"])
+        quant.f_factor = f64(val["f_factor"])
+        zenith_angle = f64(val["zenith_angle"])
+        quant.T_intern = f64(val["T_intern"])
+        self.input_surf_albedo = val["input_surf_albedo"]
+        quant.opacity_mixing = val["opacity_mixing"]
+        self.ktable_path = val["ktable_path"]
+        quant.convection = _yes_no(val["convection"])
+        quant.input_kappa_value = val["input_kappa_value"]
+        self.stellar_model = val["stellar_model"]
+        quant.planet = val["planet"]
+        quant.g, quant.a = f64(val["g"]), f64(val["a"])
+        quant.R_planet, quant.R_star, quant.T_star = f64(val["R_planet"]), f64(val["R_star"]), f64(val["T_star"])
+        self.cloud.nr_cloud_decks = int(val["nr_cloud_decks"])
+        quant.debug = _yes_no(val["debug"])
+        quant.prec = val["prec"]
+        quant.nlayer = val["nlayer"]
+        quant.adapt_interval = i32(val["adapt_interval"])
+        quant.smooth = _yes_no(val["smooth"])
+        quant.scat_corr = _yes_no(val["scat_corr"])
+        quant.i2s_transition = f64(val["i2s_transition"])
+        quant.g_0 = f64(val["g_0"])
+        quant.diffusivity = f64(val["diffusivity"])
+        quant.epsi2 = f64(val["epsi2"])
+        quant.flux_calc_method = val["flux_calc_method"]
+        quant.kcoeff_mixing = val["kcoeff_mixing"]
+        quant.input_dampara = val["input_dampara"]
+        dim, step = str(val["plancktable"]).split()[:2]
+        quant.plancktable_dim, quant.plancktable_step = i32(dim), i32(step)
+        quant.max_nr_iterations = i32(float(val["max_nr_iterations"]))
+        quant.rad_convergence_limit = f64(val["rad_convergence_limit"])
+        quant.crit_relaxation_numbers = [int(float(v)) for v in str(val["crit_relaxation_numbers"]).split()]
+        quant.foreplay = i32(val["foreplay"])
+        quant.physical_tstep = f64(0 if val["physical_tstep"] == "no" else val["physical_tstep"])
+        quant.runtime_limit = f64(val["runtime_limit"])
+        quant.add_heating = _yes_no(val["add_heating"])
+        quant.force_start_tp_from_file = i32(0)
+        quant.coupling = i32(0)
+        quant.realtime_plot = i32(0)
+        self.synthetic_spec = val["synthetic_spec"]
+
+        # ---- derived settings (read.py:884-985) ----
+        if quant.prec != "double":
+            raise IOError("ERROR: this build computes in double precision only (SURVEY.md Q16)")
+        quant.fl_prec, quant.nr_bytes = np.float64, 8
+        if quant.run_type == "iterative":
+            quant.singlewalk, quant.iso, quant.energy_correction = i32(0), i32(0), i32(1)
+        elif quant.run_type == "post-processing":
+            quant.singlewalk, quant.iso, quant.energy_correction = i32(1), i32(1), i32(0)
+        else:
+            raise IOError("ERROR: unknown run type %r" % quant.run_type)
+        quant.dir_angle = f64((180 - zenith_angle) * np.pi / 180.0)
+        quant.mu_star = f64(np.cos(quant.dir_angle))
+        if self.cloud.nr_cloud_decks < 0:
+            raise IOError("\nParameter Error: Number of cloud decks must be >=0. Please correct input value.")
+        quant.clouds = i32(1 if self.cloud.nr_cloud_decks > 0 else 0)
+        if quant.nlayer == "automatic":
+            quant.nlayer = i32(np.ceil(10.5 * np.log10(quant.p_boa / quant.p_toa)))
+        else:
+            quant.nlayer = i32(quant.nlayer)
+        if quant.g < 10:
+            quant.g = f64(10 ** quant.g)
+        if val["iso_input"] != "automatic":
+            quant.iso = _yes_no(val["iso_input"])
+        quant.epsi = f64(1.0 / quant.diffusivity)
+        if val["zenith_correction"] != "automatic":
+            quant.geom_zenith_corr = _yes_no(val["zenith_correction"])
+        else:
+            quant.geom_zenith_corr = i32(1 if zenith_angle > 70 else 0)
+        if quant.flux_calc_method == "iterative":
+            quant.flux_calc_method = "iteration"
+        if val["energy_corr"] != "automatic":
+            quant.energy_correction = _yes_no(val["energy_corr"])
+        if quant.physical_tstep > 0 and quant.convection == 0:
+            raise IOError("ERROR: Physical timesteppings needs convective adjustment switched on.")
+        if quant.planet_type == "no_atmosphere":
+            quant.no_atmo_mode = i32(1)
+            quant.p_toa, quant.p_boa = 1e-3, 2e-3
+            quant.scat, quant.convection, quant.nlayer = i32(0), i32(0), i32(2)
+        quant.ninterface = i32(quant.nlayer + 1)
+        print("\n### Welcome! This run has the name: " + str(quant.name) + ". ###")
+
+    # ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _open_table(path):
+        """dataset-name -> array mapping of an HDF5 (needs h5py) or .npz opacity/star file"""
+        if path.endswith(".npz"):
+            return dict(np.load(path))
+        try:
+            import h5py
+        except ImportError:
+            raise IOError("h5py is not installed: convert %s to .npz (same dataset names) or install h5py" % path)
+        with h5py.File(path, "r") as f:
+            return {k: f[k][()] for k in f.keys()}
+
+    def read_opac_file(self, quant, path, type="premixed"):
+        """datasets as written by the reference's k-table tool (read.py:1041-1103)"""
+        d = self._open_table(path)
+        kp = d["kpoints"] if "kpoints" in d else d["opacities"]
+        if type == "premixed":
+            quant.opac_k = np.asarray(kp, np.float64).reshape(-1)
+        quant.gauss_y = np.asarray(d["ypoints"], np.float64) if "ypoints" in d else np.array([0.5])
+        quant.ny = np.int32(len(quant.gauss_y))
+        quant.ktemp = np.asarray(d["temperatures"], np.float64)
+        quant.ntemp = np.int32(len(quant.ktemp))
+        quant.kpress = np.asarray(d["pressures"], np.float64)
+        quant.npress = np.int32(len(quant.kpress))
+        quant.opac_wave = np.asarray(d["center wavelengths"], np.float64)
+        quant.nbin = np.int32(len(quant.opac_wave))
+        quant.opac_interwave = np.asarray(d["interface wavelengths"], np.float64)
+        quant.opac_deltawave = np.asarray(d["wavelength width of bins"], np.float64)
+        if type == "premixed":
+            quant.opac_meanmass = np.asarray(d["meanmolmass"], np.float64).reshape(-1)
+            quant.opac_scat_cross = np.asarray(d["weighted Rayleigh cross-sections"], np.float64).reshape(-1)
+        return kp
+
+    def load_premixed_opacity_table(self, quant):
+        if quant.opacity_mixing == "synthetic" or str(self.ktable_path) == "synthetic":
+            self.load_synthetic_premixed_table(quant)
+            quant.opacity_mixing = "premixed"
+        else:
+            self.read_opac_file(quant, self.ktable_path, type="premixed")
+
+    def load_synthetic_premixed_table(self, quant, nbin=None, ny=20, ntemp=None, npress=None, seed=None):
+        spec = str(self.synthetic_spec).split()
+        nbin = int(nbin or spec[0])
+        ntemp = int(ntemp or spec[1])
+        npress = int(npress or spec[2])
+        seed = int(seed or spec[3])
+        rng = np.random.default_rng(seed)
+        quant.nbin, quant.ny = np.int32(nbin), np.int32(ny)
+        quant.opac_interwave, quant.opac_wave, quant.opac_deltawave = syn.wavelength_grid(nbin)
+        quant.gauss_y, _w = syn.gauss_points(ny)
+        quant.ktemp, quant.kpress = syn.tp_grid(ntemp, npress)
+        quant.ntemp, quant.npress = np.int32(ntemp), np.int32(npress)
+        quant.opac_k = syn.ktable(rng, nbin, ny, quant.ktemp, quant.kpress, quant.gauss_y)
+        quant.opac_scat_cross = syn.rayleigh_table(quant.opac_wave, ntemp, npress)
+        quant.opac_meanmass = syn.meanmass_table(ntemp, npress)
+
+    def read_kappa_table_or_use_constant_kappa(self, quant):
+        """constant kappa (default) -> kappa_lay/int and c_p = R/kappa (read.py:1105-1193)"""
+        L, I = int(quant.nlayer), int(quant.ninterface)
+        quant.entr_temp, quant.entr_press, quant.entr_kappa, quant.entr_c_p = [0.0], [0.0], [0.0], [0.0]
+        quant.entr_entropy, quant.entr_phase_number = [0.0], [0.0]
+        quant.entr_ntemp = quant.entr_npress = np.int32(1)
+        if quant.convection == 1:
+            try:
+                kap = float(quant.input_kappa_value)
+            except ValueError:
+                raise IOError("kappa tables (kappa value = file) are outside this build's scope; "
+                              "give a constant kappa value (SURVEY.md 2.2)")
+            quant.input_kappa_value = np.float64(kap)
+            quant.kappa_lay = np.ones(L) * kap
+            quant.c_p_lay = np.ones(L) * (pc.R_UNIV / kap)
+            quant.kappa_int = np.ones(I) * kap
+        else:
+            quant.c_p_lay, quant.kappa_lay, quant.kappa_int = np.zeros(L), np.zeros(L), np.zeros(I)
+
+    def read_star(self, quant):
+        if self.stellar_model == "blackbody":
+            quant.starflux = np.zeros(int(quant.nbin), quant.fl_prec)
+            quant.real_star = np.int32(0)
+        elif self.stellar_model == "file":
+            d = self._open_table(self.stellar_path)
+            quant.starflux = np.asarray(d[self.stellar_data_set], np.float64)
+            quant.real_star = np.int32(1)
+            if len(quant.starflux) != quant.nbin:
+                raise OverflowError("Stellar spectrum and opacity files have different lengths.")
+        else:
+            raise IOError("Unknown Stellar model. Please check your input.")
+
+    def read_or_fill_surf_albedo_array(self, quant):
+        """scalar albedo clamped to [1e-8, 0.999] (read.py:1258-1264)"""
+        a = max(1e-8, min(0.999, float(self.input_surf_albedo)))
+        quant.surf_albedo = np.ones(int(quant.nbin)) * a
+
+    def read_temperature_file(self, quant):
+        """HELIOS `_tp.dat` restart format: two header lines, then 'BOA' + layer rows (read.py:1274-1322)"""
+        T = []
+        with open(self.temp_path) as f:
+            next(f)
+            next(f)
+            for line in f:
+                col = line.split()
+                if len(col) > 1:
+                    T.append(float(col[1]))
+        quant.T_restart = T
+
+    def read_planet_database(self, quant):
+        raise IOError("planet database look-ups are outside this build's scope; use planet = manual")

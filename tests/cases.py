@@ -257,3 +257,68 @@ def radiation_iterations(impl, c, s, n_iter, start=0, refresh=refresh_premixed):
         flux_sweeps(impl, c, s)
         integrate_and_step(impl, c, s, it)
     return s
+
+
+# ---- on-the-fly opacity mixing (source/computation.py:865-869, :1454-1501) ---------------------------
+def add_species(c, nspecies=4, seed=3, with_h2o=True):
+    """attach a synthetic species set to a case: absorbers with constant VMRs + H2/He-like scatterers"""
+    rng = np.random.default_rng(seed)
+    sp = []
+    for s in range(nspecies):
+        sp.append(dict(name="SPEC%02d" % s, absorbing=True, scattering=False, is_h2o=False, is_cia=False,
+                       weight=float(rng.uniform(2.0, 64.0)), vmr=float(10.0 ** rng.uniform(-5.0, -2.0)),
+                       pretab=syn.ktable(rng, c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y), scat=None))
+    sp[0]["vmr"] = 0.8                       # the first absorber dominates mu (e.g. H2O-rich or CO2)
+    if nspecies > 2:
+        sp[2]["is_cia"] = True               # CIA pairs are always mixed correlated-k and skip mu
+        sp[2]["name"] = "CIA_H2H2"
+    if with_h2o:
+        sp.append(dict(name="H2O", absorbing=False, scattering=True, is_h2o=True, is_cia=False, weight=18.0153,
+                       vmr=1e-3, pretab=None, scat=None))
+    sp.append(dict(name="H2", absorbing=False, scattering=True, is_h2o=False, is_cia=False, weight=2.016,
+                   vmr=0.15, pretab=None, scat=1e-24 * (1e-4 / c.opac_wave) ** 4))
+    c.species = sp
+    return c
+
+
+def species_vmr_arrays(c):
+    S = len(c.species)
+    vl = np.array([np.full(c.nlayer, sp["vmr"]) for sp in c.species]).reshape(S, c.nlayer)
+    vi = np.array([np.full(c.ninterface, sp["vmr"]) for sp in c.species]).reshape(S, c.ninterface)
+    return vl, vi
+
+
+def refresh_onthefly(impl, c, s, ro=1):
+    X, Y, L, I = c.nbin, c.ny, c.nlayer, c.ninterface
+    vl, vi = species_vmr_arrays(c)
+    inmu = np.array([0.0 if sp["is_cia"] else 1.0 for sp in c.species])
+    w = np.array([sp["weight"] for sp in c.species])
+    s.meanmolmass_lay[:] = (vl * (w * inmu)[:, None]).sum(0) / (vl * inmu[:, None]).sum(0) * pc.AMU
+    s.meanmolmass_int[:] = (vi * (w * inmu)[:, None]).sum(0) / (vi * inmu[:, None]).sum(0) * pc.AMU
+    for a in (s.opac_wg_lay, s.opac_wg_int, s.scat_cross_lay, s.scat_cross_int):
+        a[:] = 0
+    spec_l, spec_i = np.zeros(Y * X * I), np.zeros(Y * X * I)
+    sc_l, sc_i = np.zeros(X * L), np.zeros(X * I)
+    for k, sp in enumerate(c.species):
+        if sp["absorbing"]:
+            impl.opac_species_interpol(c.T_lay, c.ktemp, c.p_lay, c.kpress, sp["pretab"], spec_l, c.npress,
+                                       c.ntemp, Y, X, L)
+            impl.opac_species_interpol(c.T_int, c.ktemp, c.p_int, c.kpress, sp["pretab"], spec_i, c.npress,
+                                       c.ntemp, Y, X, I)
+            ro_m = 0 if (sp["is_cia"] or not ro) else 1
+            impl.add_to_mixed_opac(np.ascontiguousarray(vl[k]), spec_l, s.opac_wg_lay, s.meanmolmass_lay,
+                                   c.gauss_weight, c.gauss_y, sp["weight"] * pc.AMU, k, ro_m, Y, X, L)
+            impl.add_to_mixed_opac(np.ascontiguousarray(vi[k]), spec_i, s.opac_wg_int, s.meanmolmass_int,
+                                   c.gauss_weight, c.gauss_y, sp["weight"] * pc.AMU, k, ro_m, Y, X, I)
+        if sp["scattering"]:
+            if sp["is_h2o"]:
+                impl.calc_h2o_scat(c.T_lay, c.p_lay, c.opac_wave, sc_l, np.ascontiguousarray(vl[k]),
+                                   sp["weight"] * pc.AMU, X, L)
+                impl.calc_h2o_scat(c.T_int, c.p_int, c.opac_wave, sc_i, np.ascontiguousarray(vi[k]),
+                                   sp["weight"] * pc.AMU, X, I)
+            else:
+                sc_l[:] = np.tile(sp["scat"], L)
+                sc_i[:] = np.tile(sp["scat"], I)
+            impl.add_to_mixed_scat(np.ascontiguousarray(vl[k]), sc_l, s.scat_cross_lay, X, L)
+            impl.add_to_mixed_scat(np.ascontiguousarray(vi[k]), sc_i, s.scat_cross_int, X, I)
+    refresh_transmission(impl, c, s)

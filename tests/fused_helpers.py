@@ -9,14 +9,14 @@ FUSED_KEYS = ["T_lay", "T_int", "F_up_band", "F_down_band", "F_dir_band", "F_up_
               "z_lay", "F_up_wg", "Fc_up_wg", "F_down_wg", "Fc_down_wg", "abort", "delta_t_prefactor"]
 
 
-def run_oracle(port, c0, n_iter, planck_grid=None):
+def run_oracle(port, c0, n_iter, planck_grid=None, refresh=None):
     c = c0.copy()
     s = cases.alloc_state(c)
     if planck_grid is None:
         cases.setup_planck(port, c, s)
     else:
         s.planck_grid[:] = planck_grid
-    cases.radiation_iterations(port, c, s, n_iter)
+    cases.radiation_iterations(port, c, s, n_iter, refresh=refresh or cases.refresh_premixed)
     out = dict(s)
     out["T_lay"], out["T_int"], out["z_lay"] = c.T_lay, c.T_int, c.z_lay
     out["delta_t_prefactor"] = s.deltat_prefactor
@@ -27,7 +27,14 @@ def run_oracle(port, c0, n_iter, planck_grid=None):
 
 def run_fused(ctx, c0, n_iter, ncol=1, keys=FUSED_KEYS, col=0, T_per_col=None, with_planck_grid=False):
     from helios_amd.rt import batch_from_case
-    rt = batch_from_case(ctx, c0, ncol=ncol)
+    species = c0.get("species")
+    rt = batch_from_case(ctx, c0, ncol=ncol, nspecies=len(species) if species else 0)
+    if species:
+        for k, sp in enumerate(species):
+            rt.set_species(k, sp["pretab"], sp["scat"], sp["weight"], is_h2o=2 if sp["is_h2o"] else 0,
+                           is_cia=1 if sp["is_cia"] else 0, in_mu=0 if sp["is_cia"] else 1)
+        vl, vi = cases.species_vmr_arrays(c0)
+        rt.set_column_vmr(-1, vl, vi)
     try:
         rt.keep_down_fluxes(True)
         if T_per_col is not None:

@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI boundary: the shared library loads, exports every symbol the header
+declares, its struct layouts match the ctypes mirrors, and the product never touches the oracle."""
+import ctypes
+import os
+import re
+
+from helios_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.prototypes()
+    assert len(protos) >= 65
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in protos if not hasattr(raw, n)]
+    assert not missing, missing
+
+
+def test_header_covers_every_hot_path_kernel():
+    """one hx_<kernel> per reference kernel on the hot path"""
+    protos = _lib.prototypes()
+    for k in ("plancktable", "corr_inc_energy", "temp_inter", "planck_interpol_layer",
+              "planck_interpol_interface", "opac_interpol", "meanmolmass_interpol", "opac_species_interpol",
+              "add_to_mixed_opac", "calc_h2o_scat", "add_to_mixed_scat", "calc_total_g_0_of_gas_and_clouds",
+              "calc_trans_iso", "calc_trans_noniso", "calc_delta_z", "fdir_iso", "fdir_noniso", "fband_iso",
+              "fband_noniso", "integrate_flux", "rad_temp_iter", "conv_temp_iter",
+              "integrate_optdepth_transmission_iso", "integrate_optdepth_transmission_noniso",
+              "calc_contr_func_iso", "calc_contr_func_noniso", "calc_mean_opacities", "integrate_beamflux"):
+        assert "hx_" + k in protos, k
+
+
+def test_struct_layouts_match():
+    from helios_amd import rt
+    rt._check_struct_sizes(_lib.lib())
+
+
+def test_no_gpu_means_loud_failure():
+    """there is no CPU fallback: creating a context without a GPU raises"""
+    import pytest
+    from helios_amd.device import Context
+    raw = _lib.lib()
+    n = ctypes.c_void_p()
+    rc = raw.hx_create(0, ctypes.byref(n))
+    if rc == 0:          # running on a GPU box
+        raw.hx_destroy(n)
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.HeliosHipError):
+        Context(0)
+
+
+def test_product_does_not_import_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle/|libhelios_oracle|libhelios_ref", re.M)
+    for d, _dirs, files in os.walk(os.path.join(ROOT, "helios_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(d, f)).read()
+                assert not pat.search(text), os.path.join(d, f)
+    text = open(os.path.join(ROOT, "helios.py")).read()
+    assert not pat.search(text)

@@ -1,0 +1,51 @@
+"""Multi-process path on CPU: world_size-2 gloo run of the column sharding + spectra gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from helios_amd.parallel import shard_columns
+
+
+def test_shard_columns_covers_everything():
+    for ncol, world in ((512, 8), (10, 4), (3, 8), (7, 2)):
+        seen = []
+        for r in range(world):
+            a, b = shard_columns(ncol, r, world)
+            seen += list(range(a, b))
+        assert seen == list(range(ncol))
+    assert shard_columns(512, 3, 8) == (192, 256)
+
+
+def _worker(rank, world, port, ncol, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from helios_amd.parallel import gather_spectra, shard_columns
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a, b = shard_columns(ncol, rank, world)
+    local = np.array([[c * 100.0 + k for k in range(5)] for c in range(a, b)]).reshape(b - a, 5)
+    full = gather_spectra(local, dist)
+    q.put((rank, full))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncol", [6, 7])
+def test_gather_spectra_gloo_world2(ncol):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ncol, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    want = np.array([[c * 100.0 + k for k in range(5)] for c in range(ncol)])
+    for _rank, full in res:
+        np.testing.assert_array_equal(full, want)
