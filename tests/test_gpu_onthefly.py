@@ -45,7 +45,7 @@ def _run_driver(argv, use_fused):
 
 def test_run_helios_fused_equals_stagewise(tmp_path):
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "40 6 5 7",
-            "-number_of_layers", "24", "-maximum_number_of_iterations", "60", "-name", "drv",
+            "-number_of_layers", "24", "-maximum_number_of_iterations", "20000", "-name", "drv",
             "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-3",
             "-convective_adjustment", "no"]
     a = _run_driver(argv, True)
@@ -67,7 +67,7 @@ def test_run_helios_fused_equals_stagewise(tmp_path):
 def test_run_helios_with_convection(tmp_path):
     """hot interior -> super-adiabatic deep layers -> the convection loop engages and ends stable"""
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",
-            "-number_of_layers", "20", "-maximum_number_of_iterations", "3000", "-name", "conv",
+            "-number_of_layers", "20", "-maximum_number_of_iterations", "20000", "-name", "conv",
             "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
             "-internal_temperature", "800", "-kappa_value", "0.285714"]
     q = _run_driver(argv, True)
