@@ -74,11 +74,12 @@ def build_case(w, seed):
 
 def cpu_baseline(w, seed):
     """the CPU oracle (oracle/helios_oracle.c, OpenMP over bins) on a bounded sample of the same
-    workload: the first `nb` bins, 20 iterations from iteration 0 (2 refreshes + 20 flux solves)."""
+    workload: the first `nb` bins, 20-60 iterations from iteration 0 (one opacity refresh per 10), sized
+    for roughly 10-30 s; the thread count is the fastest of a short probe."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     import oracle
-    nb = min(w["nbin"], 2000)
+    nb = min(w["nbin"], 5000)
     ws = dict(w)
     ws["nbin"] = nb
     c = build_case(ws, seed)
@@ -114,16 +115,18 @@ def cpu_baseline(w, seed):
             best = (el, th)
     threads = best[1]
     oracle.port.set_num_threads(threads)
+    # size the timed run for roughly 10-30 s of CPU work: one flux sweep took best[0]/2 s on nb bins
+    per_iter = 2.2 * best[0]                         # 4 sweeps + refresh share + the rest
+    n_it = int(min(60, max(20, 10 * round(15.0 / max(per_iter, 1e-3) / 10))))
     s = cases.alloc_state(cc)
     cc.T_lay = c.T_lay.copy()
     cases.setup_planck(oracle.port, cc, s)
-    n_it = 20
     t0 = time.perf_counter()
     cases.radiation_iterations(oracle.port, cc, s, n_it)
     dt = time.perf_counter() - t0
     return dict(value=n_it / dt * nb * c.nlayer, unit="bin*layer*iterations/s", cores=threads, kind="port",
                 sample="%d of %d bins x %d layers x %d Gauss points, %d iterations from iteration 0 "
-                       "(2 opacity refreshes), oracle/helios_oracle.c with OpenMP over bins (%d of %d visible "
+                       "(one opacity refresh per 10), oracle/helios_oracle.c with OpenMP over bins (%d of %d visible "
                        "cores: fastest of a thread-count probe), %.1f s"
                        % (nb, w["nbin"], c.nlayer, c.ny, n_it, threads, ncpu, dt))
 

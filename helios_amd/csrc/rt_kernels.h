@@ -108,34 +108,78 @@ __device__ __forceinline__ LaneMap lane_map(const KArgs& a, int bx, int part) {
 }
 
 // ---- per refresh: compact coefficient tiles ---------------------------------------------------
+// grid (ceil(ntiles / COEF_TPB), C), COEF_TPB wavefronts per workgroup, one tile each.  The opacities
+// live in the reference's layout [y + ny*x + ny*nbin*level] (level slowest), so the spectral points of
+// one tile are only 64/k doubles apart per level: the workgroup first stages the opacities of ALL its
+// tiles' spectral points (consecutive in memory when a tile row holds one bin) for every level into
+// LDS with >= 128-byte contiguous reads, then every lane builds the coefficients of its half-layers.
+constexpr int COEF_TPB = 4;
+
 template <int ROWS>
-__global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
-    const int col = blockIdx.z;
+__global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
+    extern __shared__ __align__(16) double smem[];
+    const int col = blockIdx.y;
     if (a.done[col]) return;
-    const LaneMap m = lane_map(a, blockIdx.x, blockIdx.y);
-    const hx_rt_column cp = a.colpar[col];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ntiles = a.nblk_x * a.nparts * a.NW;
+    const int TS = COEF_TPB * a.S;                  // spectral points staged per workgroup
+    double* sh_lay = smem;                          // [L][TS]
+    double* sh_int = sh_lay + (size_t)a.L * TS;     // [I][TS]
+    int* c_of_q = (int*)(sh_int + (size_t)a.I * TS);  // [TS] global spectral-point index or -1
+    int* x_of_q = c_of_q + TS;
     const size_t nc = (size_t)a.Y * a.X;
     const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
-    const double* opl = a.opac_wg_lay + col * wgI;
-    const double* opi = a.opac_wg_int + col * wgI;
+    // spectral points of this workgroup's tiles
+    for (int q = threadIdx.x; q < TS; q += blockDim.x) {
+        const int tl = blockIdx.x * COEF_TPB + q / a.S, s_in_wave = q % a.S;
+        int c = -1, xq = 0;
+        if (tl < ntiles) {
+            const int wv = tl % a.NW, part = (tl / a.NW) % a.nparts, bx = tl / (a.NW * a.nparts);
+            const int s_local = wv * a.S + s_in_wave;
+            const int xl = s_local / a.ypb, yl = s_local - xl * a.ypb;
+            const int x = bx * a.nxb + xl, y = part * a.ypb + yl;
+            if (s_local < a.G && x < a.X) { c = y + a.Y * x; xq = x; }
+        }
+        c_of_q[q] = c;
+        x_of_q[q] = xq;
+    }
+    __syncthreads();
+    {
+        const double* opl = a.opac_wg_lay + col * wgI;
+        const double* opi = a.opac_wg_int + col * wgI;
+        for (int idx = threadIdx.x; idx < a.L * TS; idx += blockDim.x) {
+            const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
+            sh_lay[idx] = c >= 0 ? opl[(size_t)c + nc * lev] : 0.0;
+        }
+        for (int idx = threadIdx.x; idx < a.I * TS; idx += blockDim.x) {
+            const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
+            sh_int[idx] = c >= 0 ? opi[(size_t)c + nc * lev] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int tl = blockIdx.x * COEF_TPB + wave;
+    if (tl >= ntiles) return;
+    const int j = lane % a.k, q = wave * a.S + lane / a.k;
+    const int c = c_of_q[q], x = x_of_q[q];
+    const bool valid = c >= 0;
+    const hx_rt_column cp = a.colpar[col];
     const double* scl = a.scat_cross_lay + col * bandI;
     const double* sci = a.scat_cross_int + col * bandI;
     const double* mml = a.mmm_lay + (size_t)col * a.I;
     const double* mmi = a.mmm_int + (size_t)col * a.I;
     const double* dcu = a.dcol_u + (size_t)col * a.L;
     const double* dcl = a.dcol_l + (size_t)col * a.L;
-    double* ctile = a.coef + col * a.coef_col + m.tile * (size_t)a.nplane * ROWS * 64 + m.lane;
+    double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64 + lane;
     const double nmu = -cp.mu_star;
     for (int r = 0; r < ROWS; r++) {
-        const int h = m.j * ROWS + r;
+        const int h = j * ROWS + r;
         double alpha = 1.0, beta = 0.0, up = 0.0, vp = 0.0, dd = 0.0, du = 0.0;
-        if (m.valid && h < a.H) {
+        if (valid && h < a.H) {
             const int i = h >> 1;
             const bool lower = (h & 1) == 0;
             // lower half averages (interface i, centre i); upper half (centre i, interface i+1)
             const int ii = lower ? i : i + 1;
-            const size_t b_l = m.x + (size_t)a.X * i, b_i = m.x + (size_t)a.X * ii;
-            const size_t k_l = m.sp + nc * i, k_i = m.sp + nc * ii;
+            const size_t b_l = x + (size_t)a.X * i, b_i = x + (size_t)a.X * ii;
             double g0 = a.g_0, ray = 0.0, csc = 0.0, cab = 0.0;
             if (a.clouds == 1) {
                 const double* gl = a.g0_tot_lay + col * bandI;
@@ -153,7 +197,8 @@ __global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
                     csc = lower ? (si[b_i] + sl[b_l]) / 2.0 : (sl[b_l] + si[b_i]) / 2.0;
                 }
             }
-            const double kap = lower ? (opi[k_i] + opl[k_l]) / 2.0 : (opl[k_l] + opi[k_i]) / 2.0;
+            const double o_l = sh_lay[(size_t)i * TS + q], o_i = sh_int[(size_t)ii * TS + q];
+            const double kap = lower ? (o_i + o_l) / 2.0 : (o_l + o_i) / 2.0;
             const double mu = lower ? (mmi[ii] + mml[i]) / 2.0 : (mml[i] + mmi[ii]) / 2.0;
             const double dcol = lower ? dcl[i] : dcu[i];
             const double w0 = single_scat_albedo(ray + csc, kap * mu + cab, a.w_0_limit);
@@ -168,9 +213,9 @@ __global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
             if (dtau < a.dtau_limit) {
                 u = v = (s.N + s.M - s.P) / 2.0;
             } else {
-                const double q = a.epsi / (s.E * (1.0 - w0 * g0)) * (s.P - s.M + s.N) / dtau;
-                u = (s.M + s.N) + q;
-                v = -s.P - q;
+                const double qq = a.epsi / (s.E * (1.0 - w0 * g0)) * (s.P - s.M + s.N) / dtau;
+                u = (s.M + s.N) + qq;
+                v = -s.P - qq;
             }
             up = K * u * invM;
             vp = K * v * invM;
@@ -178,16 +223,16 @@ __global__ void __launch_bounds__(320) k_rt_coef(KArgs a) {
                 // beam at node h (bottom) and h+1 (top) of this half-layer
                 const double* Fd = a.F_dir_wg + col * wgI;
                 const double* Fc = a.Fc_dir_wg + col * wgI;
-                const double Fbot = lower ? Fd[m.sp + nc * i] : Fc[m.sp + nc * i];
-                const double Ftop = lower ? Fc[m.sp + nc * i] : Fd[m.sp + nc * (i + 1)];
+                const double Fbot = lower ? Fd[(size_t)c + nc * i] : Fc[(size_t)c + nc * i];
+                const double Ftop = lower ? Fc[(size_t)c + nc * i] : Fd[(size_t)c + nc * (i + 1)];
                 const double dn = Fbot / nmu * (s.Gm * s.M + s.Gp * s.N) - Ftop / nmu * s.Gm * s.P;
                 const double upw = Ftop / nmu * (s.Gm * s.N + s.Gp * s.M) - Fbot / nmu * s.P * s.Gp;
                 dd = dmin(0.0, dn) * invM;
                 du = dmin(0.0, upw) * invM;
             }
             if (h == 0) {
-                a.boaK[col * nc + m.sp] = (1.0 - w0) / (s.E - w0);
-                a.Fdir0[col * nc + m.sp] = a.dir_beam == 1 ? (a.F_dir_wg + col * wgI)[m.sp] : 0.0;
+                a.boaK[col * nc + c] = (1.0 - w0) / (s.E - w0);
+                a.Fdir0[col * nc + c] = a.dir_beam == 1 ? (a.F_dir_wg + col * wgI)[c] : 0.0;
             }
         }
         ctile[(0 * ROWS + r) * 64] = alpha;
