@@ -30,6 +30,10 @@ WORKLOADS = {
                desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
     "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20,
                desc="BASELINE config 1 shape: 300 bins x 50 layers, premixed"),
+    "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
+               desc="BASELINE config 3: on-the-fly mixing, 20 species random overlap, 10 000 bins x 100 layers"),
+    "c3small": dict(nbin=1000, nlayer=100, ny=20, ntemp=12, npress=10, nspecies=20,
+                    desc="config 3 shape at 1000 bins (quick check)"),
 }
 
 
@@ -69,7 +73,39 @@ def build_case(w, seed):
     c.surf_albedo = np.zeros(c.nbin)
     c.starflux = np.zeros(c.nbin)
     c.c_p_lay = np.full(c.nlayer, 3.5 * pc.R_UNIV)
+    c.species = None
+    if w.get("nspecies"):
+        # absorbers with molar weights U(2,64) and constant VMRs log-uniform in
+        # [1e-8,1e-2], plus H2/He filler (0.85/0.15) as Rayleigh scatterers; mixing method RO
+        sp = []
+        for s_ in range(w["nspecies"]):
+            # the k-table (0.96 GB each at C3 size) is generated when it is uploaded, then dropped
+            sp.append(dict(weight=float(rng.uniform(2.0, 64.0)), vmr=float(10.0 ** rng.uniform(-8.0, -2.0)),
+                           pretab="lazy", table_seed=seed * 100 + s_, scat=None, is_h2o=False, is_cia=False))
+        sp.append(dict(weight=2.016, vmr=0.85, pretab=None, scat=1e-27 * (1e-4 / c.opac_wave) ** 4,
+                       is_h2o=False, is_cia=False))
+        sp.append(dict(weight=4.0026, vmr=0.15, pretab=None, scat=1e-28 * (1e-4 / c.opac_wave) ** 4,
+                       is_h2o=False, is_cia=False))
+        c.species = sp
     return c
+
+
+def make_batch(ctx, c, ncol):
+    from helios_amd.rt import batch_from_case
+    sp = c.species
+    rt = batch_from_case(ctx, c, ncol=ncol, nspecies=len(sp) if sp else 0)
+    if sp:
+        from helios_amd import synthetic as syn
+        for k, s_ in enumerate(sp):
+            tab = s_["pretab"]
+            if isinstance(tab, str):
+                tab = syn.ktable(np.random.default_rng(s_["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+            rt.set_species(k, tab, s_["scat"], s_["weight"], is_h2o=0, is_cia=0, in_mu=1)
+            del tab
+        vl = np.array([np.full(c.nlayer, s_["vmr"]) for s_ in sp])
+        vi = np.array([np.full(c.nlayer + 1, s_["vmr"]) for s_ in sp])
+        rt.set_column_vmr(-1, vl, vi)
+    return rt
 
 
 def cpu_baseline(w, seed):
@@ -163,7 +199,7 @@ def main():
     c = build_case(w, seed)
     ctx = Context(local_rank)
     ncol = args.columns_per_gpu
-    rt = batch_from_case(ctx, c, ncol=ncol)
+    rt = make_batch(ctx, c, ncol)
     # every column of a sweep differs (here: internal temperature -> different T-P trajectories)
     if ncol > 1 or world > 1:
         for i in range(ncol):
@@ -196,6 +232,7 @@ def main():
 
     # per-kernel timing of the dominant kernel: a separate short pass with HIP events on the stream
     roofline = None
+    rt_prof = {}
     tm = rt.traffic_model()
     if args.profile_steps > 0:
         it0 = args.warmup + args.steps
@@ -206,6 +243,12 @@ def main():
         rt.run(it0, min(args.profile_steps, 9))     # E-iterations only
         rt.profile(False)
         flux_ms, nflux = rt.profile_read("rt_flux")
+        if c.species:   # one refresh under the profiler: where the on-the-fly mixing time goes
+            rt.profile(True)
+            rt.refresh()
+            rt.profile(False)
+        rt_prof = {k: rt.profile_read(k)[0] for k in ("refresh_total", "add_to_mixed_opac",
+                                                      "opac_species_interpol", "mixed_scat", "rt_coef")}
         if nflux:
             achieved = tm["step_algorithmic"] / (flux_ms * 1e-3) / 1e9
             traffic = None
@@ -249,7 +292,9 @@ def main():
         "spectrum_checksum": float(np.sum(spec)),
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if roofline is not None and c.species:
+        roofline["refresh_kernels_ms"] = {k: rt_prof[k] for k in rt_prof}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not c.species:
         line["cpu_baseline"] = cpu_baseline(w, seed)
     elif rank == 0:
         line["cpu_baseline"] = None

@@ -192,7 +192,7 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
     const TileGeom& g = rt->g;
     const int ntiles = g.nblk_x * g.nparts * g.NW;
     const int TS = COEF_TPB * g.S;
-    const size_t shmem = ((size_t)rt->L * TS + (size_t)rt->I * TS) * sizeof(double) + 2 * TS * sizeof(int);
+    const size_t shmem = 2 * ((size_t)rt->L * TS + (size_t)rt->I * TS) * sizeof(double) + 2 * TS * sizeof(int);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<ROWS>), dim3((ntiles + COEF_TPB - 1) / COEF_TPB, rt->C),
                        dim3(64 * COEF_TPB), shmem, rt->ctx->stream, a);
 }

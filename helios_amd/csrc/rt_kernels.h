@@ -123,9 +123,11 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ntiles = a.nblk_x * a.nparts * a.NW;
     const int TS = COEF_TPB * a.S;                  // spectral points staged per workgroup
-    double* sh_lay = smem;                          // [L][TS]
-    double* sh_int = sh_lay + (size_t)a.L * TS;     // [I][TS]
-    int* c_of_q = (int*)(sh_int + (size_t)a.I * TS);  // [TS] global spectral-point index or -1
+    double* sh_lay = smem;                          // [L][TS]  opacity at layer centres
+    double* sh_int = sh_lay + (size_t)a.L * TS;     // [I][TS]  opacity at interfaces
+    double* sh_scl = sh_int + (size_t)a.I * TS;     // [L][TS]  Rayleigh cross-section (per bin, replicated)
+    double* sh_sci = sh_scl + (size_t)a.L * TS;     // [I][TS]
+    int* c_of_q = (int*)(sh_sci + (size_t)a.I * TS);  // [TS] global spectral-point index or -1
     int* x_of_q = c_of_q + TS;
     const size_t nc = (size_t)a.Y * a.X;
     const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
@@ -155,6 +157,18 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
             sh_int[idx] = c >= 0 ? opi[(size_t)c + nc * lev] : 0.0;
         }
+        if (a.scat == 1) {
+            const double* scl_g = a.scat_cross_lay + col * bandI;
+            const double* sci_g = a.scat_cross_int + col * bandI;
+            for (int idx = threadIdx.x; idx < a.L * TS; idx += blockDim.x) {
+                const int lev = idx / TS, q = idx - lev * TS;
+                sh_scl[idx] = scl_g[x_of_q[q] + (size_t)a.X * lev];
+            }
+            for (int idx = threadIdx.x; idx < a.I * TS; idx += blockDim.x) {
+                const int lev = idx / TS, q = idx - lev * TS;
+                sh_sci[idx] = sci_g[x_of_q[q] + (size_t)a.X * lev];
+            }
+        }
     }
     __syncthreads();
     const int tl = blockIdx.x * COEF_TPB + wave;
@@ -163,8 +177,6 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     const int c = c_of_q[q], x = x_of_q[q];
     const bool valid = c >= 0;
     const hx_rt_column cp = a.colpar[col];
-    const double* scl = a.scat_cross_lay + col * bandI;
-    const double* sci = a.scat_cross_int + col * bandI;
     const double* mml = a.mmm_lay + (size_t)col * a.I;
     const double* mmi = a.mmm_int + (size_t)col * a.I;
     const double* dcu = a.dcol_u + (size_t)col * a.L;
@@ -190,7 +202,8 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 cab = lower ? (ai[b_i] + al[b_l]) / 2.0 : (al[b_l] + ai[b_i]) / 2.0;
             }
             if (a.scat == 1) {
-                ray = lower ? (sci[b_i] + scl[b_l]) / 2.0 : (scl[b_l] + sci[b_i]) / 2.0;
+                const double r_l = sh_scl[(size_t)i * TS + q], r_i = sh_sci[(size_t)ii * TS + q];
+                ray = lower ? (r_i + r_l) / 2.0 : (r_l + r_i) / 2.0;
                 if (a.clouds == 1) {
                     const double* sl = a.cl_sc_lay + col * bandI;
                     const double* si = a.cl_sc_int + col * bandI;
@@ -204,7 +217,8 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             const double w0 = single_scat_albedo(ray + csc, kap * mu + cab, a.w_0_limit);
             const double dtau_gas = dcol * (kap + ray / mu);
             const double dtau = dtau_gas + dcol * (cab + csc) / mu;
-            const Slab s = slab_coeffs(w0, dtau, g0, a.epsi, a.epsi2, cp.mu_star, a.scat_corr, a.i2s);
+            const Slab s = slab_coeffs(w0, dtau, g0, a.epsi, a.epsi2, cp.mu_star, a.scat_corr, a.i2s,
+                                       a.dir_beam == 1);
             const double invM = 1.0 / s.M;
             alpha = s.P * invM;
             beta = -s.N * invM;

@@ -29,7 +29,7 @@ struct Slab {
 // everything calc_trans_* derives from (w0, total optical depth, g0) for one (half-)layer
 __device__ __forceinline__ Slab slab_coeffs(double w0, double dtau, double g0, double epsi,
                                             double epsi2, double mu_star, int scat_corr,
-                                            double i2s) {
+                                            double i2s, bool need_G = true) {
     Slab s;
     const double E = E_factor(w0, g0, scat_corr, i2s);
     const double omg = 1.0 - w0 * g0;
@@ -42,6 +42,9 @@ __device__ __forceinline__ Slab slab_coeffs(double w0, double dtau, double g0, d
     s.M = (zm * zm) * t2 - (zp * zp);
     s.N = zp * zm * (1.0 - t2);
     s.P = ((zm * zm) - (zp * zp)) * s.trans;
+    s.Gp = 0.0;
+    s.Gm = 0.0;
+    if (!need_G) return s;  // only the direct-beam terms use G+-
     // G+-, :149-213
     const double num = w0 * (E * omg + g0 * epsi / epsi2);
     const double den = E * (1.0 / (epsi * epsi)) * (E - w0) * omg - 1.0 / (mu_star * mu_star);
