@@ -10,22 +10,31 @@ constexpr int RO_NY = 20;
 constexpr int RO_N = RO_NY * RO_NY;  // 400 pair sums
 constexpr int RO_PER_LANE = 7;       // 64 * 7 = 448 >= 400
 
+
 // add_to_mixed_opac (kernels.cu:3263-3399).  ONE wavefront (= one 64-thread
 // workgroup) per (bin x, level i): the 20+20 k-coefficients, the 400 pair sums and their sorted
 // copies live in LDS (13 KB per workgroup) instead of the reference's 9.9 KB of per-thread scratch.
 //
 // Sorting: the reference repeats adjacent-swap passes with a strict '<' (a stable sort of the
-// fill-ordered array).  Here every pair sum gets its rank directly: rank(e) = #{f : K_f < K_e or
-// (K_f == K_e and f < e)} with e, f the positions in the reference's fill order, which is the same
-// permutation.  K_f is read as an LDS broadcast (all lanes, one address), each lane ranks 7 sums.
+// fill-ordered array).  Here every pair sum gets its rank directly: rank(e) = #{f : K_f < K_e} +
+// #{f < e : K_f == K_e} with e, f the positions in the reference's fill order -- the same permutation
+// (the order inside a group of equal sums matters: it decides which weight sits at the group's edge).
+// The sums are read from LDS as broadcasts (all lanes, one address, two sums per 128-bit read) and each
+// lane ranks its 7 sums with one fp64 compare + add per pair.  If two sums are exactly equal their ranks
+// collide (detected by writing the positions into the rank slots and reading them back, a wave-uniform
+// decision); only then a second pass adds the tie-break.  (Measured alternatives, both slower on gfx950:
+// 64-bit integer keys -- v_cmp_lt_u64 issues at a fraction of the fp64 compare rate; a first pass on the
+// upper 32 key bits -- pair sums of a dominant and a minor absorber agree to < 1e-6 far too often.)
 __global__ void __launch_bounds__(64)
 k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ opac_spec,
                     double* __restrict__ opac_wg, const double* __restrict__ meanmolmass,
                     const double* __restrict__ gauss_weight, const double* __restrict__ gauss_y,
                     double mass_spec, int s, int ro_method, int ny, int nbin, int nlev) {
     __shared__ double s_mix[RO_NY], s_add[RO_NY], s_hw[RO_NY], s_gy[RO_NY];
-    __shared__ double s_K[RO_N], s_G[RO_N], s_Ks[RO_N + 64], s_Y[RO_N + 64];
+    __shared__ double s_G[RO_N], s_Ks[RO_N + 64], s_Y[RO_N + 64];
+    __shared__ __align__(16) double s_K[RO_N];
     __shared__ int s_w[RO_NY];
+    int* s_slot = (int*)s_Ks;  // rank slots alias the sorted-sum buffer (used before it is filled)
     const int lane = threadIdx.x;
     const long long npair = (long long)nbin * nlev;
     if (lane < ny && lane < RO_NY) {
@@ -77,20 +86,42 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
                     else            { y1 = e / ny; y2 = e - ny * y1; }
                 }
                 ke[r] = s_mix[y1] + s_add[y2];
-                s_K[e] = ke[r];
                 s_G[e] = s_hw[y1] * s_hw[y2];
+                s_K[e] = ke[r];
             }
         }
         __syncthreads();
         // ranks
         int rank[RO_PER_LANE];
-        for (int r = 0; r < RO_PER_LANE; r++) rank[r] = 0;
-        for (int f = 0; f < RO_N; f++) {
-            const double kf = s_K[f];
 #pragma unroll
-            for (int r = 0; r < RO_PER_LANE; r++) {
-                const int e = lane + 64 * r;
-                rank[r] += (kf < ke[r] || (kf == ke[r] && f < e)) ? 1 : 0;
+        for (int r = 0; r < RO_PER_LANE; r++) rank[r] = 0;
+        {
+            const double2* keys2 = reinterpret_cast<const double2*>(s_K);
+#pragma unroll 8
+            for (int f2 = 0; f2 < RO_N / 2; f2++) {
+                const double2 kf = keys2[f2];
+#pragma unroll
+                for (int r = 0; r < RO_PER_LANE; r++) rank[r] += (kf.x < ke[r] ? 1 : 0) + (kf.y < ke[r] ? 1 : 0);
+            }
+        }
+        // equal sums collide on a rank slot
+        for (int r = 0; r < RO_PER_LANE; r++) {
+            const int e = lane + 64 * r;
+            if (e < RO_N) s_slot[rank[r]] = e;
+        }
+        __syncthreads();
+        bool clash = false;
+        for (int r = 0; r < RO_PER_LANE; r++) {
+            const int e = lane + 64 * r;
+            if (e < RO_N && s_slot[rank[r]] != e) clash = true;
+        }
+        const bool any_clash = __ballot(clash) != 0;
+        __syncthreads();
+        if (any_clash) {  // rare: exact ties -> stable order by fill position
+            for (int f = 0; f < RO_N; f++) {
+                const double kf = s_K[f];
+#pragma unroll
+                for (int r = 0; r < RO_PER_LANE; r++) rank[r] += (kf == ke[r] && f < lane + 64 * r) ? 1 : 0;
             }
         }
         // scatter into sorted order; s_Y temporarily holds the sorted weights
