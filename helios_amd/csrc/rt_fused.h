@@ -49,6 +49,10 @@ struct hx_rt {
     hx::TileGeom g;
     bool have_grid = false, have_tables = false, have_planck = false, refreshed = false;
     bool keep_down = false;
+    bool opac_stale = false;      // opac_wg_lay/int not materialised since the last (fused) refresh
+    void* tp_lay = nullptr;       // TPIndex [C][I]
+    void* tp_int = nullptr;
+    double *T_lay_ref = nullptr, *T_int_ref = nullptr;  // temperatures of the last refresh
     int nchunk;  // x-chunks of the totals reduction
 
     // shared device arrays

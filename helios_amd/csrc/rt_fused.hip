@@ -134,6 +134,9 @@ KArgs make_args(hx_rt* rt) {
     a.F_up_tot = rt->F_up_tot; a.F_down_tot = rt->F_down_tot; a.F_net = rt->F_net;
     a.coef_col = g.coef_elems_per_col; a.flux_col = g.flux_elems_per_col;
     a.done = rt->done;
+    a.ktable = rt->opac_k; a.crosstable = rt->opac_scat_cross; a.ktemp = rt->ktemp; a.kpress = rt->kpress;
+    a.tp_lay = (const TPIndex*)rt->tp_lay; a.tp_int = (const TPIndex*)rt->tp_int;
+    a.ntemp = rt->d.ntemp; a.npress = rt->d.npress; a.from_table = 0;
     return a;
 }
 
@@ -184,8 +187,22 @@ template <int ROWS>
 void launch_flux(hx_rt* rt, const KArgs& a) {
     const TileGeom& g = rt->g;
     const size_t shmem = flux_shmem_bytes(rt);
+    FluxArgs f;
+    memset(&f, 0, sizeof(f));
+    f.X = a.X; f.Y = a.Y; f.L = a.L; f.I = a.I; f.H = a.H;
+    f.k = a.k; f.nxb = a.nxb; f.ypb = a.ypb; f.nparts = a.nparts; f.G = a.G; f.NW = a.NW;
+    f.dir_beam = a.dir_beam; f.nsweep = a.nsweep; f.keep_down = a.keep_down; f.has_vp = a.has_vp;
+    f.pl_vp = a.pl_vp; f.pl_dd = a.pl_dd; f.nplane = a.nplane;
+    f.Kconst = a.Kconst;
+    f.colpar = a.colpar;
+    f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
+    f.surf_albedo = a.surf_albedo; f.gauss_w = a.gauss_w;
+    f.Utile = a.Utile; f.Dtile = a.Dtile; f.U0 = a.U0; f.F_down_band_n = a.F_down_band_n;
+    f.F_up_band_n = a.F_up_band_n;
+    f.coef_col = a.coef_col; f.flux_col = a.flux_col;
+    f.done = a.done;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
-                       rt->ctx->stream, a);
+                       rt->ctx->stream, f);
 }
 template <int ROWS>
 void launch_coef(hx_rt* rt, const KArgs& a) {
@@ -312,6 +329,12 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     RT_ALLOC(rt->F_smooth, C * L); RT_ALLOC(rt->F_smooth_sum, C * L); RT_ALLOC(rt->c_p_lay, C * L);
     RT_ALLOC(rt->abort_flags, C * (L + 1)); RT_ALLOC(rt->conv_count, C); RT_ALLOC(rt->done, C);
     RT_ALLOC(rt->iters_done, C);
+    {
+        TPIndex* t1 = nullptr; TPIndex* t2 = nullptr;
+        RT_ALLOC(t1, C * I); RT_ALLOC(t2, C * I);
+        rt->tp_lay = t1; rt->tp_int = t2;
+    }
+    RT_ALLOC(rt->T_lay_ref, C * (L + 1)); RT_ALLOC(rt->T_int_ref, C * I);
     rc = h2d(rt, rt->colpar, rt->cols.data(), C * sizeof(hx_rt_column));
     if (rc) return rc;
     *out_rt = rt;
@@ -537,6 +560,22 @@ int hx_rt_refresh(hx_rt* rt) {
         HX_LAUNCH_CHECK(ctx);
     }
     ProfScope ps_all(rt, "refresh_total");
+    // premixed table without the beam: the k-table look-up is fused into k_rt_coef (the beam needs the
+    // materialised opacities for its optical depths); HELIOS_RT_FUSED_LOOKUP=0 switches it off
+    bool fused_lookup = rt->d.nspecies == 0 && !rt->f.dir_beam;
+    if (const char* e = getenv("HELIOS_RT_FUSED_LOOKUP")) fused_lookup = fused_lookup && atoi(e) != 0;
+    if (fused_lookup) {
+        k_rt_tp_index<<<dim3(hx_cdiv(I, 64), rt->C), 64, 0, ctx->stream>>>(a, (TPIndex*)rt->tp_lay, (TPIndex*)rt->tp_int);
+        k_rt_scat_interp<<<dim3(hx_cdiv(X, 256), I, rt->C), 256, 0, ctx->stream>>>(a, rt->scat_cross_lay, rt->scat_cross_int);
+        HX_LAUNCH_CHECK(ctx);
+        // remember the temperatures this refresh used, so that the arrays can be rebuilt on demand
+        for (int c = 0; c < rt->C; c++) {
+            if (done[c]) continue;  // a finished column keeps the state of its last real refresh
+            hx_d2d(ctx, rt->T_lay_ref + (size_t)c * (L + 1), rt->T_lay + (size_t)c * (L + 1), (size_t)(L + 1) * 8);
+            hx_d2d(ctx, rt->T_int_ref + (size_t)c * I, rt->T_int + (size_t)c * I, (size_t)I * 8);
+        }
+    }
+    rt->opac_stale = fused_lookup;
     for (int c = 0; c < rt->C; c++) {
         if (done[c]) continue;
         const double* T_lay = rt->T_lay + (size_t)c * (L + 1);
@@ -549,7 +588,15 @@ int hx_rt_refresh(hx_rt* rt) {
         double* sci = rt->scat_cross_int + c * bandI;
         double* mml = rt->mmm_lay + (size_t)c * I;
         double* mmi = rt->mmm_int + (size_t)c * I;
-        if (rt->d.nspecies == 0) {
+        if (rt->d.nspecies == 0 && fused_lookup) {
+            // opacities are interpolated inside k_rt_coef; only the mean molecular mass here
+            rc = hx_meanmolmass_interpol(ctx, T_lay, rt->ktemp, mml, rt->opac_meanmass, p_lay, rt->kpress,
+                                         rt->d.npress, rt->d.ntemp, L);
+            if (rc) return rc;
+            rc = hx_meanmolmass_interpol(ctx, T_int, rt->ktemp, mmi, rt->opac_meanmass, p_int, rt->kpress,
+                                         rt->d.npress, rt->d.ntemp, I);
+            if (rc) return rc;
+        } else if (rt->d.nspecies == 0) {
             ProfScope ps(rt, "opac_interpol");
             rc = hx_opac_interpol(ctx, T_lay, rt->ktemp, p_lay, rt->kpress, rt->opac_k, opl,
                                   rt->opac_scat_cross, scl, rt->d.npress, rt->d.ntemp, Y, X, L);
@@ -672,6 +719,7 @@ int hx_rt_refresh(hx_rt* rt) {
     }
     {
         ProfScope ps(rt, "rt_coef");
+        a.from_table = fused_lookup ? 1 : 0;
         DISPATCH_ROWS(launch_coef, rt, a);
         HX_LAUNCH_CHECK(ctx);
     }
@@ -799,14 +847,14 @@ int get_flux_wg(hx_rt* rt, int col, const double* tiles, const double* bc, bool 
             const size_t c = y + Y * x;
             for (int j = 0; j < g.k; j++) {
                 const int tid = s * g.k + j, wv = tid / 64, lane = tid % 64;
-                const double* tile = t.data() + ((size_t)blk * g.NW + wv) * g.ROWS * 64 + lane;
+                const double* tile = t.data() + ((size_t)blk * g.NW + wv) * g.ROWS * 64;
                 for (int r = 0; r < g.ROWS; r++) {
                     const int h = j * g.ROWS + r;
                     if (h >= rt->H) continue;
                     const int node = up ? h + 1 : h;
                     const bool is_int = (node % 2) == 0;
                     if (is_int != interface_nodes) continue;
-                    o[c + nc * (node / 2)] = tile[(size_t)r * 64];
+                    o[c + nc * (node / 2)] = tile[plane_off(r, lane, g.ROWS)];
                 }
             }
             if (up && interface_nodes && bc) o[c] = b[c];  // U at node 0 = BOA boundary value
@@ -817,8 +865,31 @@ int get_flux_wg(hx_rt* rt, int col, const double* tiles, const double* bc, bool 
 
 }  // namespace
 
+// rebuild opac_wg_lay/int (reference layout) from the temperatures of the last refresh
+static int materialize_opac(hx_rt* rt) {
+    if (!rt->opac_stale) return 0;
+    hx_context* ctx = rt->ctx;
+    const size_t nc = (size_t)rt->X * rt->Y, wgI = nc * rt->I, bandI = (size_t)rt->X * rt->I;
+    for (int c = 0; c < rt->C; c++) {
+        int rc = hx_opac_interpol(ctx, rt->T_lay_ref + (size_t)c * (rt->L + 1), rt->ktemp, rt->p_lay + (size_t)c * rt->L,
+                                  rt->kpress, rt->opac_k, rt->opac_wg_lay + c * wgI, rt->opac_scat_cross,
+                                  rt->scat_cross_lay + c * bandI, rt->d.npress, rt->d.ntemp, rt->Y, rt->X, rt->L);
+        if (rc) return rc;
+        rc = hx_opac_interpol(ctx, rt->T_int_ref + (size_t)c * rt->I, rt->ktemp, rt->p_int + (size_t)c * rt->I,
+                              rt->kpress, rt->opac_k, rt->opac_wg_int + c * wgI, rt->opac_scat_cross,
+                              rt->scat_cross_int + c * bandI, rt->d.npress, rt->d.ntemp, rt->Y, rt->X, rt->I);
+        if (rc) return rc;
+    }
+    rt->opac_stale = false;
+    return 0;
+}
+
 int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes) {
     HX_REQUIRE(rt->ctx, col >= 0 && col < rt->C, HX_E_ARG, "column index out of range");
+    if (strncmp(name, "opac_wg_", 8) == 0) {
+        int rc = materialize_opac(rt);
+        if (rc) return rc;
+    }
     const size_t X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, nc = X * Y, c = col;
     const std::string n(name);
     if (n == "T_lay") return get_plain(rt, rt->T_lay + c * (L + 1), (L + 1) * 8, out, out_bytes);
@@ -939,8 +1010,8 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
     else if (n == "T_int") p = rt->T_int + c * I;
     else if (n == "p_lay") p = rt->p_lay + c * L;
     else if (n == "p_int") p = rt->p_int + c * I;
-    else if (n == "opac_wg_lay") p = rt->opac_wg_lay + c * nc * I;
-    else if (n == "opac_wg_int") p = rt->opac_wg_int + c * nc * I;
+    else if (n == "opac_wg_lay") { int rc = materialize_opac(rt); if (rc) return rc; p = rt->opac_wg_lay + c * nc * I; }
+    else if (n == "opac_wg_int") { int rc = materialize_opac(rt); if (rc) return rc; p = rt->opac_wg_int + c * nc * I; }
     else if (n == "scat_cross_lay") p = rt->scat_cross_lay + c * X * I;
     else if (n == "scat_cross_int") p = rt->scat_cross_int + c * X * I;
     else if (n == "meanmolmass_lay") p = rt->mmm_lay + c * I;

@@ -37,12 +37,58 @@ struct KArgs {
     double *F_down_band_n, *F_up_band_n, *tot_part, *F_up_tot, *F_down_tot, *F_net;
     size_t coef_col, flux_col;  // per-column strides (doubles) of coef / Utile / Dtile
     const int* done;
+    // premixed table look-up fused into the coefficient kernel
+    const double *ktable, *crosstable, *ktemp, *kpress;
+    const TPIndex *tp_lay, *tp_int;  // [C][I] fractional table indices of the levels
+    int ntemp, npress, from_table;
+};
+
+// the subset k_rt_flux needs (a leaner argument block keeps its SGPR pressure -- and with it the VGPR
+// count, which sits at the 256-register / 2-waves-per-SIMD edge -- down)
+struct FluxArgs {
+    int X, Y, L, I, H;
+    int k, nxb, ypb, nparts, G, NW;
+    int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane;
+    double Kconst;
+    const hx_rt_column* colpar;
+    const double *Bn, *coef, *U0_in, *boaK, *Fdir0, *surf_albedo, *gauss_w;
+    double *Utile, *Dtile, *U0, *F_down_band_n, *F_up_band_n;
+    size_t coef_col, flux_col;
+    const int* done;
 };
 
 __device__ __forceinline__ double interface_T(const double* T, int i, int L) {
     if (i == 0) return T[0] - 0.5 * (T[1] - T[0]);
     if (i == L) return T[L - 1] + 0.5 * (T[L - 1] - T[L - 2]);
     return T[i - 1] + 0.5 * (T[i] - T[i - 1]);
+}
+
+// Tile planes hold ROWS rows of 64 lanes, [row][lane]: every wavefront load/store of a row is one
+// contiguous 512-byte segment.  (A paired-row layout with 16-byte accesses per lane was measured: the
+// 16-byte register alignment pushed k_rt_flux<13> from 218 to 256+ VGPRs with scratch spills and made
+// it 40 % slower, so rows stay scalar.)  Offset of (row r, lane) inside a plane:
+__host__ __device__ __forceinline__ size_t plane_off(int r, int lane, int ROWS) {
+    (void)ROWS;
+    return (size_t)r * 64 + lane;
+}
+
+template <int ROWS>
+struct RowRegs {
+    double v[ROWS];
+    __device__ __forceinline__ double& operator[](int r) { return v[r]; }
+    __device__ __forceinline__ double operator[](int r) const { return v[r]; }
+};
+
+template <int ROWS>
+__device__ __forceinline__ void load_plane(const double* __restrict__ plane, int lane, RowRegs<ROWS>& dst) {
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) dst.v[r] = plane[r * 64 + lane];
+}
+
+template <int ROWS>
+__device__ __forceinline__ void store_plane(double* __restrict__ plane, int lane, const RowRegs<ROWS>& src) {
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) plane[r * 64 + lane] = src.v[r];
 }
 
 // ---- per iteration: interface temperatures + Planck function at every node ------------------
@@ -90,7 +136,8 @@ struct LaneMap {
 };
 
 // workgroup bx covers bins [bx*nxb, (bx+1)*nxb) and walks the nparts groups of ypb Gauss points
-__device__ __forceinline__ LaneMap lane_map(const KArgs& a, int bx, int part) {
+template <class Args>
+__device__ __forceinline__ LaneMap lane_map(const Args& a, int bx, int part) {
     LaneMap m;
     const int tid = threadIdx.x;
     m.lane = tid & 63;
@@ -149,13 +196,35 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     {
         const double* opl = a.opac_wg_lay + col * wgI;
         const double* opi = a.opac_wg_int + col * wgI;
-        for (int idx = threadIdx.x; idx < a.L * TS; idx += blockDim.x) {
-            const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
-            sh_lay[idx] = c >= 0 ? opl[(size_t)c + nc * lev] : 0.0;
-        }
-        for (int idx = threadIdx.x; idx < a.I * TS; idx += blockDim.x) {
-            const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
-            sh_int[idx] = c >= 0 ? opi[(size_t)c + nc * lev] : 0.0;
+        if (a.from_table) {
+            // premixed k-table look-up done while staging (kernels.cu:561-608): the opacity arrays of
+            // the reference are not materialised on this path (hx_rt_get rebuilds them on demand)
+            const size_t sp = nc, st = nc * a.npress;
+            for (int pass = 0; pass < 2; pass++) {
+                const int nlev = pass == 0 ? a.L : a.I;
+                const TPIndex* tp = (pass == 0 ? a.tp_lay : a.tp_int) + (size_t)col * a.I;
+                double* dst = pass == 0 ? sh_lay : sh_int;
+                for (int idx = threadIdx.x; idx < nlev * TS; idx += blockDim.x) {
+                    const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
+                    double v = 0.0;
+                    if (c >= 0) {
+                        const TPIndex k = tp[lev];
+                        const double* t0 = a.ktable + (size_t)c + st * k.tdown;
+                        const double* t1 = a.ktable + (size_t)c + st * k.tup;
+                        v = blend_tp(t0[sp * k.pdown], t0[sp * k.pup], t1[sp * k.pdown], t1[sp * k.pup], k, false);
+                    }
+                    dst[idx] = v;
+                }
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < a.L * TS; idx += blockDim.x) {
+                const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
+                sh_lay[idx] = c >= 0 ? opl[(size_t)c + nc * lev] : 0.0;
+            }
+            for (int idx = threadIdx.x; idx < a.I * TS; idx += blockDim.x) {
+                const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
+                sh_int[idx] = c >= 0 ? opi[(size_t)c + nc * lev] : 0.0;
+            }
         }
         if (a.scat == 1) {
             const double* scl_g = a.scat_cross_lay + col * bandI;
@@ -181,7 +250,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     const double* mmi = a.mmm_int + (size_t)col * a.I;
     const double* dcu = a.dcol_u + (size_t)col * a.L;
     const double* dcl = a.dcol_l + (size_t)col * a.L;
-    double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64 + lane;
+    double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64;
     const double nmu = -cp.mu_star;
     for (int r = 0; r < ROWS; r++) {
         const int h = j * ROWS + r;
@@ -249,13 +318,14 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 a.Fdir0[col * nc + c] = a.dir_beam == 1 ? (a.F_dir_wg + col * wgI)[c] : 0.0;
             }
         }
-        ctile[(0 * ROWS + r) * 64] = alpha;
-        ctile[(1 * ROWS + r) * 64] = beta;
-        ctile[(2 * ROWS + r) * 64] = up;
-        if (a.has_vp) ctile[(a.pl_vp * ROWS + r) * 64] = vp;
+        const size_t off = plane_off(r, lane, ROWS);
+        ctile[0 * ROWS * 64 + off] = alpha;
+        ctile[1 * ROWS * 64 + off] = beta;
+        ctile[2 * ROWS * 64 + off] = up;
+        if (a.has_vp) ctile[(size_t)a.pl_vp * ROWS * 64 + off] = vp;
         if (a.dir_beam == 1) {
-            ctile[(a.pl_dd * ROWS + r) * 64] = dd;
-            ctile[((a.pl_dd + 1) * ROWS + r) * 64] = du;
+            ctile[(size_t)a.pl_dd * ROWS * 64 + off] = dd;
+            ctile[(size_t)(a.pl_dd + 1) * ROWS * 64 + off] = du;
         }
     }
 }
@@ -291,7 +361,7 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 // grid (nblk_x, C).  A workgroup owns nxb bins and walks their ny/ypb groups of Gauss points one
 // after the other, so the Gauss sum of a bin is completed inside the workgroup (fixed order).
 template <int ROWS>
-__global__ void __launch_bounds__(320) k_rt_flux(KArgs a) {
+__global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = blockIdx.y;
     if (a.done[col]) return;
@@ -603,6 +673,34 @@ __global__ void __launch_bounds__(256) k_rt_fdir_band(const double* __restrict__
     double s = 0.0;
     for (int y = 0; y < Y; y++) s += 0.5 * gauss_w[y] * F_dir_wg[(size_t)y + (size_t)Y * x + (size_t)Y * X * i];
     out[(size_t)x * I + i] = s;
+}
+
+// fractional (T, log10 P) table indices of every layer and interface of every column
+__global__ void k_rt_tp_index(KArgs a, TPIndex* tp_lay, TPIndex* tp_int) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.I || a.done[col]) return;
+    const double* T = a.T_lay + (size_t)col * (a.L + 1);
+    tp_int[(size_t)col * a.I + i] = locate_tp(interface_T(T, i, a.L), a.p_int[(size_t)col * a.I + i], a.ktemp,
+                                              a.ntemp, a.kpress, a.npress, true, false);
+    if (i < a.L)
+        tp_lay[(size_t)col * a.I + i] = locate_tp(T[i], a.p_lay[(size_t)col * a.L + i], a.ktemp, a.ntemp, a.kpress,
+                                                  a.npress, true, false);
+}
+
+// Rayleigh cross-sections of the premixed table at every level (the [x + X*level] half of opac_interpol)
+__global__ void __launch_bounds__(256) k_rt_scat_interp(KArgs a, double* scat_lay, double* scat_int) {
+    const int col = blockIdx.z, lev = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.X || a.done[col]) return;
+    const size_t cp = a.X, ct = (size_t)a.X * a.npress, bandI = (size_t)a.X * a.I;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 0 && lev >= a.L) continue;
+        const TPIndex k = (pass == 0 ? a.tp_lay : a.tp_int)[(size_t)col * a.I + lev];
+        const double* t0 = a.crosstable + x + ct * k.tdown;
+        const double* t1 = a.crosstable + x + ct * k.tup;
+        (pass == 0 ? scat_lay : scat_int)[col * bandI + x + (size_t)a.X * lev] =
+            blend_tp(t0[cp * k.pdown], t0[cp * k.pup], t1[cp * k.pdown], t1[cp * k.pup], k, false);
+    }
 }
 
 // broadcast a scalar-per-bin cross-section to all levels: out[x + X*i] = src[x]
