@@ -277,6 +277,7 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     rt->X = dims->nbin; rt->Y = dims->ny; rt->L = dims->nlayer; rt->I = rt->L + 1; rt->H = 2 * rt->L;
     rt->C = dims->ncol;
     rt->nsweep = 3 * (flags->scat ? 1 : 0) + 1;  // computation.py:531-537 (iterative run type)
+    if (const char* e = getenv("HELIOS_RT_DEBUG_NSWEEP")) rt->nsweep = atoi(e);  // profiling experiments only
     if (!choose_geometry(rt->L, rt->Y, rt->X, flags->dir_beam, flags->scat_corr, rt->g)) {
         delete rt;
         return hx_fail(ctx, HX_E_UNSUPPORTED,

@@ -127,6 +127,57 @@ __global__ void __launch_bounds__(256) k_rt_nodes(KArgs a) {
     }
 }
 
+// ---- neighbour-lane moves for the scans --------------------------------------------------------
+// Distances 1, 2, 4, 8 stay inside a 16-lane DPP row: `row_shr:n` / `row_shl:n` move a register across
+// lanes in the VALU (a few cycles) instead of going through the LDS crossbar (ds_bpermute, ~100 cycles
+// of dependent latency per scan step).  Values arriving from outside the spectral point's k-lane group
+// are discarded by the callers' `j` conditions, so no masking is needed here.  Groups wider than a
+// DPP row (k = 32, 64) use __shfl for every distance.
+template <int N>
+__device__ __forceinline__ double from_lane_below(double v, int k) {  // value of lane (id - N)
+    if (N < 16 && k <= 16) {  // wave-uniform: the k-lane group lies inside one DPP row
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x110 + (N & 15), 0xf, 0xf, false);  // row_shr:N
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x110 + (N & 15), 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl_up(v, N);
+    }
+}
+template <int N>
+__device__ __forceinline__ double from_lane_above(double v, int k) {  // value of lane (id + N)
+    if (N < 16 && k <= 16) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + (N & 15), 0xf, 0xf, false);  // row_shl:N
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + (N & 15), 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl_down(v, N);
+    }
+}
+
+// one Kogge-Stone step of the affine-map scans: (A, B) <- (A, B) o (A, B)[neighbour at distance N]
+template <int N>
+__device__ __forceinline__ void scan_step_down(double& A, double& Bc, int j, int k) {
+    if (N < k) {  // wave-uniform
+        const double A2 = from_lane_above<N>(A, k), B2 = from_lane_above<N>(Bc, k);
+        if (j + N < k) {
+            Bc = fma(A, B2, Bc);
+            A *= A2;
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void scan_step_up(double& A, double& Bc, int j, int k) {
+    if (N < k) {
+        const double A2 = from_lane_below<N>(A, k), B2 = from_lane_below<N>(Bc, k);
+        if (j >= N) {
+            Bc = fma(A, B2, Bc);
+            A *= A2;
+        }
+    }
+}
+
 // which spectral point / layer chunk a thread of a flux workgroup works on
 struct LaneMap {
     int lane, wv, j, x, y, xl, yl;
@@ -431,7 +482,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
         for (int sweep = 0; sweep < a.nsweep; sweep++) {
             // ---------------- down: TOA -> BOA ----------------
             {
-                double Ubelow = __shfl_up(Uo[ROWS - 1], 1, k);  // U at the bottom node of this chunk
+                double Ubelow = from_lane_below<1>(Uo[ROWS - 1], k);  // U at the bottom node of this chunk
                 if (m.j == 0) Ubelow = U0;
                 double A = 1.0, Bc = 0.0;
 #pragma unroll
@@ -442,14 +493,13 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     A *= al[r];
                 }
                 // inclusive suffix composition over the k lanes of this spectral point
-                for (int d = 1; d < k; d <<= 1) {
-                    const double A2 = __shfl_down(A, d, k), B2 = __shfl_down(Bc, d, k);
-                    if (m.j + d < k) {
-                        Bc = fma(A, B2, Bc);
-                        A *= A2;
-                    }
-                }
-                double Din = __shfl_down(fma(A, D_toa, Bc), 1, k);
+                scan_step_down<1>(A, Bc, m.j, k);
+                scan_step_down<2>(A, Bc, m.j, k);
+                scan_step_down<4>(A, Bc, m.j, k);
+                scan_step_down<8>(A, Bc, m.j, k);
+                scan_step_down<16>(A, Bc, m.j, k);
+                scan_step_down<32>(A, Bc, m.j, k);
+                double Din = from_lane_above<1>(fma(A, D_toa, Bc), k);
                 if (m.j == k - 1) Din = D_toa;
                 double D = Din;
 #pragma unroll
@@ -464,7 +514,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             const double Ubc = __shfl(U0, 0, k);
             // ---------------- up: BOA -> TOA ----------------
             {
-                double Dabove = __shfl_down(Do[0], 1, k);  // D at the top node of this chunk
+                double Dabove = from_lane_above<1>(Do[0], k);  // D at the top node of this chunk
                 if (m.j == k - 1) Dabove = D_toa;
                 double A = 1.0, Bc = 0.0;
 #pragma unroll
@@ -474,14 +524,13 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     Bc = fma(al[r], Bc, t);
                     A *= al[r];
                 }
-                for (int d = 1; d < k; d <<= 1) {
-                    const double A2 = __shfl_up(A, d, k), B2 = __shfl_up(Bc, d, k);
-                    if (m.j >= d) {
-                        Bc = fma(A, B2, Bc);
-                        A *= A2;
-                    }
-                }
-                double Uin = __shfl_up(fma(A, Ubc, Bc), 1, k);
+                scan_step_up<1>(A, Bc, m.j, k);
+                scan_step_up<2>(A, Bc, m.j, k);
+                scan_step_up<4>(A, Bc, m.j, k);
+                scan_step_up<8>(A, Bc, m.j, k);
+                scan_step_up<16>(A, Bc, m.j, k);
+                scan_step_up<32>(A, Bc, m.j, k);
+                double Uin = from_lane_below<1>(fma(A, Ubc, Bc), k);
                 if (m.j == 0) Uin = Ubc;
                 double U = Uin;
 #pragma unroll
