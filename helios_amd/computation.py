@@ -171,8 +171,30 @@ class Compute(object):
                            _i(q.dir_beam), _i(q.clouds), _i(q.scat_corr), _i(q.debug or 0), _f(q.i2s_transition))
 
     def solve_for_spectral_fluxes_via_matrix(self, quant):
-        raise NotImplementedError("flux calculation method 'matrix' (reference fband_matrix_*, documented there "
-                                  "as unstable) is not part of this build; use 'iteration'")
+        """source/computation.py:625-710: one tridiagonal solve per spectral point instead of the sweeps"""
+        q = quant
+        work = (q.dev_alpha.d, q.dev_beta.d, q.dev_source_term_down.d, q.dev_source_term_up.d,
+                q.dev_c_prime.d, q.dev_d_prime.d, q.dev_scat_trigger.i)
+        if q.iso == 1:
+            self._call("hx_fband_matrix_iso", q.dev_F_down_wg.d, q.dev_F_up_wg.d, q.dev_F_dir_wg.d,
+                       q.dev_planckband_lay.d, q.dev_w_0.d, q.dev_M_term.d, q.dev_N_term.d, q.dev_P_term.d,
+                       q.dev_G_plus.d, q.dev_G_minus.d, q.dev_g_0_tot_lay.d, *work, q.dev_trans_wg.d,
+                       q.dev_surf_albedo.d, _f(q.g_0), _i(q.singlewalk), _f(q.R_star), _f(q.a),
+                       _i(q.ninterface), _i(q.nbin), _f(q.f_factor), _f(q.mu_star), _i(q.ny), _f(q.epsi),
+                       _i(q.dir_beam), _i(q.clouds), _i(q.scat_corr), _i(q.debug or 0), _f(q.i2s_transition))
+        else:
+            self._call("hx_fband_matrix_noniso", q.dev_F_down_wg.d, q.dev_F_up_wg.d, q.dev_Fc_down_wg.d,
+                       q.dev_Fc_up_wg.d, q.dev_F_dir_wg.d, q.dev_Fc_dir_wg.d, q.dev_planckband_lay.d,
+                       q.dev_planckband_int.d, q.dev_w_0_upper.d, q.dev_w_0_lower.d,
+                       q.dev_delta_tau_wg_upper.d, q.dev_delta_tau_wg_lower.d,
+                       q.dev_delta_tau_all_clouds_upper.d, q.dev_delta_tau_all_clouds_lower.d,
+                       q.dev_M_upper.d, q.dev_M_lower.d, q.dev_N_upper.d, q.dev_N_lower.d, q.dev_P_upper.d,
+                       q.dev_P_lower.d, q.dev_G_plus_upper.d, q.dev_G_plus_lower.d, q.dev_G_minus_upper.d,
+                       q.dev_G_minus_lower.d, q.dev_g_0_tot_lay.d, q.dev_g_0_tot_int.d, *work,
+                       q.dev_trans_wg_upper.d, q.dev_trans_wg_lower.d, q.dev_surf_albedo.d, _f(q.g_0),
+                       _i(q.singlewalk), _f(q.R_star), _f(q.a), _i(q.ninterface), _i(q.nbin), _f(q.f_factor),
+                       _f(q.mu_star), _i(q.ny), _f(q.epsi), _f(q.delta_tau_limit), _i(q.dir_beam),
+                       _i(q.clouds), _i(q.scat_corr), _i(q.debug or 0), _f(q.i2s_transition))
 
     def integrate_flux(self, quant):
         q = quant

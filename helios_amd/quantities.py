@@ -166,6 +166,13 @@ class Store(object):
                 self.dev_opac_spec_wg_int = ctx.zeros(int(self.ninterface_wg_nbin))
                 self.dev_scat_cross_spec_int = ctx.zeros(int(self.ninterface_nbin))
                 self.dev_vmr_spec_int = ctx.zeros(int(self.ninterface))
+        if self.flux_calc_method == "matrix":                      # source/quantities.py:652-665
+            slabs = wg if self.iso == 1 else 2 * wg
+            rows = int(self.wg_nbin) * (2 * int(self.ninterface) if self.iso == 1 else 4 * int(self.ninterface) - 2)
+            for n in ("alpha", "beta", "source_term_down", "source_term_up"):
+                setattr(self, "dev_" + n, ctx.zeros(slabs))
+            self.dev_c_prime = ctx.zeros(rows)
+            self.dev_d_prime = ctx.zeros(rows)
 
     def copy_device_to_host(self):
         """source/quantities.py:551-591"""

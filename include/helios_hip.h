@@ -168,6 +168,37 @@ int hx_fband_noniso(hx_context* ctx, double* F_down_wg, double* F_up_wg, double*
                     int singlewalk, double Rstar, double a, int numinterfaces, int nbin,
                     double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit,
                     int dir_beam, int clouds, int scat_corr, int debug, double i2s_transition);
+/* fband_matrix_iso, kernels.cu:1803 / computation.py:625 -- the flux solve as one tridiagonal system
+ * (Thomas algorithm) per spectral point; alpha .. d_prime are caller-provided work arrays
+ * (ny*nbin*nlayer each for alpha, beta and the two sources; ny*nbin*2*ninterface for c_prime, d_prime).
+ * The surface albedo must be > 0 (the reference's reader enforces >= 1e-8, read.py:1261). */
+int hx_fband_matrix_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
+                        const double* planckband_lay, const double* w_0, const double* M_term,
+                        const double* N_term, const double* P_term, const double* G_plus,
+                        const double* G_minus, const double* g_0_tot_lay, double* alpha, double* beta,
+                        double* source_term_down, double* source_term_up, double* c_prime,
+                        double* d_prime, const int* scat_trigger, const double* trans_wg,
+                        const double* surf_albedo, double g_0, int singlewalk, double Rstar, double a,
+                        int numinterfaces, int nbin, double f_factor, double mu_star, int ny,
+                        double epsi, int dir_beam, int clouds, int scat_corr, int debug,
+                        double i2s_transition);
+/* fband_matrix_noniso, kernels.cu:2028 / computation.py:667 (work arrays: 2*nlayer planes for alpha,
+ * beta, sources; 4*ninterface-2 planes for c_prime, d_prime) */
+int hx_fband_matrix_noniso(
+    hx_context* ctx, double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg,
+    const double* F_dir_wg, const double* Fc_dir_wg, const double* planckband_lay,
+    const double* planckband_int, const double* w_0_upper, const double* w_0_lower,
+    const double* delta_tau_wg_upper, const double* delta_tau_wg_lower,
+    const double* delta_tau_all_clouds_upper, const double* delta_tau_all_clouds_lower,
+    const double* M_upper, const double* M_lower, const double* N_upper, const double* N_lower,
+    const double* P_upper, const double* P_lower, const double* G_plus_upper,
+    const double* G_plus_lower, const double* G_minus_upper, const double* G_minus_lower,
+    const double* g_0_tot_lay, const double* g_0_tot_int, double* alpha, double* beta,
+    double* source_term_down, double* source_term_up, double* c_prime, double* d_prime,
+    const int* scat_trigger, const double* trans_wg_upper, const double* trans_wg_lower,
+    const double* surf_albedo, double g_0, int singlewalk, double Rstar, double a, int numinterfaces,
+    int nbin, double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit,
+    int dir_beam, int clouds, int scat_corr, int debug, double i2s_transition);
 /* integrate_flux_double, kernels.cu:2428 / computation.py:731 (deterministic summation order) */
 int hx_integrate_flux(hx_context* ctx, const double* deltalambda, double* F_down_tot,
                       double* F_up_tot, double* F_net, const double* F_down_wg,

@@ -1155,3 +1155,229 @@ void orc_integrate_beamflux(double* F_dir_tot, const double* F_dir_band, const d
         F_dir_tot[i] = s;
     }
 }
+
+/* ============================================================================================
+ * Flux solve as one tridiagonal system (Thomas algorithm)      source/kernels.cu:1803-2424
+ * Optional method of the reference (`flux calculation method = matrix`).  Unknowns, non-isothermal:
+ * x = [F_dn[0], F_up[0], Fc_dn[0], Fc_up[0], F_dn[1], ...], n = 4*ninterface - 2; isothermal:
+ * x = [F_dn[0], F_up[0], F_dn[1], ...], n = 2*ninterface.  Spectral points whose
+ * scat_trigger is 0 take a pure-absorption sweep instead.
+ * ============================================================================================ */
+static void thomas_solve(int n, double albedo, double src_boa, double src_toa, const double* alpha,
+                         const double* beta, const double* s_down, const double* s_up, size_t stride,
+                         double* c_prime, double* d_prime) {
+    /* rows: 0 = BOA; odd r = 2j+1: down equation of slab j; even r = 2j+2: up equation of slab j;
+     * n-1 = TOA.  The sub-diagonal of a row equals the super-diagonal of the previous one. */
+    double b = -albedo, c = 1.0, d = src_boa;
+    c_prime[0] = c / b;
+    d_prime[0] = d / b;
+    for (int i = 1; i < n - 1; i++) {
+        const double c_prev = c;
+        if (i % 2 == 0) {
+            const size_t j = (size_t)(i / 2 - 1) * stride;
+            b = -beta[j];
+            c = 1.0;
+            d = s_up[j];
+        } else {
+            const size_t j = (size_t)((i - 1) / 2) * stride;
+            b = -beta[j];
+            c = -alpha[j];
+            d = s_down[j];
+        }
+        const double den = b - c_prev * c_prime[(size_t)(i - 1) * stride];
+        c_prime[(size_t)i * stride] = c / den;
+        d_prime[(size_t)i * stride] = (d - c_prev * d_prime[(size_t)(i - 1) * stride]) / den;
+    }
+    d_prime[(size_t)(n - 1) * stride] = (src_toa - c * d_prime[(size_t)(n - 2) * stride]) /
+                                        (0.0 - c * c_prime[(size_t)(n - 2) * stride]);
+}
+
+void orc_fband_matrix_iso(double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
+                          const double* planckband_lay, const double* w_0, const double* M_term,
+                          const double* N_term, const double* P_term, const double* G_plus,
+                          const double* G_minus, const double* g_0_tot_lay, double* alpha, double* beta,
+                          double* source_term_down, double* source_term_up, double* c_prime,
+                          double* d_prime, const int* scat_trigger, const double* trans_wg,
+                          const double* surf_albedo, double g_0, double Rstar, double a, int ninterface,
+                          int nbin, double f_factor, double mu_star, int ny, double epsi, int dir_beam,
+                          int clouds, int scat_corr, double i2s_transition) {
+    const size_t sl = (size_t)ny * nbin;
+    const int nl = ninterface - 1, npl = nl + 2;
+#pragma omp parallel for
+    for (int x = 0; x < nbin; x++)
+        for (int y = 0; y < ny; y++) {
+            const size_t c = (size_t)y + (size_t)ny * x;
+            const double* B = planckband_lay + (size_t)x * npl;
+            const double src_toa = (1.0 - dir_beam) * f_factor * ((Rstar / a) * (Rstar / a)) * PI * B[nl];
+            if (scat_trigger[c] == 1) {
+                double E = 1.0, g0 = g_0; /* both persist across layers exactly as in the reference */
+                for (int j = 0; j < nl; j++) {
+                    const size_t k = c + sl * j;
+                    const double M = M_term[k], N = N_term[k], P = P_term[k], w0 = w_0[k];
+                    const double Gm = G_minus[k], Gp = G_plus[k];
+                    if (clouds == 1) g0 = g_0_tot_lay[x + (size_t)nbin * j];
+                    if (scat_corr == 1) E = E_param(w0, g0, i2s_transition);
+                    alpha[k] = P / M;
+                    beta[k] = -N / M;
+                    const double planck = 2.0 * PI * epsi * (1.0 - w0) / (E - w0) * (N + M - P) * B[j];
+                    double dd = F_dir_wg[k] / (-mu_star) * (Gm * M + Gp * N) - F_dir_wg[k + sl] / (-mu_star) * P * Gm;
+                    double du = F_dir_wg[k + sl] / (-mu_star) * (Gm * N + Gp * M) - F_dir_wg[k] / (-mu_star) * P * Gp;
+                    dd = dmin(0.0, dd);
+                    du = dmin(0.0, du);
+                    source_term_down[k] = 1.0 / M * (planck + dd);
+                    source_term_up[k] = 1.0 / M * (planck + du);
+                }
+                const double w0 = w_0[c];
+                if (clouds == 1) g0 = g_0_tot_lay[x];
+                if (scat_corr == 1) E = E_param(w0, g0, i2s_transition);
+                const double src_boa = surf_albedo[x] * F_dir_wg[c] +
+                                       (1.0 - surf_albedo[x]) * PI * (1.0 - w0) / (E - w0) * B[ninterface];
+                const int n = 2 * ninterface;
+                thomas_solve(n, surf_albedo[x], src_boa, src_toa, alpha + c, beta + c, source_term_down + c,
+                             source_term_up + c, sl, c_prime + c, d_prime + c);
+                double xi = d_prime[c + sl * (n - 1)];
+                F_up_wg[c + sl * ((n - 2) / 2)] = xi;
+                for (int i = n - 2; i >= 0; i--) {
+                    xi = d_prime[c + sl * i] - c_prime[c + sl * i] * xi;
+                    if (i % 2 == 0)
+                        F_down_wg[c + sl * (i / 2)] = xi;
+                    else
+                        F_up_wg[c + sl * ((i - 1) / 2)] = xi;
+                }
+            } else {
+                F_down_wg[c + sl * nl] = src_toa;
+                for (int i = nl - 1; i >= 0; i--) {
+                    const double t = trans_wg[c + sl * i];
+                    F_down_wg[c + sl * i] =
+                        tiny_abs(t * F_down_wg[c + sl * (i + 1)] + 2.0 * PI * epsi * (1.0 - t) * B[i]);
+                }
+                F_up_wg[c] = surf_albedo[x] * (F_dir_wg[c] + F_down_wg[c]) + (1.0 - surf_albedo[x]) * PI * B[ninterface];
+                for (int i = 1; i < ninterface; i++) {
+                    const double t = trans_wg[c + sl * (i - 1)];
+                    F_up_wg[c + sl * i] =
+                        tiny_abs(t * F_up_wg[c + sl * (i - 1)] + 2.0 * PI * epsi * (1.0 - t) * B[i - 1]);
+                }
+            }
+        }
+}
+
+void orc_fband_matrix_noniso(
+    double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg, const double* F_dir_wg,
+    const double* Fc_dir_wg, const double* planckband_lay, const double* planckband_int,
+    const double* w_0_upper, const double* w_0_lower, const double* delta_tau_wg_upper,
+    const double* delta_tau_wg_lower, const double* delta_tau_all_clouds_upper,
+    const double* delta_tau_all_clouds_lower, const double* M_upper, const double* M_lower,
+    const double* N_upper, const double* N_lower, const double* P_upper, const double* P_lower,
+    const double* G_plus_upper, const double* G_plus_lower, const double* G_minus_upper,
+    const double* G_minus_lower, const double* g_0_tot_lay, const double* g_0_tot_int, double* alpha,
+    double* beta, double* source_term_down, double* source_term_up, double* c_prime, double* d_prime,
+    const int* scat_trigger, const double* trans_wg_upper, const double* trans_wg_lower,
+    const double* surf_albedo, double g_0, double Rstar, double a, int ninterface, int nbin,
+    double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit, int dir_beam, int clouds,
+    int scat_corr, double i2s_transition) {
+    const size_t sl = (size_t)ny * nbin;
+    const int nl = ninterface - 1, npl = nl + 2;
+#pragma omp parallel for
+    for (int x = 0; x < nbin; x++)
+        for (int y = 0; y < ny; y++) {
+            const size_t c = (size_t)y + (size_t)ny * x;
+            const double* Bl = planckband_lay + (size_t)x * npl;
+            const double* Bi = planckband_int + (size_t)x * ninterface;
+            const double src_toa = (1.0 - dir_beam) * f_factor * ((Rstar / a) * (Rstar / a)) * PI * Bl[nl];
+            if (scat_trigger[c] == 1) {
+                double E = 1.0, g0 = g_0;
+                for (int j = 0; j < 2 * nl; j++) { /* slab j: even = lower half of layer j/2, odd = upper half */
+                    const int i = j / 2;
+                    const int lower = (j % 2 == 0);
+                    const size_t k = c + sl * i, b = x + (size_t)nbin * i;
+                    double M, N, P, w0, Gm, Gp, dtau, pd, pu, dd, du;
+                    if (lower) {
+                        M = M_lower[k]; N = N_lower[k]; P = P_lower[k]; w0 = w_0_lower[k];
+                        Gm = G_minus_lower[k]; Gp = G_plus_lower[k];
+                        dtau = delta_tau_wg_lower[k] + delta_tau_all_clouds_lower[b];
+                        if (clouds == 1) g0 = (g_0_tot_int[b] + g_0_tot_lay[b]) / 2.0;
+                    } else {
+                        M = M_upper[k]; N = N_upper[k]; P = P_upper[k]; w0 = w_0_upper[k];
+                        Gm = G_minus_upper[k]; Gp = G_plus_upper[k];
+                        dtau = delta_tau_wg_upper[k] + delta_tau_all_clouds_upper[b];
+                        if (clouds == 1) g0 = (g_0_tot_int[b + nbin] + g_0_tot_lay[b]) / 2.0;
+                    }
+                    if (scat_corr == 1) E = E_param(w0, g0, i2s_transition);
+                    /* B_bot / B_top: Planck function at the bottom / top node of the slab */
+                    const double B_bot = lower ? Bi[i] : Bl[i], B_top = lower ? Bl[i] : Bi[i + 1];
+                    if (dtau < delta_tau_limit) {
+                        pu = lower ? (N + M - P) * (Bi[i] + Bl[i]) / 2.0 : (N + M - P) * (Bl[i] + Bi[i + 1]) / 2.0;
+                        pd = pu;
+                    } else {
+                        const double pgrad = (B_bot - B_top) / dtau;
+                        pd = (M + N) * B_bot - P * B_top + epsi / (E * (1.0 - w0 * g0)) * (P - M + N) * pgrad;
+                        pu = (M + N) * B_top - P * B_bot + epsi / (E * (1.0 - w0 * g0)) * (M - N - P) * pgrad;
+                    }
+                    const double F_bot = lower ? F_dir_wg[k] : Fc_dir_wg[k];
+                    const double F_top = lower ? Fc_dir_wg[k] : F_dir_wg[k + sl];
+                    dd = F_bot / (-mu_star) * (Gm * M + Gp * N) - F_top / (-mu_star) * P * Gm;
+                    du = F_top / (-mu_star) * (Gm * N + Gp * M) - F_bot / (-mu_star) * P * Gp;
+                    dd = dmin(0.0, dd);
+                    du = dmin(0.0, du);
+                    const size_t kj = c + sl * j;
+                    alpha[kj] = P / M;
+                    beta[kj] = -N / M;
+                    source_term_down[kj] = 1.0 / M * (2.0 * PI * epsi * (1.0 - w0) / (E - w0) * pd + dd);
+                    source_term_up[kj] = 1.0 / M * (2.0 * PI * epsi * (1.0 - w0) / (E - w0) * pu + du);
+                }
+                const double w0 = w_0_lower[c];
+                if (clouds == 1) g0 = (g_0_tot_int[x] + g_0_tot_lay[x]) / 2.0;
+                if (scat_corr == 1) E = E_param(w0, g0, i2s_transition);
+                const double src_boa = surf_albedo[x] * F_dir_wg[c] +
+                                       (1.0 - surf_albedo[x]) * PI * (1.0 - w0) / (E - w0) * Bl[ninterface];
+                const int n = 4 * ninterface - 2;
+                thomas_solve(n, surf_albedo[x], src_boa, src_toa, alpha + c, beta + c, source_term_down + c,
+                             source_term_up + c, sl, c_prime + c, d_prime + c);
+                double xi = d_prime[c + sl * (n - 1)];
+                F_up_wg[c + sl * (ninterface - 1)] = xi;
+                for (int i = n - 2; i >= 0; i--) {
+                    xi = d_prime[c + sl * i] - c_prime[c + sl * i] * xi;
+                    if (xi < 1e-100) xi = fabs(xi);
+                    switch (i % 4) {
+                        case 0: F_down_wg[c + sl * (i / 4)] = xi; break;
+                        case 1: F_up_wg[c + sl * ((i - 1) / 4)] = xi; break;
+                        case 2: Fc_down_wg[c + sl * ((i - 2) / 4)] = xi; break;
+                        default: Fc_up_wg[c + sl * ((i - 3) / 4)] = xi; break;
+                    }
+                }
+            } else {
+                /* pure absorption, SURVEY.md 10.3 last paragraph (kernels.cu:2286-2421) */
+                F_down_wg[c + sl * nl] = src_toa;
+                for (int i = nl - 1; i >= 0; i--) {
+                    const size_t k = c + sl * i, b = x + (size_t)nbin * i;
+                    const double tu = trans_wg_upper[k], tl = trans_wg_lower[k];
+                    const double du_ = delta_tau_wg_upper[k] + delta_tau_all_clouds_upper[b];
+                    const double dl_ = delta_tau_wg_lower[k] + delta_tau_all_clouds_lower[b];
+                    double pt;
+                    if (du_ < delta_tau_limit) pt = (Bi[i + 1] + Bl[i]) / 2.0 * (1.0 - tu);
+                    else pt = Bl[i] - tu * Bi[i + 1] + epsi * (tu - 1.0) * ((Bl[i] - Bi[i + 1]) / du_);
+                    Fc_down_wg[k] = tiny_abs(tu * F_down_wg[k + sl] + 2.0 * PI * epsi * pt);
+                    if (dl_ < delta_tau_limit) pt = (Bi[i] + Bl[i]) / 2.0 * (1.0 - tl);
+                    else pt = Bi[i] - tl * Bl[i] + epsi * (tl - 1.0) * ((Bi[i] - Bl[i]) / dl_);
+                    F_down_wg[k] = tiny_abs(tl * Fc_down_wg[k] + 2.0 * PI * epsi * pt);
+                }
+                F_up_wg[c] = surf_albedo[x] * (F_dir_wg[c] + F_down_wg[c]) + (1.0 - surf_albedo[x]) * PI * Bl[ninterface];
+                for (int i = 1; i < ninterface; i++) {
+                    const size_t k = c + sl * (i - 1), b = x + (size_t)nbin * (i - 1);
+                    const double tu = trans_wg_upper[k], tl = trans_wg_lower[k];
+                    const double du_ = delta_tau_wg_upper[k] + delta_tau_all_clouds_upper[b];
+                    const double dl_ = delta_tau_wg_lower[k] + delta_tau_all_clouds_lower[b];
+                    double pt;
+                    if (dl_ < delta_tau_limit) pt = (Bi[i - 1] + Bl[i - 1]) / 2.0 * (1.0 - tl);
+                    else pt = Bl[i - 1] - tl * Bi[i - 1] + epsi * ((Bi[i - 1] - Bl[i - 1]) / dl_) * (1.0 - tl);
+                    Fc_up_wg[k] = tl * F_up_wg[k] + 2.0 * PI * epsi * pt;
+                    /* the reference patches entry i, not i-1 (:2394); at i = nlayer that is past the end
+                     * of the array, so the restatement stops one short */
+                    if (i < nl) Fc_up_wg[k + sl] = tiny_abs(Fc_up_wg[k + sl]);
+                    if (du_ < delta_tau_limit) pt = (Bi[i] + Bl[i - 1]) / 2.0 * (1.0 - tu);
+                    else pt = Bi[i] - tu * Bl[i - 1] + epsi * ((Bl[i - 1] - Bi[i]) / du_) * (1.0 - tu);
+                    F_up_wg[k + sl] = tiny_abs(tu * Fc_up_wg[k] + 2.0 * PI * epsi * pt);
+                }
+            }
+        }
+}

@@ -123,6 +123,31 @@ void orc_fband_noniso(double* F_down_wg, double* F_up_wg, double* Fc_down_wg, do
                       double epsi, double delta_tau_limit, int dir_beam, int clouds, int scat_corr,
                       double i2s_transition);
 
+/* matrix (Thomas) form of the flux solve, source/kernels.cu:1803-2424 */
+void orc_fband_matrix_iso(double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
+                          const double* planckband_lay, const double* w_0, const double* M_term,
+                          const double* N_term, const double* P_term, const double* G_plus,
+                          const double* G_minus, const double* g_0_tot_lay, double* alpha, double* beta,
+                          double* source_term_down, double* source_term_up, double* c_prime,
+                          double* d_prime, const int* scat_trigger, const double* trans_wg,
+                          const double* surf_albedo, double g_0, double Rstar, double a, int ninterface,
+                          int nbin, double f_factor, double mu_star, int ny, double epsi, int dir_beam,
+                          int clouds, int scat_corr, double i2s_transition);
+void orc_fband_matrix_noniso(
+    double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg, const double* F_dir_wg,
+    const double* Fc_dir_wg, const double* planckband_lay, const double* planckband_int,
+    const double* w_0_upper, const double* w_0_lower, const double* delta_tau_wg_upper,
+    const double* delta_tau_wg_lower, const double* delta_tau_all_clouds_upper,
+    const double* delta_tau_all_clouds_lower, const double* M_upper, const double* M_lower,
+    const double* N_upper, const double* N_lower, const double* P_upper, const double* P_lower,
+    const double* G_plus_upper, const double* G_plus_lower, const double* G_minus_upper,
+    const double* G_minus_lower, const double* g_0_tot_lay, const double* g_0_tot_int, double* alpha,
+    double* beta, double* source_term_down, double* source_term_up, double* c_prime, double* d_prime,
+    const int* scat_trigger, const double* trans_wg_upper, const double* trans_wg_lower,
+    const double* surf_albedo, double g_0, double Rstar, double a, int ninterface, int nbin,
+    double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit, int dir_beam, int clouds,
+    int scat_corr, double i2s_transition);
+
 void orc_integrate_flux(const double* deltalambda, double* F_down_tot, double* F_up_tot,
                         double* F_net, const double* F_down_wg, const double* F_up_wg,
                         const double* F_dir_wg, double* F_down_band, double* F_up_band,

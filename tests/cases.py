@@ -235,6 +235,40 @@ def flux_sweeps(impl, c, s, nsweep=None):
                 c.delta_tau_limit, c.dir_beam, c.clouds, c.scat_corr, c.i2s_transition)
 
 
+def matrix_scratch(c):
+    """work arrays of the matrix method (source/quantities.py: dev_alpha ... dev_d_prime)"""
+    n = c.ny * c.nbin
+    H = c.nlayer if c.iso == 1 else 2 * c.nlayer
+    rows = 2 * c.ninterface if c.iso == 1 else 4 * c.ninterface - 2
+    return dict(alpha=np.zeros(n * H), beta=np.zeros(n * H), source_term_down=np.zeros(n * H),
+                source_term_up=np.zeros(n * H), c_prime=np.zeros(n * rows), d_prime=np.zeros(n * rows))
+
+
+def flux_matrix(impl, c, s, m=None):
+    """source/computation.py:625-710: the tridiagonal form of the flux solve (one call, no sweeps)"""
+    X, Y, I = c.nbin, c.ny, c.ninterface
+    m = matrix_scratch(c) if m is None else m
+    if c.iso == 1:
+        impl.fband_matrix_iso(s.F_down_wg, s.F_up_wg, s.F_dir_wg, s.planckband_lay, s.w_0, s.M_term,
+                              s.N_term, s.P_term, s.G_plus, s.G_minus, s.g_0_tot_lay, m["alpha"],
+                              m["beta"], m["source_term_down"], m["source_term_up"], m["c_prime"],
+                              m["d_prime"], s.scat_trigger, s.trans_wg, c.surf_albedo, c.g_0, c.R_star,
+                              c.a, I, X, c.f_factor, c.mu_star, Y, c.epsi, c.dir_beam, c.clouds,
+                              c.scat_corr, c.i2s_transition)
+    else:
+        impl.fband_matrix_noniso(
+            s.F_down_wg, s.F_up_wg, s.Fc_down_wg, s.Fc_up_wg, s.F_dir_wg, s.Fc_dir_wg,
+            s.planckband_lay, s.planckband_int, s.w_0_upper, s.w_0_lower, s.delta_tau_wg_upper,
+            s.delta_tau_wg_lower, s.delta_tau_all_clouds_upper, s.delta_tau_all_clouds_lower,
+            s.M_upper, s.M_lower, s.N_upper, s.N_lower, s.P_upper, s.P_lower, s.G_plus_upper,
+            s.G_plus_lower, s.G_minus_upper, s.G_minus_lower, s.g_0_tot_lay, s.g_0_tot_int, m["alpha"],
+            m["beta"], m["source_term_down"], m["source_term_up"], m["c_prime"], m["d_prime"],
+            s.scat_trigger, s.trans_wg_upper, s.trans_wg_lower, c.surf_albedo, c.g_0, c.R_star, c.a, I,
+            X, c.f_factor, c.mu_star, Y, c.epsi, c.delta_tau_limit, c.dir_beam, c.clouds, c.scat_corr,
+            c.i2s_transition)
+    return m
+
+
 def integrate_and_step(impl, c, s, itervalue, step_temperature=True):
     X, Y, L, I = c.nbin, c.ny, c.nlayer, c.ninterface
     impl.integrate_flux(c.opac_deltawave, s.F_down_tot, s.F_up_tot, s.F_net, s.F_down_wg, s.F_up_wg,

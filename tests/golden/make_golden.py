@@ -151,9 +151,44 @@ def mixing_fixture():
     np.savez_compressed(os.path.join(HERE, "mixing.npz"), **data)
 
 
+MATRIX_NAMES = ["default", "dirbeam_albedo", "clouds_g0_i2s", "iso_clouds", "thin_top"]
+
+
+def matrix_state(name):
+    """inputs of the tridiagonal flux solve = the coefficient planes of chain_<name>.npz after iteration 1"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_checks as gc
+    c, z = gc.load_chain(name)
+    s = cases.alloc_state(c)
+    for k in z.files:
+        if k.startswith("it1.") and k[4:] in s and k[4:] not in ("F_down_wg", "F_up_wg", "Fc_down_wg", "Fc_up_wg"):
+            s[k[4:]][...] = z[k]
+    c.surf_albedo = np.maximum(c.surf_albedo, 1e-8)     # reader's lower bound for this method (read.py:1261)
+    if name == "default":
+        s.scat_trigger[::2] = 0                          # half of the points through the pure-absorption branch
+    return c, s
+
+
+def matrix_fixture():
+    ref = RefImpl()
+    data = {"meta": meta()}
+    for name in MATRIX_NAMES:
+        c, s = matrix_state(name)
+        m = cases.flux_matrix(ref, c, s)
+        for k in ("F_down_wg", "F_up_wg") + (("Fc_down_wg", "Fc_up_wg") if c.iso == 0 else ()):
+            data["%s.%s" % (name, k)] = s[k].copy()
+        for k, v in m.items():
+            data["%s.%s" % (name, k)] = v.copy()
+    np.savez_compressed(os.path.join(HERE, "matrix.npz"), **data)
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["matrix"]:
+        matrix_fixture()
+        sys.exit(0)
     for name, cfg in CHAIN_CONFIGS.items():
         chain_fixture(name, cfg)
     mixing_fixture()
+    matrix_fixture()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("wrote fixtures, %.1f KB total" % (tot / 1024.0))

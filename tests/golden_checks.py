@@ -107,3 +107,25 @@ def check_mixing(impl, rtol=1e-11):
     tot = h2o * 0.3
     impl.add_to_mixed_scat(z["sc.vmr"], h2o, tot, nbin, nlev)
     _close(tot, z["sc.total"], rtol, name="scat total")
+
+
+MATRIX_NAMES = ["default", "dirbeam_albedo", "clouds_g0_i2s", "iso_clouds", "thin_top"]
+
+
+def check_matrix(impl, name, rtol=1e-11):
+    """fband_matrix_* on the golden coefficient planes of chain_<name> (same inputs as the generator)"""
+    z = np.load(os.path.join(GOLDEN, "matrix.npz"))
+    c, zc = load_chain(name)
+    s = cases.alloc_state(c)
+    for k in zc.files:
+        if k.startswith("it1.") and k[4:] in s and k[4:] not in ("F_down_wg", "F_up_wg", "Fc_down_wg", "Fc_up_wg"):
+            s[k[4:]][...] = zc[k]
+    c.surf_albedo = np.maximum(c.surf_albedo, 1e-8)
+    if name == "default":
+        s.scat_trigger[::2] = 0
+    m = cases.flux_matrix(impl, c, s)
+    for k in ("alpha", "beta", "source_term_down", "source_term_up", "c_prime", "d_prime"):
+        _close(m[k], z["%s.%s" % (name, k)], rtol=rtol, name=k)
+    for k in ("F_down_wg", "F_up_wg") + (("Fc_down_wg", "Fc_up_wg") if c.iso == 0 else ()):
+        want = z["%s.%s" % (name, k)]
+        _close(s[k], want, rtol=rtol, atol=1e-14 * np.abs(want).max(), name=k)

@@ -66,6 +66,18 @@ class RefImpl(object):
         a.insert(len(a) - 1, 0)                              # debug
         self.r.fband_noniso(*a)
 
+    def fband_matrix_iso(self, *a):
+        a = list(a)
+        a.insert(21, 0)                                      # singlewalk after g_0
+        a.insert(len(a) - 1, 0)                              # debug
+        self.r.fband_matrix_iso(*a)
+
+    def fband_matrix_noniso(self, *a):
+        a = list(a)
+        a.insert(37, 0)                                      # singlewalk after g_0
+        a.insert(len(a) - 1, 0)                              # debug
+        self.r.fband_matrix_noniso(*a)
+
     def rad_temp_iter(self, F_down_tot, F_up_tot, F_net, F_net_diff, T_lay, p_lay, p_int, abrt,
                       T_store, pref, F_add_lay, F_add_sum, F_smooth, F_smooth_sum, c_p, mmm,
                       itervalue, foreplay, g, nlayer, physical_tstep, local_limit, adapt, smooth,

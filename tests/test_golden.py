@@ -16,3 +16,8 @@ def test_oracle_mixing_golden(port):
 
 def test_all_fixtures_present():
     assert len(gc.CHAIN_NAMES) == 9
+
+
+@pytest.mark.parametrize("name", gc.MATRIX_NAMES)
+def test_oracle_matrix_golden(port, name):
+    gc.check_matrix(port, name)

@@ -76,3 +76,17 @@ def test_run_helios_with_convection(tmp_path):
     hs.conv_check(q)
     assert q.conv_unstable.sum() == 0
     assert np.all(np.isfinite(q.T_lay)) and q.F_up_band.min() >= 0
+
+
+def test_run_helios_matrix_method(tmp_path):
+    """`flux calculation method = matrix` (per-stage path): same equilibrium as the iterative sweeps, whose
+    persistent up-flux state converges to the solution of the same linear system"""
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
+            "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "mat",
+            "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
+            "-convective_adjustment", "no", "-surface_albedo", "0.1"]
+    a = _run_driver(argv + ["-flux_calculation_method", "matrix"], True)
+    b = _run_driver(argv, True)
+    assert np.all(np.isfinite(a.T_lay)) and int(a.iter_value) > 3
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=5e-3)
+    np.testing.assert_allclose(a.F_up_band[-int(a.nbin):].sum(), b.F_up_band[-int(b.nbin):].sum(), rtol=5e-3)

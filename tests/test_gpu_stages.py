@@ -56,6 +56,34 @@ def test_stage_chain_vs_oracle(hip, port, cfg):
     np.testing.assert_allclose(ch.T_lay, cp.T_lay, rtol=1e-8)
 
 
+@pytest.mark.parametrize("name", gc.MATRIX_NAMES)
+def test_matrix_flux_solve_golden(hip, name):
+    # inputs are the golden coefficient planes, the solve is +,-,*,/ only: same bits expected
+    gc.check_matrix(hip, name, rtol=1e-12)
+
+
+@pytest.mark.parametrize("cfg", [dict(nbin=41, nlayer=30, albedo=0.1), dict(nbin=25, nlayer=60, clouds=1, g_0=0.2,
+                                                                           scat_corr=1, dir_beam=1, albedo=0.3),
+                                 dict(nbin=19, nlayer=21, iso=1, dir_beam=1, albedo=1e-8)])
+def test_matrix_flux_solve_vs_oracle(hip, port, cfg):
+    c0 = cases.make_case(**cfg)
+    out = []
+    for impl in (hip, port):
+        c = c0.copy()
+        s = cases.alloc_state(c)
+        cases.setup_planck(port, c, s)
+        cases.interpolate_temperatures_and_planck(port, c, s)
+        cases.refresh_premixed(port, c, s)
+        s.scat_trigger[::3] = 0
+        m = cases.flux_matrix(impl, c, s)
+        out.append((s, m))
+    (sh, mh), (sp, mp) = out
+    for k in mp:
+        np.testing.assert_allclose(mh[k], mp[k], rtol=1e-12, atol=1e-300, err_msg=k)
+    for k in ("F_down_wg", "F_up_wg") + (("Fc_down_wg", "Fc_up_wg") if c0.iso == 0 else ()):
+        np.testing.assert_allclose(sh[k], sp[k], rtol=1e-12, atol=1e-14 * np.abs(sp[k]).max(), err_msg=k)
+
+
 def test_post_loop_diagnostics_vs_oracle(hip, port):
     c0 = cases.make_case(clouds=1, g_0=0.2, nbin=21, nlayer=11)
     res = []

@@ -95,3 +95,46 @@ def test_long_run_adaptive_timestep(port, ref):
     _close(sp.T_store, sr.T_store, rtol=1e-9, name="T_store")
     _close(sp.deltat_prefactor, sr.deltat_prefactor, rtol=1e-12, name="prefactor")
     _close(sp.F_up_band, sr.F_up_band, rtol=1e-9, name="F_up_band")
+
+
+MATRIX_CONFIGS = ["default", "noscat", "dirbeam", "clouds_g0", "iso", "iso_clouds", "thin_top", "ny1"]
+
+
+@pytest.mark.parametrize("name", MATRIX_CONFIGS)
+def test_matrix_flux_solve(port, ref, name):
+    """the optional tridiagonal solve (kernels.cu:1803-2424) on identical coefficient planes"""
+    c0 = cases.make_case(**CONFIGS[name])
+    c0.surf_albedo = np.maximum(c0.surf_albedo, 1e-8)   # the reader's lower bound "for matrix method to work" (read.py:1261)
+    out = []
+    for impl in (port, ref):
+        c = c0.copy()
+        s = cases.alloc_state(c)
+        cases.setup_planck(ref, c, s)
+        cases.interpolate_temperatures_and_planck(ref, c, s)
+        cases.refresh_premixed(ref, c, s)
+        if name == "default":            # exercise both branches: half of the points without scattering
+            s.scat_trigger[::2] = 0
+        m = cases.flux_matrix(impl, c, s)
+        out.append((s, m))
+    (sp, mp), (sr, mr) = out
+    for k in ("alpha", "beta", "source_term_down", "source_term_up"):
+        _close(mp[k], mr[k], name=k)
+    # the elimination amplifies ulp differences of the sources a little (no pivoting in either)
+    for k in ("c_prime", "d_prime"):
+        _close(mp[k], mr[k], rtol=1e-11, name=k)
+    keys = ["F_down_wg", "F_up_wg"] + (["Fc_down_wg", "Fc_up_wg"] if c0.iso == 0 else [])
+    for k in keys:
+        scale = np.abs(sr[k]).max()
+        _close(sp[k], sr[k], rtol=1e-10, atol=1e-14 * scale, name=k)
+    # and the matrix solution is the fixed point of the sweeps: compare with many sweeps of the oracle
+    if CONFIGS[name].get("scat", 1) == 1 and name != "default":
+        c = c0.copy()
+        s = cases.alloc_state(c)
+        cases.setup_planck(port, c, s)
+        cases.interpolate_temperatures_and_planck(port, c, s)
+        cases.refresh_premixed(port, c, s)
+        cases.flux_sweeps(port, c, s, nsweep=3000)
+        for k in ("F_down_wg", "F_up_wg"):
+            scale = np.abs(s[k]).max()
+            assert np.isfinite(sp[k]).all()
+            np.testing.assert_allclose(sp[k], s[k], rtol=1e-5, atol=1e-6 * scale, err_msg="fixed point " + k)
