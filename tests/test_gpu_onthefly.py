@@ -88,5 +88,8 @@ def test_run_helios_matrix_method(tmp_path):
     a = _run_driver(argv + ["-flux_calculation_method", "matrix"], True)
     b = _run_driver(argv, True)
     assert np.all(np.isfinite(a.T_lay)) and int(a.iter_value) > 3
-    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=5e-3)
+    # both stop at the same flux criterion from different sides; the thin top layer and the surface are the
+    # loosest-constrained temperatures (observed: 0.5 % there, 1e-5 in the bulk)
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-2)
+    np.testing.assert_allclose(a.T_lay[3:-1], b.T_lay[3:-1], rtol=1e-4)
     np.testing.assert_allclose(a.F_up_band[-int(a.nbin):].sum(), b.F_up_band[-int(b.nbin):].sum(), rtol=5e-3)
