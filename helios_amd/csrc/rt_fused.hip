@@ -204,14 +204,32 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                        rt->ctx->stream, f);
 }
-template <int ROWS>
-void launch_coef(hx_rt* rt, const KArgs& a) {
+template <int ROWS, int TPB>
+void launch_coef_tpb(hx_rt* rt, KArgs a) {
     const TileGeom& g = rt->g;
     const int ntiles = g.nblk_x * g.nparts * g.NW;
-    const int TS = COEF_TPB * g.S;
-    const size_t shmem = 2 * ((size_t)rt->L * TS + (size_t)rt->I * TS) * sizeof(double) + 2 * TS * sizeof(int);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<ROWS>), dim3((ntiles + COEF_TPB - 1) / COEF_TPB, rt->C),
-                       dim3(64 * COEF_TPB), shmem, rt->ctx->stream, a);
+    const int TS = TPB * g.S, TSP = TS + rt->coef_pad;
+    const int NBX = g.nxb * ((TPB - 1) / (g.NW * g.nparts) + 2);
+    a.coef_pad = rt->coef_pad;
+    a.coef_nbx = NBX;
+    a.coef_debug = getenv("HELIOS_RT_COEF_DEBUG") ? atoi(getenv("HELIOS_RT_COEF_DEBUG")) : 0;
+    const size_t shmem = ((size_t)(rt->L + rt->I) * TSP + (size_t)rt->H * (NBX + 2)) * sizeof(double) + 2 * TS * sizeof(int);
+    if (shmem > 64 * 1024 && !rt->coef_shmem_raised) {
+        (void)hipFuncSetAttribute((const void*)k_rt_coef<ROWS, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)shmem);
+        rt->coef_shmem_raised = true;
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_coef<ROWS, TPB>), dim3((ntiles + TPB - 1) / TPB, rt->C), dim3(64 * TPB),
+                       shmem, rt->ctx->stream, a);
+}
+template <int ROWS>
+void launch_coef(hx_rt* rt, const KArgs& a) {
+    switch (rt->coef_tpb) {
+        case 1: launch_coef_tpb<ROWS, 1>(rt, a); break;
+        case 2: launch_coef_tpb<ROWS, 2>(rt, a); break;
+        case 8: launch_coef_tpb<ROWS, 8>(rt, a); break;
+        default: launch_coef_tpb<ROWS, 4>(rt, a); break;
+    }
 }
 
 #define DISPATCH_ROWS(fn, rt, a)                  \
@@ -284,6 +302,9 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
                        "fused path supports nlayer <= 512; use the per-stage API");
     }
     rt->nchunk = std::max(1, std::min(512, (rt->X + 31) / 32));
+    if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
+    if (const char* e = getenv("HELIOS_RT_COEF_PAD")) rt->coef_pad = atoi(e);
+    if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
     int rc = set_flux_shmem_limits(rt);
     if (rc) { delete rt; return rc; }

@@ -21,7 +21,7 @@ namespace hx {
 
 struct KArgs {
     int X, Y, L, I, H, C;
-    int k, LPL, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk;
+    int k, LPL, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk, coef_pad, coef_debug, coef_nbx;
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
     int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
     double Kconst;             // 2 pi eps: source prefactor when E == 1 (scat_corr == 0)
@@ -211,9 +211,7 @@ __device__ __forceinline__ LaneMap lane_map(const Args& a, int bx, int part) {
 // one tile are only 64/k doubles apart per level: the workgroup first stages the opacities of ALL its
 // tiles' spectral points (consecutive in memory when a tile row holds one bin) for every level into
 // LDS with >= 128-byte contiguous reads, then every lane builds the coefficients of its half-layers.
-constexpr int COEF_TPB = 4;
-
-template <int ROWS>
+template <int ROWS, int COEF_TPB>
 __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = blockIdx.y;
@@ -221,18 +219,22 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ntiles = a.nblk_x * a.nparts * a.NW;
     const int TS = COEF_TPB * a.S;                  // spectral points staged per workgroup
-    double* sh_lay = smem;                          // [L][TS]  opacity at layer centres
-    double* sh_int = sh_lay + (size_t)a.L * TS;     // [I][TS]  opacity at interfaces
-    double* sh_scl = sh_int + (size_t)a.I * TS;     // [L][TS]  Rayleigh cross-section (per bin, replicated)
-    double* sh_sci = sh_scl + (size_t)a.L * TS;     // [I][TS]
-    int* c_of_q = (int*)(sh_sci + (size_t)a.I * TS);  // [TS] global spectral-point index or -1
+    const int TSP = TS + a.coef_pad;                // row pitch of the staged opacities
+    const int NBX = a.coef_nbx;                     // bins this workgroup's tiles can touch (upper bound)
+    double* sh_lay = smem;                          // [L][TSP]  opacity at layer centres
+    double* sh_int = sh_lay + (size_t)a.L * TSP;    // [I][TSP]  opacity at interfaces
+    double* sh_ray = sh_int + (size_t)a.I * TSP;    // [H][NBX]  Rayleigh cross-section of the half-layers
+    double* sh_mu = sh_ray + (size_t)a.H * NBX;     // [H]       mean molecular mass of the half-layers
+    double* sh_dc = sh_mu + a.H;                    // [H]       column mass of the half-layers
+    int* c_of_q = (int*)(sh_dc + a.H);              // [TS] global spectral-point index or -1
     int* x_of_q = c_of_q + TS;
     const size_t nc = (size_t)a.Y * a.X;
     const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
+    const int x_base = (blockIdx.x * COEF_TPB) / (a.NW * a.nparts) * a.nxb;  // first bin of the first tile
     // spectral points of this workgroup's tiles
     for (int q = threadIdx.x; q < TS; q += blockDim.x) {
         const int tl = blockIdx.x * COEF_TPB + q / a.S, s_in_wave = q % a.S;
-        int c = -1, xq = 0;
+        int c = -1, xq = x_base;
         if (tl < ntiles) {
             const int wv = tl % a.NW, part = (tl / a.NW) % a.nparts, bx = tl / (a.NW * a.nparts);
             const int s_local = wv * a.S + s_in_wave;
@@ -243,10 +245,33 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
         c_of_q[q] = c;
         x_of_q[q] = xq;
     }
+    // per-level quantities of the half-layers.  Lower half h = 2i averages (interface i, centre i),
+    // upper half h = 2i+1 (centre i, interface i+1); the sums are commutative, so one form serves both.
+    {
+        const double* mml = a.mmm_lay + (size_t)col * a.I;
+        const double* mmi = a.mmm_int + (size_t)col * a.I;
+        const double* dcu = a.dcol_u + (size_t)col * a.L;
+        const double* dcl = a.dcol_l + (size_t)col * a.L;
+        for (int h = threadIdx.x; h < a.H; h += blockDim.x) {
+            const int i = h >> 1, ii = i + (h & 1);
+            sh_mu[h] = (mmi[ii] + mml[i]) / 2.0;
+            sh_dc[h] = (h & 1) ? dcu[i] : dcl[i];
+        }
+        const double* scl_g = a.scat_cross_lay + col * bandI;
+        const double* sci_g = a.scat_cross_int + col * bandI;
+        for (int t = threadIdx.x; t < a.H * NBX; t += blockDim.x) {
+            const int h = t / NBX, xs = t - h * NBX, x = min(x_base + xs, a.X - 1);
+            const int i = h >> 1, ii = i + (h & 1);
+            sh_ray[t] = a.scat == 1 ? (sci_g[x + (size_t)a.X * ii] + scl_g[x + (size_t)a.X * i]) / 2.0 : 0.0;
+        }
+    }
     __syncthreads();
     {
-        const double* opl = a.opac_wg_lay + col * wgI;
-        const double* opi = a.opac_wg_int + col * wgI;
+        // thread -> (staged point q0, a run of consecutive levels): consecutive levels mostly fall into
+        // the same (T, P) cell of the table, whose four corners then stay in registers.  TS divides the
+        // workgroup size (both are powers of two).
+        const int q0 = threadIdx.x % TS, nrun = blockDim.x / TS, run = threadIdx.x / TS;
+        const int cq = a.coef_debug == 2 ? -1 : c_of_q[q0];
         if (a.from_table) {
             // premixed k-table look-up done while staging (kernels.cu:561-608): the opacity arrays of
             // the reference are not materialised on this path (hx_rt_get rebuilds them on demand)
@@ -255,52 +280,44 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 const int nlev = pass == 0 ? a.L : a.I;
                 const TPIndex* tp = (pass == 0 ? a.tp_lay : a.tp_int) + (size_t)col * a.I;
                 double* dst = pass == 0 ? sh_lay : sh_int;
-                for (int idx = threadIdx.x; idx < nlev * TS; idx += blockDim.x) {
-                    const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
+                const int per = (nlev + nrun - 1) / nrun;
+                const int l0 = run * per, l1 = min(nlev, l0 + per);
+                int ktd = -1, ktu = -1, kpd = -1, kpu = -1;
+                double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+                for (int lev = l0; lev < l1; lev++) {
                     double v = 0.0;
-                    if (c >= 0) {
+                    if (cq >= 0) {
                         const TPIndex k = tp[lev];
-                        const double* t0 = a.ktable + (size_t)c + st * k.tdown;
-                        const double* t1 = a.ktable + (size_t)c + st * k.tup;
-                        v = blend_tp(t0[sp * k.pdown], t0[sp * k.pup], t1[sp * k.pdown], t1[sp * k.pup], k, false);
+                        if (k.tdown != ktd || k.tup != ktu || k.pdown != kpd || k.pup != kpu) {
+                            const double* t0 = a.ktable + (size_t)cq + st * k.tdown;
+                            const double* t1 = a.ktable + (size_t)cq + st * k.tup;
+                            c00 = t0[sp * k.pdown];
+                            c01 = t0[sp * k.pup];
+                            c10 = t1[sp * k.pdown];
+                            c11 = t1[sp * k.pup];
+                            ktd = k.tdown; ktu = k.tup; kpd = k.pdown; kpu = k.pup;
+                        }
+                        v = blend_tp(c00, c01, c10, c11, k, false);
                     }
-                    dst[idx] = v;
+                    dst[(size_t)lev * TSP + q0] = v;
                 }
             }
         } else {
-            for (int idx = threadIdx.x; idx < a.L * TS; idx += blockDim.x) {
-                const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
-                sh_lay[idx] = c >= 0 ? opl[(size_t)c + nc * lev] : 0.0;
-            }
-            for (int idx = threadIdx.x; idx < a.I * TS; idx += blockDim.x) {
-                const int lev = idx / TS, q = idx - lev * TS, c = c_of_q[q];
-                sh_int[idx] = c >= 0 ? opi[(size_t)c + nc * lev] : 0.0;
-            }
-        }
-        if (a.scat == 1) {
-            const double* scl_g = a.scat_cross_lay + col * bandI;
-            const double* sci_g = a.scat_cross_int + col * bandI;
-            for (int idx = threadIdx.x; idx < a.L * TS; idx += blockDim.x) {
-                const int lev = idx / TS, q = idx - lev * TS;
-                sh_scl[idx] = scl_g[x_of_q[q] + (size_t)a.X * lev];
-            }
-            for (int idx = threadIdx.x; idx < a.I * TS; idx += blockDim.x) {
-                const int lev = idx / TS, q = idx - lev * TS;
-                sh_sci[idx] = sci_g[x_of_q[q] + (size_t)a.X * lev];
-            }
+            const double* opl = a.opac_wg_lay + col * wgI;
+            const double* opi = a.opac_wg_int + col * wgI;
+            for (int lev = run; lev < a.L; lev += nrun)
+                sh_lay[(size_t)lev * TSP + q0] = cq >= 0 ? opl[(size_t)cq + nc * lev] : 0.0;
+            for (int lev = run; lev < a.I; lev += nrun)
+                sh_int[(size_t)lev * TSP + q0] = cq >= 0 ? opi[(size_t)cq + nc * lev] : 0.0;
         }
     }
     __syncthreads();
     const int tl = blockIdx.x * COEF_TPB + wave;
-    if (tl >= ntiles) return;
+    if (tl >= ntiles || a.coef_debug == 1) return;
     const int j = lane % a.k, q = wave * a.S + lane / a.k;
-    const int c = c_of_q[q], x = x_of_q[q];
+    const int c = c_of_q[q], x = x_of_q[q], xs = x - x_base;
     const bool valid = c >= 0;
     const hx_rt_column cp = a.colpar[col];
-    const double* mml = a.mmm_lay + (size_t)col * a.I;
-    const double* mmi = a.mmm_int + (size_t)col * a.I;
-    const double* dcu = a.dcol_u + (size_t)col * a.L;
-    const double* dcl = a.dcol_l + (size_t)col * a.L;
     double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64;
     const double nmu = -cp.mu_star;
     for (int r = 0; r < ROWS; r++) {
@@ -322,18 +339,16 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 cab = lower ? (ai[b_i] + al[b_l]) / 2.0 : (al[b_l] + ai[b_i]) / 2.0;
             }
             if (a.scat == 1) {
-                const double r_l = sh_scl[(size_t)i * TS + q], r_i = sh_sci[(size_t)ii * TS + q];
-                ray = lower ? (r_i + r_l) / 2.0 : (r_l + r_i) / 2.0;
+                ray = sh_ray[(size_t)h * NBX + xs];
                 if (a.clouds == 1) {
                     const double* sl = a.cl_sc_lay + col * bandI;
                     const double* si = a.cl_sc_int + col * bandI;
                     csc = lower ? (si[b_i] + sl[b_l]) / 2.0 : (sl[b_l] + si[b_i]) / 2.0;
                 }
             }
-            const double o_l = sh_lay[(size_t)i * TS + q], o_i = sh_int[(size_t)ii * TS + q];
+            const double o_l = sh_lay[(size_t)i * TSP + q], o_i = sh_int[(size_t)ii * TSP + q];
             const double kap = lower ? (o_i + o_l) / 2.0 : (o_l + o_i) / 2.0;
-            const double mu = lower ? (mmi[ii] + mml[i]) / 2.0 : (mml[i] + mmi[ii]) / 2.0;
-            const double dcol = lower ? dcl[i] : dcu[i];
+            const double mu = sh_mu[h], dcol = sh_dc[h];
             const double w0 = single_scat_albedo(ray + csc, kap * mu + cab, a.w_0_limit);
             const double dtau_gas = dcol * (kap + ray / mu);
             const double dtau = dtau_gas + dcol * (cab + csc) / mu;
@@ -600,11 +615,20 @@ __global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
     for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
         const int dir = t / I, i = t - dir * I;
         const double* __restrict__ band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
+        // loads issued eight bins at a time (the loop is latency-bound otherwise); summed in bin order
         double acc = 0.0;
-        if (dir == 0)
-            for (int x = x0; x < x1; x++) acc += (fdir[(size_t)x * I + i] + band[(size_t)x * I + i]) * dl[x];
-        else
-            for (int x = x0; x < x1; x++) acc += band[(size_t)x * I + i] * dl[x];
+        for (int xb = x0; xb < x1; xb += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {  // branch-free so that all 16 loads are in flight together
+                const int x = min(xb + u, x1 - 1);
+                const double f = fdir[(size_t)x * I + i], b = band[(size_t)x * I + i];
+                v[u] = dir == 0 ? f + b : b;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (xb + u < x1) acc += v[u] * dl[xb + u];
+        }
         a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
     }
 }
@@ -632,8 +656,17 @@ __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
         const int t = t0 + (threadIdx.x & 255), sgm = threadIdx.x >> 8;
         const int cper = (a.nchunk + 3) / 4, c0 = sgm * cper, c1 = min(a.nchunk, c0 + cper);
         double s = 0.0;
-        if (t < 2 * I)
-            for (int c = c0; c < c1; c++) s += a.tot_part[(((size_t)col * a.nchunk + c) * 2) * I + t];
+        if (t < 2 * I) {
+            const double* __restrict__ part = a.tot_part + ((size_t)col * a.nchunk * 2) * I + t;
+            for (int cb = c0; cb < c1; cb += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = part[(size_t)min(cb + u, c1 - 1) * 2 * I];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (cb + u < c1) s += v[u];
+            }
+        }
         seg[sgm][threadIdx.x & 255] = s;
         __syncthreads();
         if (sgm == 0 && t < 2 * I) {

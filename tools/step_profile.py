@@ -1,0 +1,52 @@
+"""Per-kernel HIP-event averages of one fused iteration (tuning aid).
+
+    python tools/step_profile.py [--workload c2] [--steps 9]
+
+Prints the average duration of every profiled scope of hx_rt_step over `steps` E-iterations (no refresh)
+and of one refresh.  Environment knobs of rt_fused.hip (HELIOS_RT_*) apply."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--steps", type=int, default=9)
+    ap.add_argument("--columns", type=int, default=1)
+    args = ap.parse_args()
+    import bench
+    from helios_amd.device import Context
+    w = bench.WORKLOADS[args.workload]
+    c = bench.build_case(w, 20242)
+    ctx = Context(0)
+    rt = bench.make_batch(ctx, c, args.columns)
+    rt.build_planck_table(1)
+    rt.run(0, 11)
+    ctx.synchronize()
+    rt.profile(True)
+    rt.run(11, min(args.steps, 9))
+    rt.profile(False)
+    out = []
+    for k in ("rt_nodes", "rt_flux", "rt_totals_a", "rt_totals_b"):
+        ms, n = rt.profile_read(k)
+        out.append("%s %.1f us (n=%d)" % (k, ms * 1e3, n))
+    ctx.timer_start()
+    rt.run(21, 9)
+    ev = ctx.timer_stop_ms() / 9
+    rt.profile(True)
+    rt.refresh()
+    rt.profile(False)
+    for k in ("refresh_total", "opac_interpol", "rt_coef", "add_to_mixed_opac", "opac_species_interpol"):
+        ms, n = rt.profile_read(k)
+        if n:
+            out.append("%s %.1f us (n=%d)" % (k, ms * 1e3, n))
+    print("step(no refresh) %.1f us | " % (ev * 1e3) + " | ".join(out))
+    rt.close()
+
+
+if __name__ == "__main__":
+    main()
