@@ -346,6 +346,15 @@ def convective_adjustment(quant):
     conv_correct(quant, fudging=1)
 
 
+def sum_mean_optdepth(quant, i, opac):
+    """optical depth from the TOA down to layer i with a mean opacity; layers flagged -3 ("temperature too
+    low for the table") are skipped, and -3 is returned when nothing could be summed (host_functions.py:321-334)"""
+    opac = np.asarray(opac[i:int(quant.nlayer)], float)
+    ok = opac != -3
+    tau = float(np.sum(np.asarray(quant.delta_colmass[i:int(quant.nlayer)], float)[ok][::-1] * opac[ok][::-1]))
+    return tau if tau > 0 else -3
+
+
 def calculate_conv_flux(quant):
     """convective net flux at the interfaces (host_functions.py:638-651)"""
     L = int(quant.nlayer)

@@ -112,6 +112,9 @@ class _Cloud(object):
             if len(np.atleast_1d(getattr(quant, stem + "_lay"))) != n_l:
                 setattr(quant, stem + "_lay", np.zeros(n_l))
                 setattr(quant, stem + "_int", np.zeros(n_i))
+        for name, n in (("f_all_clouds_lay", int(quant.nlayer)), ("f_all_clouds_int", int(quant.ninterface))):
+            if getattr(quant, name, None) is None or len(np.atleast_1d(getattr(quant, name))) != n:
+                setattr(quant, name, np.zeros(n))         # total cloud mixing ratio (clouds.py:231-232)
 
 
 class Read(object):

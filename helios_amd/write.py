@@ -1,29 +1,155 @@
-"""Output writers for the files parity is judged on: `_tp.dat`, `_integrated_flux.dat`,
-`_spec_upflux.dat`, `_spec_downflux.dat`, `_TOA_flux_eclipse.dat`, plus the abort marker.
+"""Output writers: the fixed-width text files a HELIOS run leaves in `<output>/<name>/`.
 
-Counterpart of the reference's `Write` (source/write.py:114-340).  The column layouts ({:g} = 6
-significant digits, {:<16.8e} for the spectra) are the file FORMAT that downstream tools
-parse (source/tools.py:297, :397), so they are reproduced exactly; numerical parity is checked on the
-in-memory arrays, never on these text files.
+Counterpart of the reference's `Write` (source/write.py:63-714, call order helios.py:96-126).  The file
+names, title lines and column layouts ({:g} = 6 significant digits; {:<16.8e} for the fluxes; SURVEY.md
+Q17) are the FORMAT downstream tools parse (source/tools.py:297, :397), so they are reproduced exactly.
+They are data-driven here: three file shapes (per-bin table, per-layer table, free text) described by
+small specs instead of one hand-written loop per file.  Numerical parity is checked on the in-memory
+arrays, never on these text files.
 """
 import os
+import shutil
 
 from . import host_functions as hsfunc
+from . import phys_const as pc
+
+_BIN_HEAD = ("bin", "cent_lambda[um]", "low_int_lambda[um]", "delta_lambda[um]")
+
+# per-bin tables: suffix -> (title, 4th-header width, column label, label width, levels, cell format,
+#                            value(quant, x, i)); `levels` is a Store attribute name or a callable
+_BAND_FILES = {
+    "_spec_upflux.dat": (
+        "This file contains the upward spectral flux (per wavelength) at each interface. "
+        "\nSpectral fluxes given in [erg s^-1 cm^-3].",
+        19, "F_up[", 5, "ninterface", "{:<16.8e}", lambda q, x, i: q.F_up_band[x + i * q.nbin]),
+    "_spec_downflux.dat": (
+        "This file contains the downward spectral flux (per wavelength) at each interface. "
+        "\nSpectral fluxes given in [erg s^-1 cm^-3].",
+        19, "F_down[", 7, "ninterface", "{:<16.8e}", lambda q, x, i: q.F_down_band[x + i * q.nbin]),
+    "_direct_beamflux.dat": (
+        "This file contains the direct irradiation flux (per wavelength) at each interface. "
+        "\nSpectral fluxes given in [erg s^-1 cm^-3].",
+        18, "F_dir[", 6, "ninterface", "{:<16.8e}", lambda q, x, i: q.F_dir_band[x + i * q.nbin]),
+    "_planck_int.dat": (
+        "This file contains the Planck (blackbody) function at each interface. "
+        "\nPlanck function given in [erg s^-1 cm^-3 sr^-1].",
+        19, "B_int[", 6, "ninterface", "{:<16g}", lambda q, x, i: q.planckband_int[i + x * q.ninterface]),
+    "_opacities.dat": (
+        "This file contains the bin integrated opacities at each layer center "
+        "\nOpacity given in [cm^2 g^-1].",
+        19, "opac_lay[", 9, "nlayer", "{:<15g}", lambda q, x, i: q.opac_band_lay[x + q.nbin * i]),
+    "_cloud_opacities.dat": (
+        "This file contains the cloud opacities at each layer center "
+        "\nOpacity given in [cm^2 g^-1].",
+        19, "cloud_opac[", 11, "nlayer", "{:<17g}",
+        lambda q, x, i: q.abs_cross_all_clouds_lay[x + q.nbin * i] / q.meanmolmass_lay[i]),
+    "_Rayleigh_cross_sect.dat": (
+        "This file contains Rayleigh scattering cross sections per wavelength at each layer center. "
+        "\nCross sections given in [cm^2].",
+        19, "scat_cross_sect_lay[", 20, "nlayer", "{:<24g}", lambda q, x, i: q.scat_cross_lay[x + q.nbin * i]),
+    "_cloud_scat_cross_sect.dat": (
+        "This file contains the cloud scattering cross sections per wavelength at each layer center. "
+        "\nCross sections given in [cm^2].",
+        19, "cloud_cross_sect_lay[", 21, "nlayer", "{:<25g}",
+        lambda q, x, i: q.scat_cross_all_clouds_lay[x + q.nbin * i]),
+    "_g_0.dat": (
+        "This file contains the scattering asymmetry parameter values per wavelength at each layer center."
+        "\nValues are between -1 and 1.",
+        19, "g_0_lay[", 8, "nlayer", "{:<16g}", lambda q, x, i: q.g_0_tot_lay[x + q.nbin * i]),
+    "_transmission.dat": (
+        "This file contains the transmission function for each layer and waveband.",
+        19, "transm_lay[", 11, "nlayer", "{:<18g}", lambda q, x, i: q.trans_band[x + i * q.nbin]),
+    "_optdepth.dat": (
+        "This file contains the optical depth for each layer and waveband.",
+        19, "delta_tau_lay[", 14, "nlayer", "{:<20g}", lambda q, x, i: q.delta_tau_band[x + i * q.nbin]),
+    "_cloud_optdepth.dat": (
+        "This file contains the cloud optical depth for each layer and waveband.",
+        19, "cloud_delta_tau[", 16, "nlayer", "{:<22g}", lambda q, x, i: q.delta_tau_all_clouds[x + i * q.nbin]),
+    "_contribution.dat": (
+        "This file contains the contribution function for each layer and waveband.",
+        19, "contr_func_lay[", 15, "nlayer", "{:<22g}", lambda q, x, i: q.contr_func_band[x + i * q.nbin]),
+    "_transweight.dat": (
+        "This file contains the transmission weighting function for each layer and waveband. "
+        "The units are [erg s^-1 cm^-3 sr^-1]",
+        19, "transm_weight_lay[", 18, "nlayer", "{:<25g}", lambda q, x, i: q.trans_weight_band[x + i * q.nbin]),
+}
+
+
+def _or_not_calculated(value, width):
+    return ("{:<%ds}" % width).format("not_calculated") if value == 0 else ("{:<%dg}" % width).format(value)
+
+
+def _mean_or_flag(value):
+    """-3 marks a mean opacity that could not be evaluated (write.py:54-60)"""
+    return "{:<20}".format("temp_too_low") if value == -3 else "{:<20g}".format(value)
 
 
 class Write(object):
 
+    # ---- plumbing -----------------------------------------------------------------------------------
     @staticmethod
-    def _path(quant, read, suffix):
+    def _dir(quant, read):
         d = os.path.join(read.output_path, str(quant.name))
         os.makedirs(d, exist_ok=True)
-        return os.path.join(d, str(quant.name) + suffix)
+        return d
 
+    @staticmethod
+    def _path(quant, read, suffix):
+        return os.path.join(Write._dir(quant, read), str(quant.name) + suffix)
+
+    @staticmethod
+    def _bin_prefix(quant, x):
+        return "\n{:<8g}{:<18.9g}{:<21.9g}{:<19.9g}".format(
+            x, quant.opac_wave[x] * 1e4, quant.opac_interwave[x] * 1e4, quant.opac_deltawave[x] * 1e4)
+
+    @staticmethod
+    def _band_file(quant, read, suffix):
+        """one row per wavelength bin: bin geometry, then one cell per level"""
+        title, w4, label, lw, levels, cell, value = _BAND_FILES[suffix]
+        nlev = int(getattr(quant, levels))
+        X = int(quant.nbin)
+        with open(Write._path(quant, read, suffix), "w", encoding="utf-8") as f:
+            f.write(title)
+            f.write(("\n{:<8}{:<18}{:21}{:%d}" % w4).format(*_BIN_HEAD))
+            for i in range(nlev):
+                f.write(("{:<%d}{:g}{:<4}" % lw).format(label, i, "]"))
+            for x in range(X):
+                f.write(Write._bin_prefix(quant, x))
+                f.write("".join(cell.format(value(quant, x, i)) for i in range(nlev)))
+
+    @staticmethod
+    def convert_1_0_to_yes_no(variable):
+        return "yes" if variable == 1 else "no"
+
+    @staticmethod
+    def write_physical_timestep(variable):
+        return "no" if variable == 0 else "{:g}".format(variable)
+
+    # ---- markers ------------------------------------------------------------------------------------
     @staticmethod
     def write_abort_file(quant, read):
         with open(Write._path(quant, read, "_ABORT.dat"), "w") as f:
             f.write("Run exceeded the maximum number of iteration steps (%d)." % int(quant.max_nr_iterations))
 
+    @staticmethod
+    def write_criterion_warning_file(quant, read):
+        """only when the driver had to relax the convergence criterion (computation.py:950-975)"""
+        if getattr(quant, "relaxed_criterion_trigger", 0) != 1:
+            return
+        with open(Write._path(quant, read, "_convergence_warning.dat"), "w") as f:
+            f.write("WARNING: Due to exceeding runtime the convergence criterion has been made more loose over time.\n")
+            f.write("The final relative criterion used is: {:.1e} \n".format(quant.rad_convergence_limit))
+            f.write("Even with a looser (not loser) criterion, the model results may still be accurate enough. "
+                    "Use at your own discretion!")
+
+    @staticmethod
+    def create_output_dir_and_copy_param_file(read, quant):
+        d = Write._dir(quant, read)
+        src = getattr(read, "param_file", None)
+        if src and os.path.isfile(src):
+            shutil.copyfile(src, os.path.join(d, str(quant.name) + "_" + os.path.basename(src)))
+
+    # ---- per-layer tables ---------------------------------------------------------------------------
     @staticmethod
     def write_tp(quant, read):
         T_bright = hsfunc.temp_calcs(quant)[4]
@@ -51,6 +177,57 @@ class Write(object):
                     f.write("{:<30}{:<32}".format("not_calculated", "not_calculated"))
 
     @staticmethod
+    def write_tp_cut(quant, read):
+        """the profile below 1e-6 bar (p_lay > 0.099 dyn cm^-2 as written in the reference)"""
+        L = int(quant.nlayer)
+        with open(Write._path(quant, read, "_tp_cut.dat"), "w") as f:
+            f.write("This file contains the corresponding layer temperatures and pressures.")
+            f.write("\n{:<8}{:<18}{:<24}".format("layer", "temp.[K]", "press.[10^-6bar]"))
+            f.write("\n{:<8}{:<18g}{:<24g}".format("BOA", quant.T_lay[L], quant.p_int[0]))
+            for i in range(L):
+                if quant.p_lay[i] > 0.099:
+                    f.write("\n{:<8g}{:<18g}{:<24g}".format(i, quant.T_lay[i], quant.p_lay[i]))
+
+    @staticmethod
+    def write_colmass_mu_cp_entropy(quant, read):
+        with open(Write._path(quant, read, "_colmass_mu_cp_kappa_entropy.dat"), "w") as f:
+            f.write("This file contains the total pressure and the column mass difference, mean molecular weight "
+                    "and specific heat capacity of each layer.")
+            f.write("\n{:<8}{:<24}{:<26}{:<21}{:<32}{:<23}{:<30}".format(
+                "layer", "cent.press.[10^-6bar]", "delta_col.mass[g cm^-2]", "mean mol. weight",
+                "spec.heat cap.[erg mol^-1 K^-1]", "adiabatic coefficient", "entropy [erg g^-1 K^-1]"))
+            for i in range(int(quant.nlayer)):
+                f.write("\n{:<8g}{:<24g}{:<26g}{:<21g}".format(
+                    i, quant.p_lay[i], quant.delta_colmass[i], quant.meanmolmass_lay[i] / pc.AMU))
+                f.write(_or_not_calculated(quant.c_p_lay[i], 32))
+                f.write(_or_not_calculated(quant.kappa_lay[i], 23))
+                f.write(_or_not_calculated(quant.entropy_lay[i], 30))
+
+    @staticmethod
+    def write_phase_state(quant, read):
+        """only for the `water_atmo` kappa format (write.py:210-233)"""
+        if str(quant.input_kappa_value) != "water_atmo":
+            return
+        with open(Write._path(quant, read, "_state.dat"), "w") as f:
+            f.write("Checks the phase state of the water atmosphere. If '1' the water in the atmosphere is vaporous "
+                    "or supercritical. If '<1' atmosphere might be unstable, i.e., water in liquid or solid form.")
+            f.write("\n{:<8}{:<18}{:<24}{:<24}".format(
+                "layer", "temp.[K]", "press.[10^-6bar]",
+                "state_of_water (0: liquid or solid, 1: vapor or supercritical)"))
+            for i in range(int(quant.nlayer)):
+                if quant.p_lay[i] > 0.99:
+                    f.write("\n{:<8g}{:<18g}{:<24g}{:<24g}".format(
+                        i, quant.T_lay[i], quant.p_lay[i], quant.phase_number_lay[i]))
+
+    @staticmethod
+    def write_cloud_mixing_ratio(quant, read):
+        with open(Write._path(quant, read, "_cloud_mixing_ratio.dat"), "w") as f:
+            f.write("This file contains the cloud volume mixing ratio (= n_cloud/n_gas) at each vertical layer.")
+            f.write("\n{:<8}{:<24}{:<18}".format("layer", "press.[10^-6bar]", "cloud_vmr"))
+            for i in range(int(quant.nlayer)):
+                f.write("\n{:<8g}{:<24g}{:<18g}".format(i, quant.p_lay[i], quant.f_all_clouds_lay[i]))
+
+    @staticmethod
     def write_integrated_flux(quant, read):
         L = int(quant.nlayer)
         with open(Write._path(quant, read, "_integrated_flux.dat"), "w") as f:
@@ -74,28 +251,107 @@ class Write(object):
                 if i == 0:
                     f.write("{:<12g}".format(quant.F_intern))
 
-    @staticmethod
-    def _spectral(quant, read, suffix, title, label, width, band):
-        X, I = int(quant.nbin), int(quant.ninterface)
-        with open(Write._path(quant, read, suffix), "w", encoding="utf-8") as f:
-            f.write("This file contains the " + title + " spectral flux (per wavelength) at each interface. "
-                    "\nSpectral fluxes given in [erg s^-1 cm^-3].")
-            f.write("\n{:<8}{:<18}{:21}{:19}".format("bin", "cent_lambda[um]", "low_int_lambda[um]", "delta_lambda[um]"))
-            for i in range(I):
-                f.write(("{:<%d}{:g}{:<4}" % width).format(label, i, "]"))
-            for x in range(X):
-                f.write("\n{:<8g}{:<18.9g}{:<21.9g}{:<19.9g}".format(
-                    x, quant.opac_wave[x] * 1e4, quant.opac_interwave[x] * 1e4, quant.opac_deltawave[x] * 1e4))
-                for i in range(I):
-                    f.write("{:<16.8e}".format(band[x + i * X]))
+    def write_mean_extinction(self, quant, read):
+        with open(Write._path(quant, read, "_mean_extinct.dat"), "w") as f:
+            f.write("This file contains the Rosseland and Planck mean opacities of layers & optical depths "
+                    "summed up to a certain layer, weighted either by the blackbody function "
+                    "with the stellar or the planetary atmospheric temperature."
+                    "\nMean opacity given in [cm^2 g^-1].")
+            f.write("\n{:<10}{:<20}{:<20}{:<20}{:<20}{:<20}{:<20}{:<20}{:<20}{:<20}".format(
+                "layer", "press.[10^-6bar]", "Planck_opac_T_lay", "Ross_opac_T_lay", "Planck_opac_T_star",
+                "Ross_opac_T_star", "Planck_tau_T_lay", "Ross_tau_T_lay", "Planck_tau_T_star", "Ross_tau_T_star"))
+            means = (quant.planck_opac_T_pl, quant.ross_opac_T_pl, quant.planck_opac_T_star, quant.ross_opac_T_star)
+            for i in range(int(quant.nlayer)):
+                f.write("\n{:<8g}{:<20g}".format(i, quant.p_lay[i]))
+                f.write("".join(_mean_or_flag(m[i]) for m in means))
+                f.write("".join(_mean_or_flag(hsfunc.sum_mean_optdepth(quant, i, m)) for m in means))
 
+    # ---- per-bin tables -----------------------------------------------------------------------------
     @staticmethod
     def write_upward_spectral_flux(quant, read):
-        Write._spectral(quant, read, "_spec_upflux.dat", "upward", "F_up[", 5, quant.F_up_band)
+        Write._band_file(quant, read, "_spec_upflux.dat")
 
     @staticmethod
     def write_downward_spectral_flux(quant, read):
-        Write._spectral(quant, read, "_spec_downflux.dat", "downward", "F_down[", 7, quant.F_down_band)
+        Write._band_file(quant, read, "_spec_downflux.dat")
+
+    @staticmethod
+    def write_direct_spectral_beam_flux(quant, read):
+        Write._band_file(quant, read, "_direct_beamflux.dat")
+
+    @staticmethod
+    def write_planck_interface(quant, read):
+        if quant.iso == 0:
+            Write._band_file(quant, read, "_planck_int.dat")
+
+    @staticmethod
+    def write_planck_center(quant, read):
+        """layer centres plus the stellar and the internal-temperature Planck columns"""
+        X, L = int(quant.nbin), int(quant.nlayer)
+        with open(Write._path(quant, read, "_planck_cent.dat"), "w") as f:
+            f.write("This file contains the Planck (blackbody) function at each layer center and "
+                    "from the stellar (2nd last column) and internal (last column) temperatures. "
+                    "\nPlanck function given in [erg s^-1 cm^-3 sr^-1].")
+            f.write("\n{:<8}{:<18}{:21}{:19}".format(*_BIN_HEAD))
+            for i in range(L):
+                f.write("{:<6}{:g}{:<4}".format("B_lay[", i, "]"))
+            f.write("{:<16}{:<16}".format("Planck_T_star", "Planck_T_intern"))
+            for x in range(X):
+                f.write(Write._bin_prefix(quant, x))
+                row = quant.planckband_lay[x * (L + 2):(x + 1) * (L + 2)]
+                f.write("".join("{:<16g}".format(v) for v in row))
+
+    @staticmethod
+    def write_opacities(quant, read):
+        Write._band_file(quant, read, "_opacities.dat")
+
+    @staticmethod
+    def write_cloud_opacities(quant, read):
+        Write._band_file(quant, read, "_cloud_opacities.dat")
+
+    @staticmethod
+    def write_Rayleigh_cross_sections(quant, read):
+        Write._band_file(quant, read, "_Rayleigh_cross_sect.dat")
+
+    @staticmethod
+    def write_cloud_scat_cross_sections(quant, read):
+        Write._band_file(quant, read, "_cloud_scat_cross_sect.dat")
+
+    @staticmethod
+    def write_g_0(quant, read):
+        Write._band_file(quant, read, "_g_0.dat")
+
+    @staticmethod
+    def write_transmission(quant, read):
+        Write._band_file(quant, read, "_transmission.dat")
+
+    @staticmethod
+    def write_opt_depth(quant, read):
+        Write._band_file(quant, read, "_optdepth.dat")
+
+    @staticmethod
+    def write_cloud_opt_depth(quant, read):
+        Write._band_file(quant, read, "_cloud_optdepth.dat")
+
+    @staticmethod
+    def write_contribution_function(quant, read):
+        Write._band_file(quant, read, "_contribution.dat")
+
+    @staticmethod
+    def write_trans_weight_function(quant, read):
+        Write._band_file(quant, read, "_transweight.dat")
+
+    @staticmethod
+    def write_surface_albedo(quant, read):
+        with open(Write._path(quant, read, "_surf_albedo.dat"), "w") as f:
+            f.write("This file contains the surface albedo per wavelength.")
+            if str(read.input_surf_albedo) == "file":
+                f.write("\nThe surface material used is: " + str(read.albedo_file_surface_name))
+            else:
+                f.write("\nA value was chosen manually, hence all the values below are constant.")
+            f.write("\n{:<8}{:<18}{:<21}{:<19}{:<16}".format(*(_BIN_HEAD + ("surface_albedo",))))
+            for x in range(int(quant.nbin)):
+                f.write(Write._bin_prefix(quant, x) + "{:<16g}".format(quant.surf_albedo[x]))
 
     @staticmethod
     def write_TOA_flux_eclipse_depth(quant, read):
@@ -105,11 +361,9 @@ class Write(object):
                     "and the secondary eclipse depth (= planet to star flux ratio)."
                     "\nSpectral fluxes given in [erg s^-1 cm^-3].")
             f.write("\n{:<8}{:<18}{:<21}{:<19}{:<16}{:<16}{:<24}".format(
-                "bin", "cent_lambda[um]", "low_int_lambda[um]", "delta_lambda[um]", "F_down_at_TOA", "F_up_at_TOA",
-                "planet/star flux ratio"))
+                *(_BIN_HEAD + ("F_down_at_TOA", "F_up_at_TOA", "planet/star flux ratio"))))
             for x in range(X):
-                f.write("\n{:<8g}{:<18.9g}{:<21.9g}{:<19.9g}".format(
-                    x, quant.opac_wave[x] * 1e4, quant.opac_interwave[x] * 1e4, quant.opac_deltawave[x] * 1e4))
+                f.write(Write._bin_prefix(quant, x))
                 f.write("{:<16g}{:<16g}".format(quant.F_down_band[x + L * X], quant.F_up_band[x + L * X]))
                 if quant.T_star > 10:
                     f.write("{:<24g}".format(quant.F_ratio[x]))
@@ -117,9 +371,27 @@ class Write(object):
                     f.write("{:<24}".format("not_avail."))
 
     @staticmethod
-    def write_all(quant, read):
-        Write.write_tp(quant, read)
-        Write.write_integrated_flux(quant, read)
-        Write.write_upward_spectral_flux(quant, read)
-        Write.write_downward_spectral_flux(quant, read)
-        Write.write_TOA_flux_eclipse_depth(quant, read)
+    def write_flux_ratio_only(quant, read):
+        """wavelength [um] and planet/star flux ratio only (e.g. for PandExo)"""
+        with open(Write._path(quant, read, "_flux_ratio.dat"), "w") as f:
+            for x in range(int(quant.nbin)):
+                f.write("{:<18.9g}".format(quant.opac_wave[x] * 1e4))
+                if quant.T_star > 10:
+                    f.write("{:<12g}\n".format(quant.F_ratio[x]))
+                else:
+                    f.write("{:<12}\n".format("not_avail."))
+
+    # ---- everything, in the reference's order (helios.py:100-126) --------------------------------------
+    def write_all(self, quant, read):
+        Write.create_output_dir_and_copy_param_file(read, quant)
+        for w in (Write.write_colmass_mu_cp_entropy, Write.write_integrated_flux,
+                  Write.write_downward_spectral_flux, Write.write_upward_spectral_flux,
+                  Write.write_TOA_flux_eclipse_depth, Write.write_direct_spectral_beam_flux,
+                  Write.write_planck_interface, Write.write_planck_center, Write.write_tp, Write.write_tp_cut,
+                  Write.write_opacities, Write.write_cloud_mixing_ratio, Write.write_cloud_opacities,
+                  Write.write_Rayleigh_cross_sections, Write.write_cloud_scat_cross_sections, Write.write_g_0,
+                  Write.write_transmission, Write.write_opt_depth, Write.write_cloud_opt_depth,
+                  Write.write_trans_weight_function, Write.write_contribution_function,
+                  self.write_mean_extinction, Write.write_flux_ratio_only, Write.write_phase_state,
+                  Write.write_surface_albedo, Write.write_criterion_warning_file):
+            w(quant, read)

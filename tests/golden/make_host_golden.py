@@ -1,0 +1,257 @@
+"""Generates golden vectors for the HOST side (pure-Python grid / convective-adjustment / bookkeeping
+functions and the text-file writers) by importing the reference's own modules in the build container.
+
+    python tests/golden/make_host_golden.py          # needs /root/reference; never runs on the GPU box
+
+The reference's `source/host_functions.py` and `source/write.py` import pycuda and astropy at module
+top; neither is installed, and none of the functions exercised here touches them.  The modules are
+therefore imported with empty stand-ins for `pycuda.*` and an `astropy.constants` object carrying the
+cgs constants of helios_amd/phys_const.py ("pure-numpy host functions can be exercised
+in this container only by pre-seeding sys.modules").  Outputs are data only:
+
+    tests/golden/host_functions.npz      inputs + results of the grid / convection / bookkeeping functions
+    tests/golden/writer/*.dat            every output file the reference writes for one small seeded state
+    tests/golden/writer/state.npz        that state
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from helios_amd import phys_const as pc  # noqa: E402
+
+
+def import_reference():
+    for name in ("pycuda", "pycuda.driver", "pycuda.autoinit", "pycuda.gpuarray", "pycuda.compiler"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pycuda.compiler"].SourceModule = object
+    sys.modules["pycuda"].driver = sys.modules["pycuda.driver"]
+    sys.modules["pycuda"].gpuarray = sys.modules["pycuda.gpuarray"]
+
+    class _Q(object):
+        def __init__(self, v):
+            self.value = v
+            self.cgs = self
+            self.esu = self
+
+    const = types.ModuleType("astropy.constants")
+    # CODATA 2018 / IAU 2015 values for the constants helios_amd/phys_const.py does not need itself
+    extra = dict(m_e=9.1093837015e-28, e=4.803204712570263e-10, M_sun=1.988409870698051e33,
+                 M_jup=1.8981245973360505e30, M_earth=5.972167867791379e27, sigma_T=6.6524587321e-25)
+    for attr, val in dict(c=pc.C, k_B=pc.K_B, h=pc.H, R=pc.R_UNIV, N_A=pc.N_A, sigma_sb=pc.SIGMA_SB, au=pc.AU,
+                          u=pc.AMU, R_sun=pc.R_SUN, R_jup=pc.R_JUP, R_earth=pc.R_EARTH, G=pc.G, **extra).items():
+        setattr(const, attr, _Q(val))
+    astropy = types.ModuleType("astropy")
+    astropy.constants = const
+    sys.modules["astropy"] = astropy
+    sys.modules["astropy.constants"] = const
+    sys.path.insert(0, REF)
+    from source import host_functions as ref_hs
+    from source import write as ref_write
+    return ref_hs, ref_write
+
+
+# ---- shared seeded states (also imported by tests/test_host_golden.py) ----------------------------------
+def grid_state(nlayer=13, p_boa=1e8, p_toa=1.0, g=2500.0):
+    q = types.SimpleNamespace()
+    q.nlayer, q.ninterface = np.int32(nlayer), np.int32(nlayer + 1)
+    q.p_boa, q.p_toa, q.g = p_boa, p_toa, g
+    q.p_lay, q.p_int, q.delta_colmass, q.delta_col_upper, q.delta_col_lower = [], [], [], [], []
+    return q
+
+
+def convection_state(seed, nlayer=24, kind="deep"):
+    """a column with a super-adiabatic region: `deep` (bottom + surface), `detached` (two zones with a hole)"""
+    rng = np.random.default_rng(seed)
+    q = grid_state(nlayer)
+    lev = [q.p_boa * (q.p_toa / q.p_boa) ** (i / (2 * nlayer - 1)) for i in range(2 * nlayer)]
+    q.p_lay = np.array(lev[1::2])
+    q.p_int = np.array(lev[0::2] + [q.p_toa * (q.p_toa / q.p_boa) ** (1 / (2 * nlayer - 1))])
+    kappa = 2.0 / 7.0
+    q.kappa_lay = np.full(nlayer, kappa) * (1 + 0.05 * rng.uniform(-1, 1, nlayer))
+    q.kappa_int = np.full(nlayer + 1, kappa) * (1 + 0.05 * rng.uniform(-1, 1, nlayer + 1))
+    q.c_p_lay = np.full(nlayer, 3.5 * pc.R_UNIV) * (1 + 0.02 * rng.uniform(-1, 1, nlayer))
+    q.meanmolmass_lay = np.full(nlayer, 2.3 * pc.AMU)
+    T = 1800.0 * (q.p_lay / q.p_lay[0]) ** 0.12                  # stable background
+    if kind == "deep":
+        T[:8] = 2600.0 * (q.p_lay[:8] / q.p_lay[0]) ** 0.45      # steep (unstable) bottom
+        T_surf = 3000.0
+    else:
+        T[2:7] = 2200.0 * (q.p_lay[2:7] / q.p_lay[2]) ** 0.5
+        T[9:13] = T[8] * (q.p_lay[9:13] / q.p_lay[8]) ** 0.42
+        T_surf = T[0] * 1.0001
+    q.T_lay = np.append(T * (1 + 0.002 * rng.uniform(-1, 1, nlayer)), T_surf)
+    q.conv_unstable = np.zeros(nlayer + 1, np.int32)
+    q.conv_layer = np.zeros(nlayer + 1, np.int32)
+    q.marked_red = np.zeros(nlayer + 1, np.int32)
+    q.F_intern = 1.0e5
+    q.input_dampara = "automatic"
+    q.T_star = 5000.0 if kind == "deep" else 0.0
+    q.F_add_heat_sum = np.zeros(nlayer)
+    q.F_smooth_sum = np.zeros(nlayer)
+    q.F_down_tot = 10.0 ** rng.uniform(5, 8, nlayer + 1)
+    q.F_up_tot = (q.F_down_tot + q.F_intern) * (1 + 0.05 * rng.uniform(-1, 1, nlayer + 1))
+    q.iter_value = 40
+    q.input_kappa_value = "0.2857"
+    q.T_surf = T_surf
+    return q
+
+
+def writer_state(seed=7, nbin=4, nlayer=5, iso=0, T_star=5000.0, convection=1):
+    """every array the writers touch, filled with seeded values of mixed magnitude"""
+    rng = np.random.default_rng(seed)
+    q = types.SimpleNamespace()
+    X, L, I = nbin, nlayer, nlayer + 1
+    q.name = "gold"
+    q.fl_prec = np.float64
+    q.nbin, q.nlayer, q.ninterface = np.int32(X), np.int32(L), np.int32(I)
+    q.iso, q.convection, q.singlewalk = np.int32(iso), np.int32(convection), np.int32(0)
+    q.T_star, q.R_star, q.a, q.R_planet = T_star, 6.96e10, 7.5e11, 7.1e9
+    q.f_factor, q.F_intern, q.T_intern = 0.25, 12345.678, 30.0
+    q.dir_beam, q.mu_star = np.int32(0), -0.5
+    q.max_nr_iterations = 1000
+    q.rad_convergence_limit, q.relaxed_criterion_trigger = 1e-7, 1
+    q.input_kappa_value = "water_atmo"
+    q.planet_type = "gas"
+    edges = 0.3e-4 * (500.0 / 0.3) ** (np.arange(X + 1) / X)
+    q.opac_interwave = edges
+    q.opac_wave = 0.5 * (edges[1:] + edges[:-1])
+    q.opac_deltawave = np.diff(edges)
+    q.p_int = 10.0 ** np.linspace(8, -0.2, I)
+    q.p_lay = np.sqrt(q.p_int[1:] * q.p_int[:-1])
+    q.T_lay = rng.uniform(300, 2500, L + 1)
+    q.z_lay = np.cumsum(rng.uniform(1e5, 5e6, L))
+    q.delta_z_lay = rng.uniform(1e5, 5e6, L)
+    q.conv_unstable = rng.integers(0, 2, L + 1).astype(np.int32)
+    q.conv_layer = rng.integers(0, 2, L + 1).astype(np.int32)
+    q.delta_colmass = rng.uniform(1e-3, 1e3, L)
+    q.meanmolmass_lay = rng.uniform(2, 30, L) * pc.AMU
+    q.c_p_lay = rng.uniform(1e8, 4e8, L)
+    q.c_p_lay[1] = 0
+    q.kappa_lay = rng.uniform(0.1, 0.4, L)
+    q.kappa_lay[2] = 0
+    q.entropy_lay = np.zeros(L)
+    q.entropy_lay[0] = 3.21e8
+    q.phase_number_lay = rng.integers(0, 2, L).astype(float)
+    q.f_all_clouds_lay = 10.0 ** rng.uniform(-12, -4, L)
+
+    def band(n, lo, hi):
+        return 10.0 ** rng.uniform(lo, hi, X * n)
+    for name, n, lo, hi in (("F_up_band", I, -3, 9), ("F_down_band", I, -120, 9), ("F_dir_band", I, -300, 8),
+                            ("opac_band_lay", L, -8, 4), ("abs_cross_all_clouds_lay", L, -30, -20),
+                            ("scat_cross_lay", L, -30, -22), ("scat_cross_all_clouds_lay", L, -30, -20),
+                            ("trans_band", L, -8, 0), ("delta_tau_band", L, -9, 3), ("delta_tau_all_clouds", L, -9, 1),
+                            ("contr_func_band", L, -3, 7), ("trans_weight_band", L, -3, 7)):
+        setattr(q, name, band(n, lo, hi))
+    q.g_0_tot_lay = rng.uniform(-1, 1, X * L)
+    q.planckband_int = 10.0 ** rng.uniform(-20, 8, X * I)
+    q.planckband_lay = 10.0 ** rng.uniform(-20, 8, X * (L + 2))
+    q.surf_albedo = rng.uniform(0, 1, X)
+    for name in ("F_down_tot", "F_up_tot", "F_dir_tot"):
+        setattr(q, name, 10.0 ** rng.uniform(3, 9, I))
+    q.F_net = q.F_up_tot - q.F_down_tot
+    q.F_net_diff = rng.normal(0, 1e3, L)
+    q.F_add_heat_lay = rng.uniform(0, 10, L)
+    q.F_add_heat_sum = np.cumsum(q.F_add_heat_lay)
+    q.F_smooth_sum = np.zeros(L)
+    for name in ("planck_opac_T_pl", "ross_opac_T_pl", "planck_opac_T_star", "ross_opac_T_star"):
+        v = 10.0 ** rng.uniform(-6, 2, L)
+        v[rng.integers(0, L)] = -3
+        setattr(q, name, v)
+    q.star_corr_factor = 1.0
+    q.F_ratio = []
+    return q
+
+
+def reader_stub(out_dir):
+    r = types.SimpleNamespace()
+    r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
+    r.input_surf_albedo = 0.1
+    r.albedo_file_surface_name = None
+    r.param_file = "param.dat"
+    return r
+
+
+WRITERS = ["write_colmass_mu_cp_entropy", "write_integrated_flux", "write_downward_spectral_flux",
+           "write_upward_spectral_flux", "write_TOA_flux_eclipse_depth", "write_direct_spectral_beam_flux",
+           "write_planck_interface", "write_planck_center", "write_tp", "write_tp_cut", "write_opacities",
+           "write_cloud_mixing_ratio", "write_cloud_opacities", "write_Rayleigh_cross_sections",
+           "write_cloud_scat_cross_sections", "write_g_0", "write_transmission", "write_opt_depth",
+           "write_cloud_opt_depth", "write_trans_weight_function", "write_contribution_function",
+           "write_mean_extinction", "write_flux_ratio_only", "write_phase_state", "write_surface_albedo",
+           "write_criterion_warning_file"]
+
+
+def run_writers(hs, Write, q, out_dir):
+    """the reference's output sequence (helios.py:96-126) without the parameter-file copy"""
+    r = reader_stub(out_dir)
+    os.makedirs(os.path.join(out_dir, q.name), exist_ok=True)
+    hs.calculate_conv_flux(q)
+    hs.calc_F_ratio(q)
+    w = Write()
+    for name in WRITERS:
+        getattr(w, name)(q, r)
+
+
+def main():
+    hs, ref_write = import_reference()
+    data = {}
+    # grid construction
+    for tag, kw in (("g13", dict(nlayer=13)), ("g50", dict(nlayer=50, p_boa=1e9, p_toa=1e-1, g=980.0))):
+        q = grid_state(**kw)
+        hs.construct_grid(q)
+        for k in ("p_lay", "p_int", "delta_colmass", "delta_col_upper", "delta_col_lower"):
+            data["%s.%s" % (tag, k)] = np.array(getattr(q, k))
+        data[tag + ".args"] = np.array([kw.get("nlayer"), kw.get("p_boa", 1e8), kw.get("p_toa", 1.0), kw.get("g", 2500.0)])
+    # convective adjustment: check / mark / correct chain
+    for tag, seed, kind in (("deep", 11, "deep"), ("detached", 12, "detached")):
+        q = convection_state(seed, kind=kind)
+        data["conv.%s.T_in" % tag] = q.T_lay.copy()
+        hs.conv_check(q)
+        data["conv.%s.unstable0" % tag] = q.conv_unstable.copy()
+        hs.mark_convective_layers(q, stitching=0)
+        data["conv.%s.layer0" % tag] = q.conv_layer.copy()
+        q = convection_state(seed, kind=kind)
+        hs.convective_adjustment(q)
+        data["conv.%s.T_out" % tag] = np.array(q.T_lay, float)
+        data["conv.%s.layer" % tag] = np.array(q.conv_layer)
+        data["conv.%s.unstable" % tag] = np.array(q.conv_unstable)
+    # altitude grid
+    for ptype in ("gas", "rocky"):
+        q = convection_state(3)
+        q.planet_type = ptype
+        q.delta_z_lay = np.random.default_rng(5).uniform(1e5, 4e6, int(q.nlayer))
+        q.z_lay = np.zeros(int(q.nlayer))
+        hs.calculate_height_z(q)
+        data["z.%s" % ptype] = q.z_lay.copy()
+        data["z.%s.dz" % ptype] = q.delta_z_lay.copy()
+    # bookkeeping used by the writers
+    q = writer_state()
+    hs.calculate_conv_flux(q)
+    hs.calc_F_ratio(q)
+    data["book.F_net_conv"] = np.array(q.F_net_conv)
+    data["book.F_ratio"] = np.array(q.F_ratio)
+    data["book.tau"] = np.array([[hs.sum_mean_optdepth(q, i, getattr(q, m)) for i in range(int(q.nlayer))]
+                                 for m in ("planck_opac_T_pl", "ross_opac_T_pl")], float)
+    data["book.temp_calcs"] = np.array(hs.temp_calcs(q), float)
+    np.savez_compressed(os.path.join(HERE, "host_functions.npz"), **data)
+
+    # writers: two states (non-isothermal with convection columns; isothermal, no star, no convection)
+    out = os.path.join(HERE, "writer")
+    for tag, kw in (("a", dict()), ("b", dict(seed=8, iso=1, T_star=0.0, convection=0, nbin=3, nlayer=4))):
+        q = writer_state(**kw)
+        q.name = "gold_" + tag
+        run_writers(hs, ref_write.Write, q, out)
+    n = sum(len(f) for _, _, f in os.walk(out))
+    print("wrote host_functions.npz and %d writer files" % n)
+
+
+if __name__ == "__main__":
+    main()

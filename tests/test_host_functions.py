@@ -145,7 +145,8 @@ def test_output_formats(tmp_path):
     q.F_ratio = [1e-3, 2e-3, 3e-3]
     r = Read()
     r.output_path = str(tmp_path) + "/"
-    Write.write_all(q, r)
+    for w in (Write.write_tp, Write.write_upward_spectral_flux, Write.write_TOA_flux_eclipse_depth):
+        w(q, r)          # the full set is compared byte for byte in tests/test_host_golden.py
     tp = open(os.path.join(str(tmp_path), "t", "t_tp.dat")).read().split("\n")
     assert tp[2].startswith("BOA     1100") and "not_calculated" in tp[2]
     assert tp[3].split()[:3] == ["0", "1000.12", "1e+08"]             # {:g}: 6 significant digits

@@ -1,0 +1,86 @@
+"""Host side against vectors produced by the REFERENCE's own Python (tests/golden/make_host_golden.py):
+every text file `Write` emits, byte for byte, and the grid / convective-adjustment / bookkeeping
+functions.  The seeded input states are rebuilt here by the generator's own state functions (plain numpy,
+no reference import)."""
+import filecmp
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+spec = importlib.util.spec_from_file_location("make_host_golden", os.path.join(GOLD, "make_host_golden.py"))
+mk = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(mk)
+
+from helios_amd import host_functions as hs  # noqa: E402
+from helios_amd.write import Write  # noqa: E402
+
+Z = np.load(os.path.join(GOLD, "host_functions.npz"))
+
+
+@pytest.mark.parametrize("tag,kw", [("a", dict()), ("b", dict(seed=8, iso=1, T_star=0.0, convection=0, nbin=3, nlayer=4))])
+def test_writers_byte_identical(tmp_path, tag, kw):
+    q = mk.writer_state(**kw)
+    q.name = "gold_" + tag
+    mk.run_writers(hs, Write, q, str(tmp_path))
+    want_dir = os.path.join(GOLD, "writer", q.name)
+    got_dir = os.path.join(str(tmp_path), q.name)
+    want = sorted(os.listdir(want_dir))
+    assert sorted(os.listdir(got_dir)) == want
+    for f in want:
+        if not filecmp.cmp(os.path.join(want_dir, f), os.path.join(got_dir, f), shallow=False):
+            a = open(os.path.join(want_dir, f)).read().split("\n")
+            b = open(os.path.join(got_dir, f)).read().split("\n")
+            for n, (la, lb) in enumerate(zip(a, b)):
+                assert la == lb, "%s line %d" % (f, n)
+            assert len(a) == len(b), f
+
+
+@pytest.mark.parametrize("tag,kw", [("g13", dict(nlayer=13)), ("g50", dict(nlayer=50, p_boa=1e9, p_toa=1e-1, g=980.0))])
+def test_grid_construction(tag, kw):
+    q = mk.grid_state(**kw)
+    hs.construct_grid(q)
+    for k in ("p_lay", "p_int", "delta_colmass", "delta_col_upper", "delta_col_lower"):
+        np.testing.assert_allclose(np.array(getattr(q, k)), Z["%s.%s" % (tag, k)], rtol=1e-14, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,seed", [("deep", 11), ("detached", 12)])
+def test_convective_adjustment(tag, seed):
+    q = mk.convection_state(seed, kind=tag)
+    np.testing.assert_array_equal(q.T_lay, Z["conv.%s.T_in" % tag])
+    hs.conv_check(q)
+    np.testing.assert_array_equal(q.conv_unstable, Z["conv.%s.unstable0" % tag])
+    assert q.conv_unstable.sum() > 0
+    hs.mark_convective_layers(q, stitching=0)
+    np.testing.assert_array_equal(q.conv_layer, Z["conv.%s.layer0" % tag])
+    q = mk.convection_state(seed, kind=tag)
+    hs.convective_adjustment(q)
+    np.testing.assert_array_equal(np.array(q.conv_layer), Z["conv.%s.layer" % tag])
+    np.testing.assert_array_equal(np.array(q.conv_unstable), Z["conv.%s.unstable" % tag])
+    np.testing.assert_allclose(np.array(q.T_lay, float), Z["conv.%s.T_out" % tag], rtol=1e-12)
+
+
+@pytest.mark.parametrize("ptype", ["gas", "rocky"])
+def test_altitude_grid(ptype):
+    q = mk.convection_state(3)
+    q.planet_type = ptype
+    q.delta_z_lay = Z["z.%s.dz" % ptype].copy()
+    q.z_lay = np.zeros(int(q.nlayer))
+    hs.calculate_height_z(q)
+    np.testing.assert_allclose(q.z_lay, Z["z.%s" % ptype], rtol=1e-14)
+
+
+def test_bookkeeping():
+    q = mk.writer_state()
+    hs.calculate_conv_flux(q)
+    hs.calc_F_ratio(q)
+    np.testing.assert_allclose(q.F_net_conv, Z["book.F_net_conv"], rtol=1e-15)
+    np.testing.assert_allclose(q.F_ratio, Z["book.F_ratio"], rtol=1e-15)
+    tau = np.array([[hs.sum_mean_optdepth(q, i, getattr(q, m)) for i in range(int(q.nlayer))]
+                    for m in ("planck_opac_T_pl", "ross_opac_T_pl")], float)
+    np.testing.assert_allclose(tau, Z["book.tau"], rtol=1e-14)
+    np.testing.assert_allclose(np.array(hs.temp_calcs(q), float), Z["book.temp_calcs"], rtol=1e-14)
