@@ -170,6 +170,61 @@ def writer_state(seed=7, nbin=4, nlayer=5, iso=0, T_star=5000.0, convection=1):
     return q
 
 
+def mixing_state(seed=21, nlayer=9, ntemp=6, npress=5):
+    """VMR tables on the opacity (T, log10 P) grid, a T-P profile that leaves the grid on both sides, and a
+    species list with one CIA pair and H- continuum entries (excluded from the mean molecular mass)"""
+    rng = np.random.default_rng(seed)
+    q = types.SimpleNamespace()
+    q.fl_prec = np.float64
+    q.nlayer, q.ninterface = np.int32(nlayer), np.int32(nlayer + 1)
+    q.ktemp = np.linspace(200.0, 2200.0, ntemp)
+    q.log_kpress = np.linspace(0.0, 8.0, npress)
+    q.log_p_lay = np.linspace(9.0, -1.0, nlayer)              # beyond the table at both ends
+    q.log_p_int = np.linspace(9.5, -1.5, nlayer + 1)
+    q.T_prof_lay = np.concatenate(([100.0, 200.0, 2200.0, 3000.0], rng.uniform(200, 2200, nlayer - 4)))
+    q.T_prof_int = rng.uniform(150, 2500, nlayer + 1)
+    q.species_list = []
+    for name, weight in (("H2O", 18.0153), ("CO2", 44.01), ("CIA_H2H2", 4.03), ("H-_ff", 1.0), ("He-", 4.0),
+                         ("H2", 2.016)):
+        sp = types.SimpleNamespace()
+        sp.name, sp.weight = name, weight
+        sp.vmr_pretab = 10.0 ** rng.uniform(-8, -0.3, (ntemp, npress))
+        sp.vmr_layer = 10.0 ** rng.uniform(-8, -0.3, nlayer)
+        sp.vmr_interface = 10.0 ** rng.uniform(-8, -0.3, nlayer + 1)
+        q.species_list.append(sp)
+    return q
+
+
+def radeq_state(seed, limit):
+    rng = np.random.default_rng(seed)
+    q = types.SimpleNamespace()
+    L = 12
+    q.nlayer = np.int32(L)
+    q.T_lay = rng.uniform(500, 2000, L + 1)
+    q.conv_layer = (rng.uniform(size=L + 1) < 0.3).astype(np.int32)
+    q.F_intern = 5.0e4
+    q.F_add_heat_sum = np.cumsum(rng.uniform(0, 50, L))
+    q.F_smooth_sum = np.zeros(L)
+    q.F_down_tot = 10.0 ** rng.uniform(6, 8, L + 1)
+    q.F_net = q.F_intern * (1 + 10.0 ** rng.uniform(-9, -1, L + 1) * rng.choice([-1, 1], L + 1))
+    q.rad_convergence_limit = limit
+    q.iter_value = 7
+    return q
+
+
+def start_state(dir_beam, T_star):
+    q = types.SimpleNamespace()
+    q.fl_prec = np.float64
+    q.planet = "manual"
+    q.g, q.a, q.R_planet, q.R_star, q.T_star = 3.4, 0.05, 1.2, 0.9, T_star
+    q.dir_beam, q.f_factor, q.mu_star = dir_beam, 0.25, -0.6
+    q.singlewalk, q.force_start_tp_from_file, q.physical_tstep = 0, 0, 0
+    q.nlayer = np.int32(7)
+    q.T_intern = 150.0
+    q.ny = 20
+    return q
+
+
 def reader_stub(out_dir):
     r = types.SimpleNamespace()
     r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
@@ -241,6 +296,31 @@ def main():
     data["book.tau"] = np.array([[hs.sum_mean_optdepth(q, i, getattr(q, m)) for i in range(int(q.nlayer))]
                                  for m in ("planck_opac_T_pl", "ross_opac_T_pl")], float)
     data["book.temp_calcs"] = np.array(hs.temp_calcs(q), float)
+    # on-the-fly mixing: VMR profile interpolation (scipy bilinear spline in the reference), mean molecular mass
+    q = mixing_state()
+    for n, sp in enumerate(q.species_list):
+        data["mix.vmr_lay.%d" % n] = np.array(hs.interpolate_grid_to_lay_or_int(
+            q.log_kpress, q.ktemp, sp.vmr_pretab, q.log_p_lay, q.T_prof_lay), float)
+        data["mix.vmr_int.%d" % n] = np.array(hs.interpolate_grid_to_lay_or_int(
+            q.log_kpress, q.ktemp, sp.vmr_pretab, q.log_p_int, q.T_prof_int), float)
+    data["mix.mu_lay"] = hs.calc_meanmolmass(q, type="layer")
+    data["mix.mu_int"] = hs.calc_meanmolmass(q, type="interface")
+    # local radiative-equilibrium check of the convection loop
+    for tag, seed, limit in (("tight", 31, 1e-7), ("loose", 32, 1e-2)):
+        q = radeq_state(seed, limit)
+        data["radeq.%s.criterion" % tag] = np.array(hs.check_for_radiative_eq(q))
+        data["radeq.%s.converged" % tag] = q.converged.copy()
+        data["radeq.%s.marked_red" % tag] = q.marked_red.copy()
+    # start-up: unit conversion, numerical limits, isothermal start, internal flux
+    for tag, db, ts in (("hemi", 0, 5200.0), ("beam", 1, 3000.0), ("nostar", 0, 0.0)):
+        q = start_state(db, ts)
+        hs.planet_param(q, None)
+        hs.set_up_numerical_parameters(q)
+        hs.initial_temp(q, None)
+        hs.calc_F_intern(q)
+        data["start.%s" % tag] = np.array([q.g, q.a, q.R_planet, q.R_star, q.T_star, q.w_0_limit, q.w_0_scat_limit,
+                                           q.delta_tau_limit, q.F_intern, q.T_lay[0]], float)
+        data["start.%s.gauss_weight" % tag] = np.array(q.gauss_weight)
     np.savez_compressed(os.path.join(HERE, "host_functions.npz"), **data)
 
     # writers: two states (non-isothermal with convection columns; isothermal, no star, no convection)

@@ -84,3 +84,35 @@ def test_bookkeeping():
                     for m in ("planck_opac_T_pl", "ross_opac_T_pl")], float)
     np.testing.assert_allclose(tau, Z["book.tau"], rtol=1e-14)
     np.testing.assert_allclose(np.array(hs.temp_calcs(q), float), Z["book.temp_calcs"], rtol=1e-14)
+
+
+def test_vmr_interpolation_and_mean_molecular_mass():
+    q = mk.mixing_state()
+    for n, sp in enumerate(q.species_list):
+        got = hs.interpolate_grid_to_lay_or_int(q.log_kpress, q.ktemp, sp.vmr_pretab, q.log_p_lay, q.T_prof_lay)
+        np.testing.assert_allclose(got, Z["mix.vmr_lay.%d" % n], rtol=1e-12)
+        got = hs.interpolate_grid_to_lay_or_int(q.log_kpress, q.ktemp, sp.vmr_pretab, q.log_p_int, q.T_prof_int)
+        np.testing.assert_allclose(got, Z["mix.vmr_int.%d" % n], rtol=1e-12)
+    np.testing.assert_allclose(hs.calc_meanmolmass(q, type="layer"), Z["mix.mu_lay"], rtol=1e-14)
+    np.testing.assert_allclose(hs.calc_meanmolmass(q, type="interface"), Z["mix.mu_int"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("tag,seed,limit", [("tight", 31, 1e-7), ("loose", 32, 1e-2)])
+def test_radiative_equilibrium_check(tag, seed, limit):
+    q = mk.radeq_state(seed, limit)
+    assert hs.check_for_radiative_eq(q) == int(Z["radeq.%s.criterion" % tag])
+    np.testing.assert_array_equal(q.converged, Z["radeq.%s.converged" % tag])
+    np.testing.assert_array_equal(q.marked_red, Z["radeq.%s.marked_red" % tag])
+
+
+@pytest.mark.parametrize("tag,db,ts", [("hemi", 0, 5200.0), ("beam", 1, 3000.0), ("nostar", 0, 0.0)])
+def test_start_up(tag, db, ts):
+    q = mk.start_state(db, ts)
+    hs.planet_param(q, None)
+    hs.set_up_numerical_parameters(q)
+    hs.initial_temp(q, None)
+    hs.calc_F_intern(q)
+    got = np.array([q.g, q.a, q.R_planet, q.R_star, q.T_star, q.w_0_limit, q.w_0_scat_limit, q.delta_tau_limit,
+                    q.F_intern, q.T_lay[0]], float)
+    np.testing.assert_allclose(got, Z["start.%s" % tag], rtol=1e-15)
+    np.testing.assert_allclose(np.array(q.gauss_weight), Z["start.%s.gauss_weight" % tag], rtol=1e-15)
