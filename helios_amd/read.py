@@ -40,7 +40,7 @@ _OPTIONS = [
     ("kappa value", "input_kappa_value", "kappa_value", "0.285714"),
     ("stellar spectral model", "stellar_model", "stellar_spectral_model", "blackbody"),
     ("planet", "planet", "planet", "manual"),
-    ("manual --> surface gravity [cm s^-2 or log10 (cm s^-2)]", "g", "surface_gravity", "1000"),
+    ("manual --> surface gravity [cm s^-2]", "g", "surface_gravity", "1000"),
     ("manual --> orbital distance [AU]", "a", "orbital_distance", "0.05"),
     ("manual --> radius planet [R_Jup]", "R_planet", "radius_planet", "1"),
     ("manual --> radius star [R_Sun]", "R_star", "radius_star", "1"),
@@ -144,7 +144,7 @@ class Read(object):
                 key, rest = line.split("=", 1)
                 rest = rest.split("[", 1)[0].split("(CL:", 1)[0].strip()
                 if rest:
-                    out[key.strip()] = rest
+                    out[" ".join(key.split())] = rest
         return out
 
     def read_param_file_and_command_line(self, quant, cloud=None, argv=None):
@@ -159,7 +159,7 @@ class Read(object):
         file_vals = self._parse_param_file(self.param_file)
         val = {}
         for key, attr, flag, default in _OPTIONS:
-            v = file_vals.get(key, default)
+            v = file_vals.get(" ".join(key.split()), default)
             if flag and getattr(args, flag) is not None:
                 v = getattr(args, flag)
             val[attr] = v

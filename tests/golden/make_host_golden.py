@@ -11,7 +11,7 @@ in this container only by pre-seeding sys.modules").  Outputs are data only:
 
     tests/golden/host_functions.npz      inputs + results of the grid / convection / bookkeeping functions
     tests/golden/writer/*.dat            every output file the reference writes for one small seeded state
-    tests/golden/writer/state.npz        that state
+    tests/golden/reader/parsed.json      what the reference's reader parses from reader/param_sample.dat
 """
 import os
 import sys
@@ -255,8 +255,56 @@ def run_writers(hs, Write, q, out_dir):
         getattr(w, name)(q, r)
 
 
+READER_CASES = {
+    "file_only": [],
+    "with_command_line": ["-name", "cl_run", "-number_of_layers", "42", "-scattering", "no",
+                          "-direct_irradiation_beam", "no", "-f_factor", "0.3", "-isothermal_layers", "yes",
+                          "-surface_gravity", "981", "-temperature_star", "0", "-convective_adjustment", "yes",
+                          "-flux_calculation_method", "iteration", "-planet_type", "gas", "-toa_pressure", "1e-2",
+                          "-geometric_zenith_angle_correction", "no", "-energy_budget_correction", "yes",
+                          "-radiative_equilibrium_criterion", "1e-6", "-physical_timestep", "120",
+                          "-stellar_zenith_angle", "30", "-kappa_value", "0.25"],
+    "post_processing": ["-run_type", "post-processing", "-planet_type", "no_atmosphere"],
+}
+
+
+def reader_fixture():
+    """what the reference's reader makes of tests/golden/reader/param_sample.dat (+ command-line flags)"""
+    import json
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    from source import clouds as ref_clouds
+    from source import quantities as ref_quant
+    from source import read as ref_read
+    # the reference rewrites ./source/kernels.cu for the chosen precision at this point; the reference tree is
+    # read-only here and nothing else of that step is needed
+    ref_read.Read.set_prec_in_cudafile = lambda self, quant: None
+    out = {}
+    sample = os.path.join(HERE, "reader", "param_sample.dat")
+    for case, flags in READER_CASES.items():
+        argv0 = sys.argv
+        sys.argv = ["helios.py", "-parameter_file", sample] + flags
+        try:
+            k, r, c = ref_quant.Store(), ref_read.Read(), ref_clouds.Cloud()
+            r.read_param_file_and_command_line(k, c)
+        finally:
+            sys.argv = argv0
+        rec = {}
+        for prefix, obj in (("quant.", k), ("read.", r)):
+            for a, v in vars(obj).items():
+                if a == "param_file" or v is None:
+                    continue
+                if isinstance(v, (str, int, float, np.integer, np.floating)):
+                    rec[prefix + a] = v if isinstance(v, str) else float(v)
+                elif isinstance(v, list) and v and all(isinstance(e, (int, float, np.integer, np.floating)) for e in v):
+                    rec[prefix + a] = [float(e) for e in v]
+        out[case] = dict(flags=flags, parsed=rec)
+    with open(os.path.join(HERE, "reader", "parsed.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     hs, ref_write = import_reference()
+    reader_fixture()
     data = {}
     # grid construction
     for tag, kw in (("g13", dict(nlayer=13)), ("g50", dict(nlayer=50, p_boa=1e9, p_toa=1e-1, g=980.0))):
