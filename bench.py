@@ -32,6 +32,9 @@ WORKLOADS = {
                desc="BASELINE config 1 shape: 300 bins x 50 layers, premixed"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
                desc="BASELINE config 3: on-the-fly mixing, 20 species random overlap, 10 000 bins x 100 layers"),
+    "c5": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, clouds=2, albedo=0.1, scat_corr=1,
+               desc="BASELINE config 5 shape, one column: 30 000 bins x 200 layers, non-iso scattering (I2S "
+                    "correction), two cloud decks, surface albedo; premixed table (the mixing cost is config 3's)"),
     "c3small": dict(nbin=1000, nlayer=100, ny=20, ntemp=12, npress=10, nspecies=20,
                     desc="config 3 shape at 1000 bins (quick check)"),
 }
@@ -73,6 +76,13 @@ def build_case(w, seed):
     c.surf_albedo = np.zeros(c.nbin)
     c.starflux = np.zeros(c.nbin)
     c.c_p_lay = np.full(c.nlayer, 3.5 * pc.R_UNIV)
+    if w.get("albedo"):
+        c.surf_albedo = np.full(c.nbin, float(w["albedo"]))
+    if w.get("scat_corr"):
+        c.scat_corr, c.g_0 = 1, 0.1
+    if w.get("clouds"):
+        c.clouds = 1            # two synthetic decks (bases at 0.1 bar and 1 mbar), SURVEY.md 8(d) config 5
+        c.update(syn.cloud_arrays(c.nbin, c.nlayer, c.opac_wave, np.asarray(c.p_lay), np.asarray(c.p_int), rng))
     c.species = None
     if w.get("nspecies"):
         # absorbers with molar weights U(2,64) and constant VMRs log-uniform in

@@ -31,6 +31,8 @@ FUSED_CONFIGS = {
     "L50": dict(nbin=21, nlayer=50, clouds=1),  # k=8, two bins per workgroup
     "L200": dict(nbin=7, nlayer=200, dir_beam=1),  # k=32, two Gauss-point partials per bin
     "L33_ny16": dict(nbin=9, nlayer=33, ny=16),
+    "L400": dict(nbin=5, nlayer=400, clouds=1, g_0=0.1),   # k=64: one spectral point per wavefront, >64 KiB LDS in k_rt_coef
+    "L200_i2s": dict(nbin=6, nlayer=200, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),  # config-5 flags: 4 planes + clouds
 }
 
 
