@@ -18,6 +18,7 @@ import numpy as np
 from . import host_functions as hsfunc
 from . import phys_const as pc
 from . import synthetic as syn
+from .clouds import Cloud
 
 # (param.dat key, attribute, command-line flag, default) for the options that reach the hot path
 _OPTIONS = [
@@ -46,6 +47,16 @@ _OPTIONS = [
     ("manual --> radius star [R_Sun]", "R_star", "radius_star", "1"),
     ("manual --> temperature star [K]", "T_star", "temperature_star", "5000"),
     ("number of cloud decks", "nr_cloud_decks", "number_of_cloud_decks", "0"),
+    ("path to Mie files", "mie_path", "path_to_mie_files", "./input/cloud1/ ./input/cloud2/"),
+    ("aerosol radius mode [micron]", "cloud_r_mode", "aerosol_radius_mode", "10 20"),
+    ("aerosol radius geometric std dev", "cloud_r_std_dev", "aerosol_radius_geometric_std_dev", "2 1.5"),
+    ("cloud mixing ratio", "cloud_mixing_ratio_setting", "cloud_mixing_ratio", "manual"),
+    ("file --> path to file with cloud data", "cloud_vmr_file", "path_to_file_with_cloud_data", "./input/cloud_file.txt"),
+    ("file --> cloud file format", "cloud_file_format", None, "1 Pressure cgs"),
+    ("file --> aerosol name", "cloud_file_species_name", "aerosol_name", "Aerosol1 Aerosol2"),
+    ("manual --> cloud bottom pressure [10^-6 bar]", "p_cloud_bot", "cloud_bottom_pressure", "1e5 1e3"),
+    ("manual --> cloud bottom mixing ratio", "f_cloud_bot", "cloud_bottom_mixing_ratio", "1e-19 1e-19"),
+    ("manual --> cloud to gas scale height ratio", "cloud_to_gas_scale_height", "cloud_to_gas_scale_height_ratio", "0.5 0.5"),
     ("debugging feedback", "debug", "debugging_feedback", "no"),
     ("precision", "prec", "precision", "double"),
     ("number of layers", "nlayer", "number_of_layers", "automatic"),
@@ -102,21 +113,6 @@ class Species(object):
         self.scat_cross_sect_interface = []
 
 
-class _Cloud(object):
-    """minimal stand-in for source/clouds.py's Cloud: the hot path only needs the six cloud arrays"""
-    nr_cloud_decks = 0
-
-    def cloud_pre_processing(self, quant):
-        n_l, n_i = int(quant.nlayer) * int(quant.nbin), int(quant.ninterface) * int(quant.nbin)
-        for stem in ("abs_cross_all_clouds", "scat_cross_all_clouds", "g_0_all_clouds"):
-            if len(np.atleast_1d(getattr(quant, stem + "_lay"))) != n_l:
-                setattr(quant, stem + "_lay", np.zeros(n_l))
-                setattr(quant, stem + "_int", np.zeros(n_i))
-        for name, n in (("f_all_clouds_lay", int(quant.nlayer)), ("f_all_clouds_int", int(quant.ninterface))):
-            if getattr(quant, name, None) is None or len(np.atleast_1d(getattr(quant, name))) != n:
-                setattr(quant, name, np.zeros(n))         # total cloud mixing ratio (clouds.py:231-232)
-
-
 class Read(object):
     """reads the parameter file, the command line and the input tables"""
 
@@ -128,7 +124,7 @@ class Read(object):
         self.stellar_model = "blackbody"
         self.input_surf_albedo = "0.0"
         self.synthetic_spec = None
-        self.cloud = _Cloud()
+        self.cloud = Cloud()
 
     # ---------------------------------------------------------------------------------------------
     @staticmethod
@@ -185,7 +181,30 @@ class Read(object):
         quant.planet = val["planet"]
         quant.g, quant.a = f64(val["g"]), f64(val["a"])
         quant.R_planet, quant.R_star, quant.T_star = f64(val["R_planet"]), f64(val["R_star"]), f64(val["T_star"])
-        self.cloud.nr_cloud_decks = int(val["nr_cloud_decks"])
+        cloud = cloud if cloud is not None else self.cloud
+        self.cloud = cloud
+        cloud.nr_cloud_decks = np.int32(val["nr_cloud_decks"])
+        n_decks = max(int(cloud.nr_cloud_decks), 0)
+
+        def per_deck(key, conv, flag):
+            """one value per deck from the parameter file; a command-line flag sets a single deck (read.py:759-787)"""
+            if flag and getattr(args, flag) is not None:
+                return [conv(getattr(args, flag))]
+            return [conv(v) for v in str(val[key]).split()[:n_decks]]
+        cloud.mie_path = per_deck("mie_path", str, "path_to_mie_files")
+        cloud.cloud_r_mode = per_deck("cloud_r_mode", f64, "aerosol_radius_mode")
+        cloud.cloud_r_std_dev = per_deck("cloud_r_std_dev", f64, "aerosol_radius_geometric_std_dev")
+        cloud.cloud_mixing_ratio_setting = val["cloud_mixing_ratio_setting"]
+        cloud.cloud_vmr_file = val["cloud_vmr_file"]
+        fmt = str(val["cloud_file_format"]).split()
+        cloud.cloud_vmr_file_header_lines = int(fmt[0])
+        cloud.cloud_file_press_name, cloud.cloud_file_press_units = fmt[1], fmt[2]
+        manual = cloud.cloud_mixing_ratio_setting == "manual"
+        cloud.cloud_file_species_name = [] if manual else per_deck("cloud_file_species_name", str, "aerosol_name")
+        cloud.p_cloud_bot = per_deck("p_cloud_bot", f64, "cloud_bottom_pressure") if manual else []
+        cloud.f_cloud_bot = per_deck("f_cloud_bot", f64, "cloud_bottom_mixing_ratio") if manual else []
+        cloud.cloud_to_gas_scale_height = per_deck("cloud_to_gas_scale_height", f64,
+                                                   "cloud_to_gas_scale_height_ratio") if manual else []
         quant.debug = _yes_no(val["debug"])
         quant.prec = val["prec"]
         quant.nlayer = val["nlayer"]

@@ -225,6 +225,71 @@ def start_state(dir_beam, T_star):
     return q
 
 
+def write_mie_files(directory, seed):
+    """synthetic LX-MIE output: one file per radius of the reference's hard-wired grid, 7 columns of which the
+    reader uses wavelength [micron], scattering and absorption cross-section and g_0 (columns 0, 3, 4, 6)"""
+    rng = np.random.default_rng(seed)
+    os.makedirs(directory, exist_ok=True)
+    lam = 0.2 * (600.0 / 0.2) ** (np.arange(37) / 36.0)          # micron
+    slope = rng.uniform(0.8, 1.6)
+    for r in 10 ** np.arange(-2, 3.1, 0.1):
+        x = 2 * np.pi * r / lam
+        q_sca = x ** 4 / (1 + x ** 4) * (1.5 + 0.3 * np.sin(3 * np.log(x)))
+        q_abs = 0.2 * x ** slope / (1 + x ** slope)
+        geo = np.pi * (r * 1e-4) ** 2
+        g0 = 0.85 * x ** 2 / (1 + x ** 2)
+        with open(os.path.join(directory, "r{:.6f}.dat".format(r)), "w") as f:
+            f.write("# wavelength[micron] size_par ext scat abs albedo g_0\n")
+            for k in range(len(lam)):
+                f.write("%.8e %.6e %.8e %.8e %.8e %.6e %.8e\n" % (lam[k], x[k], geo * (q_sca[k] + q_abs[k]),
+                                                                  geo * q_sca[k], geo * q_abs[k],
+                                                                  q_sca[k] / (q_sca[k] + q_abs[k]), g0[k]))
+
+
+def cloud_case(tag, workdir):
+    """(cloud settings, quant) of the two golden cloud cases; Mie files and the VMR file are written to `workdir`"""
+    q = types.SimpleNamespace()
+    nbin, nlayer = 14, 11
+    q.nbin, q.nlayer, q.ninterface = np.int32(nbin), np.int32(nlayer), np.int32(nlayer + 1)
+    edges = 0.1e-4 * (1000.0 / 0.1) ** (np.arange(nbin + 1) / nbin)      # 0.1 - 1000 micron: wider than the tables
+    q.opac_interwave = edges
+    q.opac_wave = 0.5 * (edges[1:] + edges[:-1])
+    lev = [1e8 * (1e0 / 1e8) ** (i / (2 * nlayer - 1)) for i in range(2 * nlayer)]
+    q.p_lay = lev[1::2]
+    q.p_int = lev[0::2] + [1e0 * (1e0 / 1e8) ** (1 / (2 * nlayer - 1))]
+    q.clouds = np.int32(1)
+    s = dict(nr_cloud_decks=2, mie_path=[os.path.join(workdir, "mie1") + "/", os.path.join(workdir, "mie2") + "/"],
+             cloud_r_mode=[0.5, 8.0], cloud_r_std_dev=[1.8, 1.3])
+    write_mie_files(s["mie_path"][0], 41)
+    write_mie_files(s["mie_path"][1], 42)
+    if tag == "manual":
+        q.iso = np.int32(0)
+        s.update(cloud_mixing_ratio_setting="manual", p_cloud_bot=[2e6, 3e3], f_cloud_bot=[1e-12, 4e-14],
+                 cloud_to_gas_scale_height=[0.4, 1.0])
+    else:
+        q.iso = np.int32(1)
+        path = os.path.join(workdir, "cloud_vmr.txt")
+        with open(path, "w") as f:
+            f.write("cloud mixing ratios\nPressure Dust Ice\n")
+            for p, a, b in ((5e-1, 1e-16, 3e-15), (5e0, 1e-15, 2e-14), (5e1, 1e-14, 1e-13), (5e2, 3e-14, 5e-15)):
+                f.write("%g %g %g\n" % (p, a, b))
+        s.update(cloud_mixing_ratio_setting="file", cloud_vmr_file=path, cloud_vmr_file_header_lines=1,
+                 cloud_file_press_name="Pressure", cloud_file_press_units="Pa", cloud_file_species_name=["Dust", "Ice"])
+    return s, q
+
+
+CLOUD_KEYS = ["f_all_clouds_lay", "f_all_clouds_int", "abs_cross_all_clouds_lay", "abs_cross_all_clouds_int",
+              "scat_cross_all_clouds_lay", "scat_cross_all_clouds_int", "g_0_all_clouds_lay", "g_0_all_clouds_int"]
+
+
+def run_clouds(cloud_obj, tag, workdir):
+    s, q = cloud_case(tag, workdir)
+    for k, v in s.items():
+        setattr(cloud_obj, k, v)
+    cloud_obj.cloud_pre_processing(q)
+    return q
+
+
 def reader_stub(out_dir):
     r = types.SimpleNamespace()
     r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
@@ -265,7 +330,38 @@ READER_CASES = {
                           "-radiative_equilibrium_criterion", "1e-6", "-physical_timestep", "120",
                           "-stellar_zenith_angle", "30", "-kappa_value", "0.25"],
     "post_processing": ["-run_type", "post-processing", "-planet_type", "no_atmosphere"],
+    "one_deck_command_line": ["-number_of_cloud_decks", "1", "-path_to_mie_files", "./mie/enstatite/",
+                              "-aerosol_radius_mode", "3.5", "-aerosol_radius_geometric_std_dev", "1.7",
+                              "-cloud_bottom_pressure", "2e4", "-cloud_bottom_mixing_ratio", "3e-13",
+                              "-cloud_to_gas_scale_height_ratio", "0.7"],
+    "two_decks_manual": [],
+    "two_decks_file": [],
 }
+# per case: textual substitutions applied to reader/param_sample.dat before it is parsed
+READER_EDITS = {
+    "two_decks_manual": [("number of cloud decks =                               0",
+                          "number of cloud decks =                               2")],
+    "two_decks_file": [("number of cloud decks =                               0",
+                        "number of cloud decks =                               2"),
+                       ("cloud mixing ratio =                                  manual",
+                        "cloud mixing ratio =                                  file")],
+}
+
+
+def reader_param_file(case, workdir):
+    """the sample parameter file, edited for `case` if needed; returns its path"""
+    sample = os.path.join(HERE, "reader", "param_sample.dat")
+    edits = READER_EDITS.get(case)
+    if not edits:
+        return sample
+    text = open(sample).read()
+    for a, b in edits:
+        assert a in text
+        text = text.replace(a, b)
+    path = os.path.join(workdir, "param_%s.dat" % case)
+    with open(path, "w") as f:
+        f.write(text)
+    return path
 
 
 def reader_fixture():
@@ -279,17 +375,18 @@ def reader_fixture():
     # read-only here and nothing else of that step is needed
     ref_read.Read.set_prec_in_cudafile = lambda self, quant: None
     out = {}
-    sample = os.path.join(HERE, "reader", "param_sample.dat")
+    import tempfile
     for case, flags in READER_CASES.items():
         argv0 = sys.argv
-        sys.argv = ["helios.py", "-parameter_file", sample] + flags
-        try:
-            k, r, c = ref_quant.Store(), ref_read.Read(), ref_clouds.Cloud()
-            r.read_param_file_and_command_line(k, c)
-        finally:
-            sys.argv = argv0
+        with tempfile.TemporaryDirectory() as wd:
+            sys.argv = ["helios.py", "-parameter_file", reader_param_file(case, wd)] + flags
+            try:
+                k, r, c = ref_quant.Store(), ref_read.Read(), ref_clouds.Cloud()
+                r.read_param_file_and_command_line(k, c)
+            finally:
+                sys.argv = argv0
         rec = {}
-        for prefix, obj in (("quant.", k), ("read.", r)):
+        for prefix, obj in (("quant.", k), ("read.", r), ("cloud.", c)):
             for a, v in vars(obj).items():
                 if a == "param_file" or v is None:
                     continue
@@ -297,6 +394,10 @@ def reader_fixture():
                     rec[prefix + a] = v if isinstance(v, str) else float(v)
                 elif isinstance(v, list) and v and all(isinstance(e, (int, float, np.integer, np.floating)) for e in v):
                     rec[prefix + a] = [float(e) for e in v]
+                elif isinstance(v, list) and v and all(isinstance(e, str) for e in v):
+                    rec[prefix + a] = list(v)
+                elif isinstance(v, list) and not v and prefix == "cloud.":
+                    rec[prefix + a] = []
         out[case] = dict(flags=flags, parsed=rec)
     with open(os.path.join(HERE, "reader", "parsed.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
@@ -369,6 +470,28 @@ def main():
         data["start.%s" % tag] = np.array([q.g, q.a, q.R_planet, q.R_star, q.T_star, q.w_0_limit, q.w_0_scat_limit,
                                            q.delta_tau_limit, q.F_intern, q.T_lay[0]], float)
         data["start.%s.gauss_weight" % tag] = np.array(q.gauss_weight)
+    # cloud pre-processing: Mie tables -> size distribution -> wavelength bins -> decks (source/clouds.py)
+    import contextlib
+    import io
+    import tempfile
+    from source import clouds as ref_clouds
+    from source import tools as ref_tools
+    for tag in ("manual", "file"):
+        with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):
+            q = run_clouds(ref_clouds.Cloud(), tag, wd)
+        for k in CLOUD_KEYS:
+            data["cloud.%s.%s" % (tag, k)] = np.array(getattr(q, k), float)
+    # the spectrum re-binning on its own (both interpolation types, table narrower / wider than the bins)
+    rng = np.random.default_rng(77)
+    old_l = np.sort(10.0 ** rng.uniform(-0.3, 1.7, 60))
+    old_f = 10.0 ** rng.uniform(-3, 2, 60)
+    new_l = 10.0 ** np.linspace(-0.6, 2.0, 23)
+    data["rebin.old_lambda"], data["rebin.old_flux"], data["rebin.new_lambda"] = old_l, old_f, new_l
+    for kind in ("linear", "log"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            data["rebin." + kind] = np.array(ref_tools.convert_spectrum(old_l, old_f, new_l, type=kind), float)
+            data["rebin.fine." + kind] = np.array(ref_tools.convert_spectrum(
+                old_l, old_f, 10.0 ** np.linspace(0.0, 1.5, 400), type=kind), float)
     np.savez_compressed(os.path.join(HERE, "host_functions.npz"), **data)
 
     # writers: two states (non-isothermal with convection columns; isothermal, no star, no convection)

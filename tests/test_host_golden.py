@@ -143,20 +143,42 @@ def test_parameter_file_and_command_line(case):
     with open(os.path.join(GOLD, "reader", "parsed.json")) as f:
         rec = json.load(f)[case]
     q, r = Store(), Read()
-    r.read_param_file_and_command_line(q, r.cloud, ["-parameter_file", os.path.join(GOLD, "reader", "param_sample.dat")]
-                                       + rec["flags"])
+    import tempfile
+    with tempfile.TemporaryDirectory() as wd:
+        r.read_param_file_and_command_line(q, r.cloud, ["-parameter_file", mk.reader_param_file(case, wd)] + rec["flags"])
     checked = 0
     for key, want in rec["parsed"].items():
         if key in _READER_NOT_CARRIED:
             continue
-        obj, attr = (q, key[6:]) if key.startswith("quant.") else (r, key[5:])
+        obj, attr = {"quant": (q, key[6:]), "read.": (r, key[5:]), "cloud": (r.cloud, key[6:])}[key[:5]]
         assert hasattr(obj, attr), key
         got = getattr(obj, attr)
         if isinstance(want, str):
             assert str(got) == want, key
+        elif isinstance(want, list) and (not want or isinstance(want[0], str)):
+            assert list(got) == want, key
         elif isinstance(want, list):
             np.testing.assert_allclose(np.array(got, float), want, rtol=1e-15, err_msg=key)
         else:
             np.testing.assert_allclose(float(got), want, rtol=1e-15, err_msg=key)
         checked += 1
     assert checked >= 55
+
+
+@pytest.mark.parametrize("tag", ["manual", "file"])
+def test_cloud_pre_processing(tmp_path, tag):
+    from helios_amd.clouds import Cloud
+    q = mk.run_clouds(Cloud(), tag, str(tmp_path))
+    for k in mk.CLOUD_KEYS:
+        want = Z["cloud.%s.%s" % (tag, k)]
+        assert np.abs(want).max() > 0 or k.endswith("_int") and tag == "file"
+        np.testing.assert_allclose(np.array(getattr(q, k), float), want, rtol=1e-11, atol=1e-300, err_msg=k)
+
+
+@pytest.mark.parametrize("kind", ["linear", "log"])
+def test_spectrum_rebinning(kind):
+    from helios_amd.tools import convert_spectrum
+    old_l, old_f, new_l = Z["rebin.old_lambda"], Z["rebin.old_flux"], Z["rebin.new_lambda"]
+    np.testing.assert_allclose(convert_spectrum(old_l, old_f, new_l, type=kind), Z["rebin." + kind], rtol=1e-12)
+    fine = convert_spectrum(old_l, old_f, 10.0 ** np.linspace(0.0, 1.5, 400), type=kind)
+    np.testing.assert_allclose(fine, Z["rebin.fine." + kind], rtol=1e-12)
