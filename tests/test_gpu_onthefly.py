@@ -1,5 +1,7 @@
 """GPU parity of on-the-fly opacity mixing (species loop with random overlap) through the fused path,
 and of the Python driver surface (Store / Compute / run_helios) in both its fused and per-stage forms."""
+import os
+
 import numpy as np
 import pytest
 
@@ -93,3 +95,31 @@ def test_run_helios_matrix_method(tmp_path):
     np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-2)
     np.testing.assert_allclose(a.T_lay[3:-1], b.T_lay[3:-1], rtol=1e-4)
     np.testing.assert_allclose(a.F_up_band[-int(a.nbin):].sum(), b.F_up_band[-int(b.nbin):].sum(), rtol=5e-3)
+
+
+def test_run_helios_with_mie_cloud_deck(tmp_path):
+    """parameter reader -> Mie tables -> size distribution -> deck -> fused path with clouds: the deck changes the
+    emission spectrum and the run still balances its energy"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "make_host_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_host_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    mie = os.path.join(str(tmp_path), "mie") + "/"
+    mk.write_mie_files(mie, 5)
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "40 6 5 7",
+            "-number_of_layers", "20", "-maximum_number_of_iterations", "20000", "-name", "cl",
+            "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
+            "-convective_adjustment", "no"]
+    cloudy = _run_driver(argv + ["-number_of_cloud_decks", "1", "-path_to_mie_files", mie, "-aerosol_radius_mode", "1.0",
+                                 "-aerosol_radius_geometric_std_dev", "1.8", "-cloud_bottom_pressure", "1e6",
+                                 "-cloud_bottom_mixing_ratio", "1e-13", "-cloud_to_gas_scale_height_ratio", "0.5"], True)
+    clear = _run_driver(argv, True)
+    assert int(cloudy.clouds) == 1 and cloudy.abs_cross_all_clouds_lay.max() > 0
+    assert np.all(np.isfinite(cloudy.T_lay)) and cloudy.F_up_band.min() >= 0
+    X = int(clear.nbin)
+    toa_c, toa_0 = cloudy.F_up_band[-X:], clear.F_up_band[-X:]
+    assert np.abs(toa_c - toa_0).max() > 1e-3 * toa_0.max()
+    from helios_amd import host_functions as hs
+    assert abs(hs.global_energy_imbalance(cloudy)) < 1e-3
+    assert os.path.getsize(os.path.join(str(tmp_path), "cl", "cl_cloud_opacities.dat")) > 100
