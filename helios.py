@@ -50,6 +50,9 @@ def run_helios(argv=None):
 
     computer.integrate_optdepth_transmission(keeper)
     computer.calculate_contribution_function(keeper)
+    if keeper.convection == 1:
+        computer.interpolate_entropy(keeper)
+        computer.interpolate_phase_state(keeper)
     computer.calculate_mean_opacities(keeper)
     computer.integrate_beamflux(keeper)
 

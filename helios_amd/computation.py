@@ -89,9 +89,14 @@ class Compute(object):
             self._call("hx_meanmolmass_interpol", T.d, quant.dev_ktemp.d, mmm.d, quant.dev_opac_meanmass.d, p.d,
                        quant.dev_kpress.d, _i(quant.npress), _i(quant.ntemp), n)
 
+    @staticmethod
+    def _kappa_from_table(quant):
+        """`kappa value = file` or `water_atmo`: the reference tests "is the value a string" (computation.py:202)"""
+        return isinstance(quant.input_kappa_value, str)
+
     def interpolate_kappa_and_cp(self, quant):
-        """only with a kappa/c_p table (`kappa value = file`); a constant kappa needs no kernel"""
-        if str(quant.input_kappa_value) != "file":
+        """only with a kappa/c_p table; a constant kappa needs no kernel (computation.py:199-250)"""
+        if not self._kappa_from_table(quant):
             return
         for T, p, kap, n in self._levels(quant, "dev_T_{}", "dev_p_{}", "dev_kappa_{}"):
             self._call("hx_kappa_interpol", T.d, quant.dev_entr_temp.d, p.d, quant.dev_entr_press.d, kap.d,
@@ -99,6 +104,20 @@ class Compute(object):
         self._call("hx_cp_interpol", quant.dev_T_lay.d, quant.dev_entr_temp.d, quant.dev_p_lay.d,
                    quant.dev_entr_press.d, quant.dev_c_p_lay.d, quant.dev_entr_c_p.d, _i(quant.entr_npress),
                    _i(quant.entr_ntemp), _i(quant.nlayer))
+
+    def interpolate_entropy(self, quant):
+        """layer entropy from the kappa file (diagnostic column of one output file; computation.py:252-271)"""
+        if self._kappa_from_table(quant):
+            self._call("hx_entropy_interpol", quant.dev_T_lay.d, quant.dev_entr_temp.d, quant.dev_p_lay.d,
+                       quant.dev_entr_press.d, quant.dev_entropy_lay.d, quant.dev_entr_entropy.d,
+                       _i(quant.entr_npress), _i(quant.entr_ntemp), _i(quant.nlayer))
+
+    def interpolate_phase_state(self, quant):
+        """water phase number, `water_atmo` tables only (computation.py:273-292)"""
+        if quant.input_kappa_value == "water_atmo":
+            self._call("hx_phase_number_interpol", quant.dev_T_lay.d, quant.dev_entr_temp.d, quant.dev_p_lay.d,
+                       quant.dev_entr_press.d, quant.dev_phase_number_lay.d, quant.dev_entr_phase_number.d,
+                       _i(quant.entr_npress), _i(quant.entr_ntemp), _i(quant.nlayer))
 
     def calc_total_g_0_of_gas_and_clouds(self, quant):
         for scat, g_cl, s_cl, g_tot, n in self._levels(quant, "dev_scat_cross_{}", "dev_g_0_all_clouds_{}",
@@ -334,7 +353,7 @@ class Compute(object):
 
     def _fused_supported(self, quant):
         return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
-                and quant.flux_calc_method == "iteration" and str(quant.input_kappa_value) != "file"
+                and quant.flux_calc_method == "iteration" and not self._kappa_from_table(quant)
                 and quant.add_heating != 1)
 
     def _make_rt(self, quant):

@@ -259,4 +259,22 @@ int hx_cp_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
     return 0;
 }
 
+int hx_entropy_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
+                        const double* press, const double* entr_press, double* entropy,
+                        const double* entr_entropy, int entr_npress, int entr_ntemp, int nlayer) {
+    k_scalar_table<<<hx_cdiv(nlayer, 64), 64, 0, ctx->stream>>>(
+        temp, entr_temp, press, entr_press, entropy, entr_entropy, entr_npress, entr_ntemp, nlayer, 1);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_phase_number_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
+                             const double* press, const double* entr_press, double* state,
+                             const double* entr_state, int entr_npress, int entr_ntemp, int nlayer) {
+    k_scalar_table<<<hx_cdiv(nlayer, 64), 64, 0, ctx->stream>>>(
+        temp, entr_temp, press, entr_press, state, entr_state, entr_npress, entr_ntemp, nlayer, 0);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 }  // extern "C"

@@ -39,6 +39,7 @@ _OPTIONS = [
     ("premixed   --> path to opacity file", "ktable_path", "path_to_opacity_file", "./input/r50_kdistr_solar_eq.h5"),
     ("convective adjustment", "convection", "convective_adjustment", "yes"),
     ("kappa value", "input_kappa_value", "kappa_value", "0.285714"),
+    ("file --> kappa file path", "entr_kappa_path", "kappa_file_path", "./input/delad_example.dat"),
     ("stellar spectral model", "stellar_model", "stellar_spectral_model", "blackbody"),
     ("planet", "planet", "planet", "manual"),
     ("manual --> surface gravity [cm s^-2]", "g", "surface_gravity", "1000"),
@@ -122,6 +123,7 @@ class Read(object):
         self.ktable_path = None
         self.temp_path = None
         self.stellar_model = "blackbody"
+        self.entr_kappa_path = None
         self.input_surf_albedo = "0.0"
         self.synthetic_spec = None
         self.cloud = Cloud()
@@ -177,6 +179,7 @@ class Read(object):
         self.ktable_path = val["ktable_path"]
         quant.convection = _yes_no(val["convection"])
         quant.input_kappa_value = val["input_kappa_value"]
+        self.entr_kappa_path = val["entr_kappa_path"]
         self.stellar_model = val["stellar_model"]
         quant.planet = val["planet"]
         quant.g, quant.a = f64(val["g"]), f64(val["a"])
@@ -331,23 +334,47 @@ class Read(object):
         quant.opac_meanmass = syn.meanmass_table(ntemp, npress)
 
     def read_kappa_table_or_use_constant_kappa(self, quant):
-        """constant kappa (default) -> kappa_lay/int and c_p = R/kappa (read.py:1105-1193)"""
+        """constant kappa -> kappa_lay/int and c_p = R/kappa; `file` / `water_atmo` -> the (T, P) table of
+        kappa (= delad), c_p, entropy [and water phase number] that the interpolation kernels use
+        (read.py:1105-1193).  Table layout as read: value[p + npress * t]; rows sorted by T then P in the file."""
         L, I = int(quant.nlayer), int(quant.ninterface)
-        quant.entr_temp, quant.entr_press, quant.entr_kappa, quant.entr_c_p = [0.0], [0.0], [0.0], [0.0]
-        quant.entr_entropy, quant.entr_phase_number = [0.0], [0.0]
-        quant.entr_ntemp = quant.entr_npress = np.int32(1)
-        if quant.convection == 1:
-            try:
-                kap = float(quant.input_kappa_value)
-            except ValueError:
-                raise IOError("kappa tables (kappa value = file) are outside this build's scope; "
-                              "give a constant kappa value (SURVEY.md 2.2)")
-            quant.input_kappa_value = np.float64(kap)
+        for name in ("entr_temp", "entr_press", "entr_kappa", "entr_c_p", "entr_entropy", "entr_phase_number"):
+            setattr(quant, name, [])
+        quant.entr_ntemp = quant.entr_npress = np.int32(0)
+        if quant.convection != 1:
+            quant.c_p_lay, quant.kappa_lay, quant.kappa_int = np.zeros(L), np.zeros(L), np.zeros(I)
+            return
+        try:
+            quant.input_kappa_value = np.float64(quant.input_kappa_value)
+        except ValueError:
+            pass
+        if not isinstance(quant.input_kappa_value, str):
+            kap = float(quant.input_kappa_value)
             quant.kappa_lay = np.ones(L) * kap
             quant.c_p_lay = np.ones(L) * (pc.R_UNIV / kap)
             quant.kappa_int = np.ones(I) * kap
-        else:
-            quant.c_p_lay, quant.kappa_lay, quant.kappa_int = np.zeros(L), np.zeros(L), np.zeros(I)
+            return
+        water = quant.input_kappa_value == "water_atmo"
+        if not water and quant.input_kappa_value != "file":
+            raise IOError("ERROR: kappa value must be a number, 'file' or 'water_atmo'")
+        print("\nReading kappa/delad values from file (%s format)." % ("water atmospheres" if water else "standard"))
+        with open(self.entr_kappa_path, "r") as f:
+            rows = [ln.split() for ln in f.readlines()[5 if water else 2:]]
+        for col in (r for r in rows if r):
+            quant.entr_temp.append(quant.fl_prec(col[0]))
+            quant.entr_press.append(quant.fl_prec(col[1]))
+            quant.entr_kappa.append(quant.fl_prec(col[2]))
+            quant.entr_c_p.append(quant.fl_prec(col[3]))
+            if water:
+                quant.entr_entropy.append(10 ** quant.fl_prec(col[4]))
+                quant.entr_phase_number.append(quant.fl_prec(col[7]))
+            else:
+                quant.entr_entropy.append(10 ** quant.fl_prec(col[4]) if len(col) > 4 else 0)
+        quant.entr_press = np.sort(list(set(quant.entr_press)))
+        quant.entr_temp = np.sort(list(set(quant.entr_temp)))
+        quant.entr_npress = np.int32(len(quant.entr_press))
+        quant.entr_ntemp = np.int32(len(quant.entr_temp))
+        quant.kappa_lay, quant.c_p_lay, quant.kappa_int = np.zeros(L), np.zeros(L), np.zeros(I)
 
     def read_star(self, quant):
         if self.stellar_model == "blackbody":

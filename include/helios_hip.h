@@ -96,6 +96,14 @@ int hx_kappa_interpol(hx_context* ctx, const double* temp, const double* entr_te
 int hx_cp_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
                    const double* press, const double* entr_press, double* cp_lay,
                    const double* entr_cp, int entr_npress, int entr_ntemp, int nlayer);
+/* entropy_interpol, kernels.cu:815 (log10 T grid) and phase_number_interpol, kernels.cu:869 /
+ * computation.py:252, :273 -- diagnostics of the kappa-file modes */
+int hx_entropy_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
+                        const double* press, const double* entr_press, double* entropy,
+                        const double* entr_entropy, int entr_npress, int entr_ntemp, int nlayer);
+int hx_phase_number_interpol(hx_context* ctx, const double* temp, const double* entr_temp,
+                             const double* press, const double* entr_press, double* state,
+                             const double* entr_state, int entr_npress, int entr_ntemp, int nlayer);
 /* planck_interpol_layer, kernels.cu:923 / computation.py:294 */
 int hx_planck_interpol_layer(hx_context* ctx, const double* temp, double* planckband_lay,
                              const double* planck_grid, const double* starflux, int realstar,

@@ -274,6 +274,20 @@ void orc_cp_interpol(const double* temp, const double* entr_temp, const double* 
     scalar_table_interpol(temp, entr_temp, press, entr_press, cp, entr_cp, entr_npress, entr_ntemp,
                           nlev, 1);
 }
+/* source/kernels.cu:815-865 (log10 T) */
+void orc_entropy_interpol(const double* temp, const double* entr_temp, const double* press,
+                          const double* entr_press, double* entropy, const double* entr_entropy,
+                          int entr_npress, int entr_ntemp, int nlayer) {
+    scalar_table_interpol(temp, entr_temp, press, entr_press, entropy, entr_entropy, entr_npress,
+                          entr_ntemp, nlayer, 1);
+}
+/* source/kernels.cu:869-919 (linear T) */
+void orc_phase_number_interpol(const double* temp, const double* entr_temp, const double* press,
+                               const double* entr_press, double* state, const double* entr_state,
+                               int entr_npress, int entr_ntemp, int nlayer) {
+    scalar_table_interpol(temp, entr_temp, press, entr_press, state, entr_state, entr_npress, entr_ntemp,
+                          nlayer, 0);
+}
 
 /* source/kernels.cu:3209-3259 */
 void orc_opac_species_interpol(const double* temp, const double* opactemp, const double* press,

@@ -52,6 +52,12 @@ void orc_kappa_interpol(const double* temp, const double* entr_temp, const doubl
 void orc_cp_interpol(const double* temp, const double* entr_temp, const double* press,
                      const double* entr_press, double* cp, const double* entr_cp, int entr_npress,
                      int entr_ntemp, int nlev);
+void orc_entropy_interpol(const double* temp, const double* entr_temp, const double* press,
+                          const double* entr_press, double* entropy, const double* entr_entropy,
+                          int entr_npress, int entr_ntemp, int nlayer);
+void orc_phase_number_interpol(const double* temp, const double* entr_temp, const double* press,
+                               const double* entr_press, double* state, const double* entr_state,
+                               int entr_npress, int entr_ntemp, int nlayer);
 void orc_opac_species_interpol(const double* temp, const double* opactemp, const double* press,
                                const double* opacpress, const double* pretab, double* opac_spec,
                                int npress, int ntemp, int ny, int nbin, int nlev);

@@ -140,6 +140,23 @@ void ref_cp_interpol(double* temp, double* entr_temp, double* press, double* ent
                     nlayer);
     });
 }
+// computation.py:252-292 (diagnostics of the kappa-file modes)
+void ref_entropy_interpol(double* temp, double* entr_temp, double* press, double* entr_press,
+                          double* entropy, double* entr_entropy, int entr_npress, int entr_ntemp,
+                          int nlayer) {
+    launch({cdiv(nlayer, 16), 1, 1}, {16, 1, 1}, [&] {
+        entropy_interpol(temp, entr_temp, press, entr_press, entropy, entr_entropy, entr_npress,
+                         entr_ntemp, nlayer);
+    });
+}
+void ref_phase_number_interpol(double* temp, double* entr_temp, double* press, double* entr_press,
+                               double* state, double* entr_state, int entr_npress, int entr_ntemp,
+                               int nlayer) {
+    launch({cdiv(nlayer, 16), 1, 1}, {16, 1, 1}, [&] {
+        phase_number_interpol(temp, entr_temp, press, entr_press, state, entr_state, entr_npress,
+                              entr_ntemp, nlayer);
+    });
+}
 
 // computation.py:294-313
 void ref_planck_interpol_layer(double* temp, double* planckband_lay, double* planck_grid,

@@ -290,6 +290,42 @@ def run_clouds(cloud_obj, tag, workdir):
     return q
 
 
+def write_kappa_file(path, water, seed=3, const_kappa=None):
+    """a kappa (= delad) / c_p / entropy table in the reference's two ASCII layouts (read.py:1121-1162)"""
+    rng = np.random.default_rng(seed)
+    temps = np.linspace(100.0, 3100.0, 7)
+    press = 10.0 ** np.linspace(0.0, 9.0, 6)
+    with open(path, "w") as f:
+        for _ in range(5 if water else 2):
+            f.write("# header line\n")
+        for t in temps:
+            for p in press:
+                kap = const_kappa if const_kappa is not None else rng.uniform(0.15, 0.4)
+                cp = 8.31446261815324e7 / kap if const_kappa is not None else rng.uniform(2.5e8, 4e8)
+                row = [t, p, kap, cp, rng.uniform(7.5, 9.5)]
+                if water:
+                    row += [rng.uniform(0, 1), rng.uniform(0, 1), float(rng.integers(0, 2))]
+                f.write(" ".join("%.10e" % v for v in row) + "\n")
+            f.write("\n")
+
+
+def kappa_state(mode, path):
+    q = types.SimpleNamespace()
+    q.fl_prec = np.float64
+    q.convection, q.iso = np.int32(1), np.int32(0)
+    q.nlayer, q.ninterface = np.int32(6), np.int32(7)
+    q.input_kappa_value = mode
+    for name in ("entr_temp", "entr_press", "entr_kappa", "entr_c_p", "entr_entropy", "entr_phase_number"):
+        setattr(q, name, [])
+    r = types.SimpleNamespace()
+    r.entr_kappa_path = path
+    return q, r
+
+
+KAPPA_KEYS = ["entr_temp", "entr_press", "entr_kappa", "entr_c_p", "entr_entropy", "entr_phase_number", "kappa_lay",
+              "c_p_lay", "kappa_int"]
+
+
 def reader_stub(out_dir):
     r = types.SimpleNamespace()
     r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
@@ -481,6 +517,17 @@ def main():
             q = run_clouds(ref_clouds.Cloud(), tag, wd)
         for k in CLOUD_KEYS:
             data["cloud.%s.%s" % (tag, k)] = np.array(getattr(q, k), float)
+    # kappa / c_p / entropy tables and the constant-kappa shortcut
+    from source import read as ref_read2
+    for mode in ("file", "water_atmo", "0.2857"):
+        with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):
+            path = os.path.join(wd, "delad.dat")
+            write_kappa_file(path, mode == "water_atmo")
+            q, r = kappa_state(mode, path)
+            ref_read2.Read.read_kappa_table_or_use_constant_kappa(r, q)
+        for k in KAPPA_KEYS:
+            data["kappa.%s.%s" % (mode, k)] = np.array(getattr(q, k), float)
+        data["kappa.%s.dims" % mode] = np.array([getattr(q, "entr_ntemp", 0) or 0, getattr(q, "entr_npress", 0) or 0], float)
     # the spectrum re-binning on its own (both interpolation types, table narrower / wider than the bins)
     rng = np.random.default_rng(77)
     old_l = np.sort(10.0 ** rng.uniform(-0.3, 1.7, 60))

@@ -27,6 +27,8 @@ class RefImpl(object):
         self.meanmolmass_interpol = r.meanmolmass_interpol
         self.kappa_interpol = r.kappa_interpol
         self.cp_interpol = r.cp_interpol
+        self.entropy_interpol = r.entropy_interpol
+        self.phase_number_interpol = r.phase_number_interpol
         self.opac_species_interpol = r.opac_species_interpol
         self.add_to_mixed_opac = r.add_to_mixed_opac
         self.calc_h2o_scat = r.calc_h2o_scat

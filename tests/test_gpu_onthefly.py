@@ -123,3 +123,27 @@ def test_run_helios_with_mie_cloud_deck(tmp_path):
     from helios_amd import host_functions as hs
     assert abs(hs.global_energy_imbalance(cloudy)) < 1e-3
     assert os.path.getsize(os.path.join(str(tmp_path), "cl", "cl_cloud_opacities.dat")) > 100
+
+
+def test_run_helios_with_kappa_table(tmp_path):
+    """`kappa value = file`: the per-stage loop interpolates kappa and c_p from the table every refresh; a table
+    holding the constant 2/7 everywhere must reproduce the constant-kappa run"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "make_host_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_host_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    path = os.path.join(str(tmp_path), "delad.dat")
+    kap = 0.1                                            # small adiabatic gradient: the deep layers must convect
+    mk.write_kappa_file(path, False, const_kappa=kap)
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",
+            "-number_of_layers", "20", "-maximum_number_of_iterations", "20000", "-name", "kap",
+            "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
+            "-internal_temperature", "1500"]
+    a = _run_driver(argv + ["-kappa_value", "file", "-kappa_file_path", path], True)
+    b = _run_driver(argv + ["-kappa_value", repr(kap)], False)
+    assert a.conv_layer.sum() > 0                      # the convection loop engaged
+    np.testing.assert_allclose(a.kappa_lay, kap, rtol=1e-12)
+    np.testing.assert_array_equal(a.conv_layer, b.conv_layer)
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-9)
+    assert a.entropy_lay.min() > 0                     # entropy diagnostic interpolated from the table

@@ -84,6 +84,23 @@ def test_matrix_flux_solve_vs_oracle(hip, port, cfg):
         np.testing.assert_allclose(sh[k], sp[k], rtol=1e-12, atol=1e-14 * np.abs(sp[k]).max(), err_msg=k)
 
 
+def test_scalar_table_interpolations_vs_oracle(hip, port):
+    """kappa / c_p / entropy / phase-number tables (kernels.cu:703-919): bilinear in (T or log10 T, log10 P) with the
+    0.001 clamp; profile points inside, on the grid nodes and outside the table"""
+    rng = np.random.default_rng(11)
+    nt, npr = 9, 7
+    et, ep = np.linspace(100, 4000, nt), np.logspace(0, 9, npr)
+    tab = rng.uniform(0.1, 0.4, nt * npr)
+    temp = np.concatenate((rng.uniform(50, 4500, 20), et[[0, 3, -1]], [10.0, 9000.0]))
+    press = np.concatenate((10.0 ** rng.uniform(-1, 10, 20), ep[[0, 2, -1]], [1e-3, 1e12]))
+    n = len(temp)
+    for fn in ("kappa_interpol", "cp_interpol", "entropy_interpol", "phase_number_interpol"):
+        a, b = np.zeros(n), np.zeros(n)
+        getattr(hip, fn)(temp, et, press, ep, a, tab, npr, nt, n)
+        getattr(port, fn)(temp, et, press, ep, b, tab, npr, nt, n)
+        np.testing.assert_allclose(a, b, rtol=1e-12, err_msg=fn)
+
+
 def test_post_loop_diagnostics_vs_oracle(hip, port):
     c0 = cases.make_case(clouds=1, g_0=0.2, nbin=21, nlayer=11)
     res = []

@@ -128,7 +128,7 @@ _READER_NOT_CARRIED = {
     "quant.add_heating_file_data_name", "quant.add_heating_file_header_lines", "quant.add_heating_file_press_name",
     "quant.add_heating_file_press_unit", "quant.add_heating_path", "quant.real_star",
     "read.albedo_file", "read.albedo_file_header_lines", "read.albedo_file_surface_name",
-    "read.albedo_file_wavelength_name", "read.albedo_file_wavelength_unit", "read.entr_kappa_path",
+    "read.albedo_file_wavelength_name", "read.albedo_file_wavelength_unit",
     "read.fastchem_path", "read.force_eq_chem", "read.opacity_path", "read.species_file", "read.stellar_data_set",
     "read.stellar_path", "read.temp_format", "read.temp_pressure_unit", "read.vertical_vmr_file",
     "read.vertical_vmr_file_header_lines", "read.vertical_vmr_file_press_name", "read.vertical_vmr_file_press_units",
@@ -182,3 +182,17 @@ def test_spectrum_rebinning(kind):
     np.testing.assert_allclose(convert_spectrum(old_l, old_f, new_l, type=kind), Z["rebin." + kind], rtol=1e-12)
     fine = convert_spectrum(old_l, old_f, 10.0 ** np.linspace(0.0, 1.5, 400), type=kind)
     np.testing.assert_allclose(fine, Z["rebin.fine." + kind], rtol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["file", "water_atmo", "0.2857"])
+def test_kappa_table_reader(tmp_path, mode):
+    from helios_amd.read import Read
+    path = os.path.join(str(tmp_path), "delad.dat")
+    mk.write_kappa_file(path, mode == "water_atmo")
+    q, _ = mk.kappa_state(mode, path)
+    r = Read()
+    r.entr_kappa_path = path
+    r.read_kappa_table_or_use_constant_kappa(q)
+    for k in mk.KAPPA_KEYS:
+        np.testing.assert_allclose(np.array(getattr(q, k), float), Z["kappa.%s.%s" % (mode, k)], rtol=1e-15, err_msg=k)
+    np.testing.assert_array_equal([int(q.entr_ntemp), int(q.entr_npress)], Z["kappa.%s.dims" % mode].astype(int))

@@ -146,7 +146,7 @@ def test_kappa_cp_interpol(port, ref):
     tab = rng.uniform(0.1, 0.4, nt * npr)
     temp = rng.uniform(50, 4500, nlev)
     press = 10.0 ** rng.uniform(-1, 10, nlev)
-    for fn in ("kappa_interpol", "cp_interpol"):
+    for fn in ("kappa_interpol", "cp_interpol", "entropy_interpol", "phase_number_interpol"):
         a, b = np.zeros(nlev), np.zeros(nlev)
         getattr(port, fn)(temp, et, press, ep, a, tab, npr, nt, nlev)
         getattr(ref, fn)(temp, et, press, ep, b, tab, npr, nt, nlev)
