@@ -24,9 +24,13 @@ def run_helios(argv=None):
     reader.read_param_file_and_command_line(keeper, reader.cloud, argv)
     if keeper.opacity_mixing in ("premixed", "synthetic"):
         reader.load_premixed_opacity_table(keeper)
+    elif keeper.opacity_mixing == "on-the-fly":
+        reader.read_species_file(keeper)
+        reader.read_species_opacities(keeper)
+        reader.read_species_scat_cross_sections(keeper)
+        reader.read_species_mixing_ratios(keeper)
     else:
-        raise IOError("on-the-fly species files are read by user code: fill Store.species_list "
-                      "(see tests/test_gpu_onthefly.py) and call the driver functions directly")
+        raise IOError("ERROR: opacity mixing must be 'premixed' or 'on-the-fly' (or 'synthetic' for generated tables)")
     reader.read_kappa_table_or_use_constant_kappa(keeper)
     reader.read_or_fill_surf_albedo_array(keeper)
     keeper.dimensions()

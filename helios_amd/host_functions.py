@@ -120,6 +120,46 @@ def interpolate_grid_to_lay_or_int(log_press, temp, table_2d, log_press_profile,
     return list(v)
 
 
+def interpolate_vmr_to_opacity_grid(read, quant, vmr):
+    """FastChem's (T, P) grid -> the opacity tables' (T, P) grid, bilinear in T and log10 P; beyond an edge of the
+    FastChem grid the nearest row/column is used (host_functions.py:783-871).  Layouts: vmr[p + np_old * t] in,
+    out[p + npress * t]."""
+    t_old, p_old = np.asarray(read.fastchem_temp, float), np.asarray(read.fastchem_press, float)
+    t_new, p_new = np.asarray(quant.ktemp, float), np.asarray(quant.kpress, float)
+    old = np.asarray(vmr, float).reshape(len(t_old), len(p_old))
+
+    def bracket(x_old, x_new):
+        """index of the last old node <= x (0 and `clamped` when there is none or it is the last node)"""
+        left = np.searchsorted(x_old, x_new, side="right") - 1
+        clamped = (left < 0) | (left == len(x_old) - 1)
+        return np.maximum(left, 0), clamped
+    tl, t_cl = bracket(t_old, t_new)
+    pl, p_cl = bracket(p_old, p_new)
+    tr, pr = np.minimum(tl + 1, len(t_old) - 1), np.minimum(pl + 1, len(p_old) - 1)
+    lp_old, lp_new = np.log10(p_old), np.log10(p_new)
+    out = np.zeros((len(t_new), len(p_new)))
+    for i in range(len(t_new)):
+        for j in range(len(p_new)):
+            a, b, c, d = tl[i], tr[i], pl[j], pr[j]
+            if p_cl[j] and t_cl[i]:
+                v = old[a, c]
+            elif t_cl[i]:
+                v = (old[a, d] * (lp_new[j] - lp_old[c]) + old[a, c] * (lp_old[d] - lp_new[j])) / (lp_old[d] - lp_old[c])
+            elif p_cl[j]:
+                v = (old[b, c] * (t_new[i] - t_old[a]) + old[a, c] * (t_old[b] - t_new[i])) / (t_old[b] - t_old[a])
+            else:
+                v = (old[b, d] * (t_new[i] - t_old[a]) * (lp_new[j] - lp_old[c])
+                     + old[b, c] * (t_new[i] - t_old[a]) * (lp_old[d] - lp_new[j])
+                     + old[a, d] * (t_old[b] - t_new[i]) * (lp_new[j] - lp_old[c])
+                     + old[a, c] * (t_old[b] - t_new[i]) * (lp_old[d] - lp_new[j])) \
+                    / ((t_old[b] - t_old[a]) * (lp_old[d] - lp_old[c]))
+            if np.isnan(v):
+                print("NaN-Error at entry with indices:", "pressure:", j, "temperature:", i)
+                raise SystemExit()
+            out[i, j] = v
+    return out.reshape(-1)
+
+
 def calculate_vmr_for_all_species(quant):
     """vertical VMR profiles of FastChem-tabulated species (host_functions.py:874-901)"""
     if quant.rt is not None:

@@ -326,6 +326,81 @@ KAPPA_KEYS = ["entr_temp", "entr_press", "entr_kappa", "entr_c_p", "entr_entropy
               "c_p_lay", "kappa_int"]
 
 
+def write_species_inputs(workdir, seed=9, nbin=6, ny=4, sorted_k=False):
+    """everything the on-the-fly readers open: species file, FastChem table, vertical-profile file, per-species opacity
+    containers and Rayleigh cross-sections (.npz with the reference's HDF5 dataset names)"""
+    rng = np.random.default_rng(seed)
+    os.makedirs(os.path.join(workdir, "opac"), exist_ok=True)
+    os.makedirs(os.path.join(workdir, "chem"), exist_ok=True)
+    with open(os.path.join(workdir, "species.dat"), "w") as f:
+        f.write("species      absorbing       scattering         mixing_ratio\n\n"
+                "H2   no  yes  FastChem\n\nH2O  yes yes FastChem\n\nCO2  yes no  file\nCH4 yes no 1e-4\n"
+                "H-   yes no  FastChem\nHe  no yes 0.15\nCIA_H2H2 yes no FastChem\nCIA_H2He yes no 0.85&0.15\n"
+                "CIA_CO2CO2 yes no file\n")
+    temps, press_bar = np.linspace(300.0, 2700.0, 5), 10.0 ** np.linspace(-5.0, 2.0, 4)
+    cols = ["H2O1", "C1O2", "H2", "He", "H1-", "H", "e-"]
+    with open(os.path.join(workdir, "chem", "chem.dat"), "w") as f:
+        f.write("#P(bar) T(k) n_<tot>(cm-3) " + " ".join(cols) + "\n")
+        for t in temps:
+            for p in press_bar:
+                f.write("%.6e %.6e %.6e " % (p, t, p * 1e6 / (1.380649e-16 * t)) +
+                        " ".join("%.8e" % v for v in 10.0 ** rng.uniform(-12, -0.5, len(cols))) + "\n")
+    with open(os.path.join(workdir, "vmr.txt"), "w") as f:
+        f.write("vertical mixing ratios\nPressure CO2 H2O\n")
+        for p in (1e-2, 1.0, 1e2, 1e4, 1e6):                       # Pa
+            f.write("%g %.6e %.6e\n" % (p, 10.0 ** rng.uniform(-6, -3), 10.0 ** rng.uniform(-6, -3)))
+    ntemp, npress = 3, 3
+    grids = {"center wavelengths": 1e-4 * 2.0 ** np.arange(nbin), "ypoints": (np.arange(ny) + 0.5) / ny,
+             "temperatures": np.array([200.0, 1000.0, 1800.0]), "pressures": np.array([1e2, 1e5, 1e8])}
+    for k, name in enumerate(("H2O", "CO2", "CH4", "H-_bf", "H-_ff", "CIA_H2H2", "CIA_H2He", "CIA_CO2CO2")):
+        d = dict(grids) if name == "H2O" else {}
+        tab = 10.0 ** rng.uniform(-8, 2, (ntemp, npress, nbin, ny))
+        if sorted_k:                # k-distributions increase with the Gauss point, as real tables do
+            tab = np.sort(tab, axis=-1)
+        d["kpoints" if k % 2 == 0 else "opacities"] = tab.reshape(-1)
+        stem = ("_opac_ip_kdistr", "_opac_ip", "_opac_ip_sampling")[k % 3]
+        np.savez(os.path.join(workdir, "opac", name + stem + ".npz"), **d)
+    np.savez(os.path.join(workdir, "opac", "scat_cross_sections.npz"),
+             rayleigh_H2=10.0 ** rng.uniform(-28, -24, nbin), rayleigh_He=10.0 ** rng.uniform(-29, -25, nbin))
+
+
+def species_reader_setup(reader, quant, workdir):
+    reader.species_file = os.path.join(workdir, "species.dat")
+    reader.fastchem_path = os.path.join(workdir, "chem") + "/"
+    reader.opacity_path = os.path.join(workdir, "opac") + "/"
+    reader.vertical_vmr_file = os.path.join(workdir, "vmr.txt")
+    reader.vertical_vmr_file_header_lines = 1
+    reader.vertical_vmr_file_press_name, reader.vertical_vmr_file_press_units = "Pressure", "Pa"
+    reader.force_eq_chem = "no"
+    quant.fl_prec = np.float64
+    quant.coupling, quant.coupling_iter_nr, quant.iso = 0, 0, np.int32(0)
+    quant.nlayer, quant.ninterface = np.int32(7), np.int32(8)
+    quant.p_boa, quant.p_toa = 1e8, 1e0
+    quant.species_list = []
+
+
+def run_species_readers(reader, quant):
+    reader.read_species_file(quant)
+    reader.read_species_opacities(quant)
+    reader.read_species_scat_cross_sections(quant)
+    reader.read_species_mixing_ratios(quant)
+
+
+def species_record(quant):
+    rec = {"names": np.array([sp.name for sp in quant.species_list]),
+           "weights": np.array([sp.weight for sp in quant.species_list], float),
+           "fc_names": np.array([str(sp.fc_name) for sp in quant.species_list])}
+    for k in ("opac_wave", "opac_interwave", "opac_deltawave", "gauss_y", "ktemp", "kpress"):
+        rec["grid." + k] = np.array(getattr(quant, k), float)
+    for n, sp in enumerate(quant.species_list):
+        for attr in ("vmr_layer", "vmr_interface", "vmr_pretab", "opacity_pretab", "scat_cross_sect_layer",
+                     "scat_cross_sect_interface"):
+            v = getattr(sp, attr, None)
+            if v is not None and len(np.atleast_1d(v)) > 0:
+                rec["%d.%s" % (n, attr)] = np.array(v, float)
+    return rec
+
+
 def reader_stub(out_dir):
     r = types.SimpleNamespace()
     r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
@@ -517,8 +592,35 @@ def main():
             q = run_clouds(ref_clouds.Cloud(), tag, wd)
         for k in CLOUD_KEYS:
             data["cloud.%s.%s" % (tag, k)] = np.array(getattr(q, k), float)
-    # kappa / c_p / entropy tables and the constant-kappa shortcut
     from source import read as ref_read2
+    # on-the-fly species readers.  The reference opens its containers with h5py (not installed); for this generator
+    # only, `h5py.File` is a thin read-only adapter over .npz files holding the same dataset names.
+    class _NpzFile(object):
+        def __init__(self, name, mode="r"):
+            path = name if os.path.exists(name) else name[:-3] + ".npz"
+            if not os.path.exists(path):
+                raise IOError(name)
+            self.d = dict(np.load(path))
+
+        def __enter__(self):
+            return self.d
+
+        def __exit__(self, *a):
+            return False
+    sys.modules["h5py"].File = _NpzFile
+    from source import quantities as ref_quant2
+    with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):
+        write_species_inputs(wd)
+        rq, rr = ref_quant2.Store(), ref_read2.Read()
+        species_reader_setup(rr, rq, wd)
+        run_species_readers(rr, rq)
+        for k, v in species_record(rq).items():
+            data["species." + k] = v
+    from source import species_database as ref_sdb
+    data["speciesdb.names"] = np.array(list(ref_sdb.species_lib.keys()))
+    data["speciesdb.fc"] = np.array([v.fc_name for v in ref_sdb.species_lib.values()])
+    data["speciesdb.weight"] = np.array([v.weight for v in ref_sdb.species_lib.values()], float)
+    # kappa / c_p / entropy tables and the constant-kappa shortcut
     for mode in ("file", "water_atmo", "0.2857"):
         with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):
             path = os.path.join(wd, "delad.dat")

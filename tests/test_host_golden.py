@@ -196,3 +196,34 @@ def test_kappa_table_reader(tmp_path, mode):
     for k in mk.KAPPA_KEYS:
         np.testing.assert_allclose(np.array(getattr(q, k), float), Z["kappa.%s.%s" % (mode, k)], rtol=1e-15, err_msg=k)
     np.testing.assert_array_equal([int(q.entr_ntemp), int(q.entr_npress)], Z["kappa.%s.dims" % mode].astype(int))
+
+
+def test_species_table_matches_reference():
+    from helios_amd.species_data import species_lib
+    names = [str(n) for n in Z["speciesdb.names"]]
+    assert sorted(species_lib) == sorted(names)
+    for n, fc, w in zip(names, Z["speciesdb.fc"], Z["speciesdb.weight"]):
+        assert species_lib[n].weight == w, n
+        want = None if "not included in FastChem" in str(fc) else str(fc)
+        assert species_lib[n].fc_name == want, n
+
+
+def test_species_readers(tmp_path):
+    """species file (H- split, absorber first), FastChem table -> opacity grid, vertical-profile file, constant and
+    pair mixing ratios, per-species opacity containers (three file-name variants, both dataset names), Rayleigh tables"""
+    from helios_amd.quantities import Store
+    from helios_amd.read import Read
+    wd = str(tmp_path)
+    mk.write_species_inputs(wd)
+    q, r = Store(), Read()
+    mk.species_reader_setup(r, q, wd)
+    mk.run_species_readers(r, q)
+    rec = mk.species_record(q)
+    want_keys = sorted(k[8:] for k in Z.files if k.startswith("species."))
+    assert sorted(rec) == want_keys
+    for k in want_keys:
+        want = Z["species." + k]
+        if want.dtype.kind in "US":
+            assert [str(v) for v in rec[k]] == [str(v) for v in want], k
+        else:
+            np.testing.assert_allclose(rec[k], want, rtol=1e-13, err_msg=k)
