@@ -147,3 +147,37 @@ def test_run_helios_with_kappa_table(tmp_path):
     np.testing.assert_array_equal(a.conv_layer, b.conv_layer)
     np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-9)
     assert a.entropy_lay.min() > 0                     # entropy diagnostic interpolated from the table
+
+
+def _host_golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "make_host_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_host_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    return mk
+
+
+def test_run_helios_on_the_fly_from_files(tmp_path):
+    """`opacity mixing = on-the-fly` end to end: species file -> FastChem / profile / constant mixing ratios ->
+    per-species containers -> species loop with random overlap on the device; fused and per-stage drivers agree"""
+    wd = str(tmp_path)
+    _host_golden_module().write_species_inputs(wd, nbin=14, ny=20, sorted_k=True)
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "on-the-fly",
+            "-path_to_species_file", os.path.join(wd, "species.dat"),
+            "-file_with_vertical_mixing_ratios", os.path.join(wd, "vmr.txt"),
+            "-directory_with_fastchem_files", os.path.join(wd, "chem") + "/",
+            "-directory_with_opacity_files", os.path.join(wd, "opac") + "/",
+            "-number_of_layers", "18", "-maximum_number_of_iterations", "20000", "-name", "otf",
+            "-output_directory", wd + "/", "-radiative_equilibrium_criterion", "1e-4",
+            "-convective_adjustment", "no", "-toa_pressure", "1e0", "-boa_pressure", "1e8"]
+    a = _run_driver(argv, True)
+    b = _run_driver(argv, False)
+    names = [sp.name for sp in a.species_list]
+    assert names[0] == "H2O" and "H-_ff" in names and len(names) == 10
+    assert int(a.iter_value) == int(b.iter_value) and int(a.iter_value) > 3
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-7)
+    np.testing.assert_allclose(a.F_up_band, b.F_up_band, rtol=1e-6, atol=1e-12 * b.F_up_band.max())
+    np.testing.assert_allclose(a.meanmolmass_lay, b.meanmolmass_lay, rtol=1e-12)
+    from helios_amd import host_functions as hs
+    assert abs(hs.global_energy_imbalance(a)) < 1e-3
