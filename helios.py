@@ -7,6 +7,7 @@ the iteration body running on the MI355X through libhelios_hip.so.
 """
 import sys
 
+from helios_amd import additional_heating as add_heat
 from helios_amd import computation as comp
 from helios_amd import host_functions as hsfunc
 from helios_amd import quantities as quant_mod
@@ -39,7 +40,10 @@ def run_helios(argv=None):
     hsfunc.set_up_numerical_parameters(keeper)
     hsfunc.construct_grid(keeper)
     hsfunc.initial_temp(keeper, reader)
+    if keeper.approx_f == 1 and keeper.planet_type == "rocky":
+        hsfunc.approx_f_from_formula(keeper, reader)
     hsfunc.calc_F_intern(keeper)
+    add_heat.load_heating_terms_or_not(keeper)
     reader.cloud.cloud_pre_processing(keeper)
 
     keeper.create_zero_arrays()
@@ -67,6 +71,8 @@ def run_helios(argv=None):
     hsfunc.calculate_conv_flux(keeper)
     hsfunc.calc_F_ratio(keeper)
     writer.write_all(keeper, reader)
+    if keeper.approx_f == 1:
+        hsfunc.calc_tau_lw_sw(keeper, reader)
     hsfunc.success_message(keeper)
     return keeper
 

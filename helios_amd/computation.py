@@ -351,6 +351,15 @@ class Compute(object):
         quant.dev_z_lay.set(quant.z_lay)
         self.calculate_direct_beamflux(quant)
 
+    def _refresh_additional_heating(self, quant):
+        """heating flux of the layers from the heating density and the current layer heights, every 10th iteration
+        (computation.py:913-918, :1127-1132)"""
+        if quant.add_heating == 1 and quant.iter_value % 10 == 0:
+            quant.delta_z_lay = quant.dev_delta_z_lay.get()
+            hsfunc.calc_add_heating_flux(quant)
+            quant.dev_F_add_heat_lay.set(np.asarray(quant.F_add_heat_lay, np.float64))
+            quant.dev_F_add_heat_sum.set(np.asarray(quant.F_add_heat_sum, np.float64))
+
     def _fused_supported(self, quant):
         return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
                 and quant.flux_calc_method == "iteration" and not self._kappa_from_table(quant)
@@ -505,6 +514,7 @@ class Compute(object):
                 abortsum = 0
                 quant.marked_red = np.zeros(L + 1, np.int32)
                 if quant.iter_value >= quant.foreplay:
+                    self._refresh_additional_heating(quant)
                     if quant.physical_tstep != 0 and quant.iter_value % 10 == 0:
                         self.interpolate_kappa_and_cp(quant)
                     self.rad_temp_iteration(quant)
@@ -597,6 +607,7 @@ class Compute(object):
             condition = (not hsfunc.check_for_radiative_eq(quant)) or (quant.iter_value < 400) or \
                         (sum(quant.conv_layer) == 0)
             if condition:
+                self._refresh_additional_heating(quant)
                 quant.dev_conv_layer.set(quant.conv_layer)
                 quant.dev_marked_red.set(quant.marked_red)
                 self.conv_temp_iteration(quant)

@@ -25,6 +25,66 @@ def planet_param(quant, read=None):
     quant.T_star = quant.fl_prec(max(quant.T_star, 2.7))
 
 
+def approx_f_from_formula(quant, read):
+    """heat-redistribution factor of a rocky planet from its longwave optical depth, Koll (2021) Eq. 10; tau_lw of a
+    previous run of the same name is picked up if its output exists (host_functions.py:51-77)"""
+    name = quant.name[:-5] if "_post" in quant.name else quant.name
+    try:
+        with open(read.output_path + name + "/" + name + "_tau_lw_tau_sw_f_factor.dat", "r") as f:
+            for line in f.readlines()[2:]:
+                quant.tau_lw = float(line.split()[0])
+        print("\ntau_lw read in from previous output file!")
+        print("\ntau_lw = ", quant.tau_lw)
+    except IOError:
+        print("\nWarning: Unable to read in tau_lw from file. Using either commandline values or starting from 1 per default.")
+    T_eq = (quant.R_star / (2 * quant.a)) ** 0.5 * quant.T_star
+    term = quant.tau_lw * (quant.p_boa / 1e6) ** (2 / 3) * (T_eq / 600) ** (-4 / 3)
+    quant.f_factor = 2 / 3 - 5 / 12 * term / (2 + term)
+
+
+def calc_planck(lamda, temp):
+    return 2 * pc.H * pc.C ** 2 / lamda ** 5 / (np.exp(pc.H * pc.C / (lamda * pc.K_B * temp)) - 1)
+
+
+def calc_tau_lw_sw(quant, read):
+    """Planck-weighted longwave (surface temperature) and shortwave (stellar temperature) optical depths of the whole
+    column, written next to the f factor for the next run of `approx_f_from_formula` (host_functions.py:92-162)"""
+    X, L = int(quant.nbin), int(quant.nlayer)
+    num_lw = denom_lw = num_sw = denom_sw = 0
+    tau_top = [sum(quant.delta_tau_band[x + i * X] for i in range(L)) for x in range(X)]
+    for x in range(X):
+        B_surf = calc_planck(quant.opac_wave[x], quant.T_lay[L])
+        num_lw += B_surf * np.exp(-tau_top[x]) * quant.opac_deltawave[x]
+        denom_lw += B_surf * quant.opac_deltawave[x]
+        if quant.T_star > 10:
+            B_star = calc_planck(quant.opac_wave[x], quant.T_star)
+            num_sw += B_star * np.exp(-tau_top[x]) * quant.opac_deltawave[x]
+            denom_sw += B_star * quant.opac_deltawave[x]
+    with np.errstate(divide="ignore"):
+        tau_lw = -np.log(num_lw / denom_lw)
+        tau_sw = -np.log(num_sw / denom_sw) if quant.T_star > 10 else 0
+    if np.isinf(tau_lw):
+        # transmission underflowed: fall back to the Planck mean of tau itself (the reference keeps adding to the
+        # running sums of the first pass, host_functions.py:134-154)
+        for x in range(X):
+            B_surf = calc_planck(quant.opac_wave[x], quant.T_lay[L])
+            num_lw += B_surf * tau_top[x] * quant.opac_deltawave[x]
+            denom_lw += B_surf * quant.opac_deltawave[x]
+            if quant.T_star > 10:
+                B_star = calc_planck(quant.opac_wave[x], quant.T_star)
+                num_sw += B_star * tau_top[x] * quant.opac_deltawave[x]
+                denom_sw += B_star * quant.opac_deltawave[x]
+        tau_lw = num_lw / denom_lw
+        tau_sw = num_sw / denom_sw if quant.T_star > 10 else 0
+    import os
+    os.makedirs(read.output_path + quant.name, exist_ok=True)
+    with open(read.output_path + quant.name + "/" + quant.name + "_tau_lw_tau_sw_f_factor.dat", "w") as f:
+        f.write("This file contains the total longwave and shortwave optical depths at BOA (=surface), tau_lw and tau_sw, "
+                "and the f factor as used in the model")
+        f.write("\n{:<15}{:<15}{:<15}".format("tau_lw", "tau_sw", "f_factor"))
+        f.write("\n{:<15g}{:<15g}{:<15g}".format(tau_lw, tau_sw, quant.f_factor))
+
+
 def calculate_pressure_levels(quant):
     """2*nlayer log-spaced levels; even = interfaces, odd = layer centres (host_functions.py:714-724)"""
     n = int(quant.nlayer)

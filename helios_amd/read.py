@@ -29,12 +29,17 @@ _OPTIONS = [
     ("BOA pressure [10^-6 bar]", "p_boa", "boa_pressure", "1e9"),
     ("run type", "run_type", "run_type", "iterative"),
     ("post-proc. --> path to temperature file", "temp_path", "path_to_temperature_file", "./output/0/0_tp.dat"),
+    ("post-proc. --> temperature file format", "temp_file_format", None, "helios"),
     ("scattering", "scat", "scattering", "yes"),
     ("direct irradiation beam", "dir_beam", "direct_irradiation_beam", "no"),
     ("no  --> f factor", "f_factor", "f_factor", "0.5"),
     ("yes --> stellar zenith angle [deg]", "zenith_angle", "stellar_zenith_angle", "60"),
     ("internal temperature [K]", "T_intern", "internal_temperature", "30"),
     ("surface albedo", "input_surf_albedo", "surface_albedo", "0.0"),
+    ("file --> path to albedo file", "albedo_file", "path_to_albedo_file", "./input/albedo.dat"),
+    ("file --> albedo file format", "albedo_file_format", None, "2 Wavelength micron"),
+    ("file --> surface name", "albedo_file_surface_name", "surface_name", "Feldspathic"),
+    ("rocky planet --> use f approximation formula", "approx_f", "use_f_approximation_formula", "no"),
     ("opacity mixing", "opacity_mixing", "opacity_mixing", "premixed"),
     ("premixed   --> path to opacity file", "ktable_path", "path_to_opacity_file", "./input/r50_kdistr_solar_eq.h5"),
     ("on-the-fly --> path to species file", "species_file", "path_to_species_file", "./input/species.dat"),
@@ -46,6 +51,8 @@ _OPTIONS = [
     ("kappa value", "input_kappa_value", "kappa_value", "0.285714"),
     ("file --> kappa file path", "entr_kappa_path", "kappa_file_path", "./input/delad_example.dat"),
     ("stellar spectral model", "stellar_model", "stellar_spectral_model", "blackbody"),
+    ("file --> path to stellar spectrum file", "stellar_path", "path_to_stellar_spectrum_file", "./input/star_2022.h5"),
+    ("file --> dataset in stellar spectrum file", "stellar_data_set", "dataset_in_stellar_spectrum_file", "/r50_kdistr/phoenix/gj1214"),
     ("planet", "planet", "planet", "manual"),
     ("manual --> surface gravity [cm s^-2]", "g", "surface_gravity", "1000"),
     ("manual --> orbital distance [AU]", "a", "orbital_distance", "0.05"),
@@ -86,7 +93,10 @@ _OPTIONS = [
     ("number of prerun timesteps", "foreplay", "number_of_prerun_timesteps", "0"),
     ("physical timestep [s]", "physical_tstep", "physical_timestep", "no"),
     ("number --> runtime limit [s]", "runtime_limit", "runtime_limit", "86400"),
+    ("number --> start from provided TP profile", "force_start_tp_from_file", "start_from_provided_tp_profile", "no"),
     ("include additional heating", "add_heating", "include_additional_heating", "no"),
+    ("yes --> path to heating file", "add_heating_path", "path_to_heating_file", "./input/heating_file.txt"),
+    ("yes --> heating file format", "add_heating_file_format", None, "1 Pressure cgs Heating 1e7"),
     # extensions for synthetic inputs (not in the reference)
     ("synthetic --> bins layers-are-set-above ntemp npress seed", "synthetic_spec", "synthetic", "300 30 20 20241"),
 ]
@@ -174,12 +184,21 @@ class Read(object):
         quant.p_toa, quant.p_boa = f64(val["p_toa"]), f64(val["p_boa"])
         quant.run_type = val["run_type"]
         self.temp_path = val["temp_path"]
+        tf = str(val["temp_file_format"]).split()
+        self.temp_format = tf[0]
+        self.temp_pressure_unit = tf[1] if len(tf) > 1 else "[helios,"      # the reference reads the next token, whatever it is
         quant.scat = _yes_no(val["scat"])
         quant.dir_beam = _yes_no(val["dir_beam"])
         quant.f_factor = f64(val["f_factor"])
         zenith_angle = f64(val["zenith_angle"])
         quant.T_intern = f64(val["T_intern"])
         self.input_surf_albedo = val["input_surf_albedo"]
+        self.albedo_file = val["albedo_file"]
+        af = str(val["albedo_file_format"]).split()
+        self.albedo_file_header_lines = int(af[0])
+        self.albedo_file_wavelength_name, self.albedo_file_wavelength_unit = af[1], af[2]
+        self.albedo_file_surface_name = val["albedo_file_surface_name"]
+        quant.approx_f = _yes_no(val["approx_f"])
         quant.opacity_mixing = val["opacity_mixing"]
         self.ktable_path = val["ktable_path"]
         self.species_file = val["species_file"]
@@ -193,6 +212,7 @@ class Read(object):
         quant.input_kappa_value = val["input_kappa_value"]
         self.entr_kappa_path = val["entr_kappa_path"]
         self.stellar_model = val["stellar_model"]
+        self.stellar_path, self.stellar_data_set = val["stellar_path"], val["stellar_data_set"]
         quant.planet = val["planet"]
         quant.g, quant.a = f64(val["g"]), f64(val["a"])
         quant.R_planet, quant.R_star, quant.T_star = f64(val["R_planet"]), f64(val["R_star"]), f64(val["T_star"])
@@ -242,7 +262,12 @@ class Read(object):
         quant.physical_tstep = f64(0 if val["physical_tstep"] == "no" else val["physical_tstep"])
         quant.runtime_limit = f64(val["runtime_limit"])
         quant.add_heating = _yes_no(val["add_heating"])
-        quant.force_start_tp_from_file = i32(0)
+        quant.add_heating_path = val["add_heating_path"]
+        hf = str(val["add_heating_file_format"]).split()
+        quant.add_heating_file_header_lines = int(hf[0])
+        quant.add_heating_file_press_name, quant.add_heating_file_press_unit = hf[1], hf[2]
+        quant.add_heating_file_data_name, quant.add_heating_file_data_conv_factor = hf[3], f64(hf[4])
+        quant.force_start_tp_from_file = _yes_no(val["force_start_tp_from_file"])
         quant.coupling = i32(0)
         quant.realtime_plot = i32(0)
         self.synthetic_spec = val["synthetic_spec"]
@@ -549,34 +574,86 @@ class Read(object):
                     sp.scat_cross_sect_interface = np.array(sp.scat_cross_sect_pretab * int(quant.ninterface), quant.fl_prec)
 
     def read_star(self, quant):
+        """stellar spectrum on the opacity wavelength grid from an HDF5 / .npz container, or the black-body flag"""
         if self.stellar_model == "blackbody":
             quant.starflux = np.zeros(int(quant.nbin), quant.fl_prec)
             quant.real_star = np.int32(0)
+            print("\nUsing blackbody flux for the stellar irradiation.")
         elif self.stellar_model == "file":
             d = self._open_table(self.stellar_path)
-            quant.starflux = np.asarray(d[self.stellar_data_set], np.float64)
+            key = self.stellar_data_set if self.stellar_data_set in d else str(self.stellar_data_set).strip("/")
+            if key not in d:
+                raise IOError("There is no such stellar spectrum found. Please check file path and data set.")
+            quant.starflux = np.asarray(d[key], np.float64)
             quant.real_star = np.int32(1)
+            print("\nReading", str(self.stellar_path) + str(self.stellar_data_set), "as spectral model of the host star.")
             if len(quant.starflux) != quant.nbin:
-                raise OverflowError("Stellar spectrum and opacity files have different lengths.")
+                raise OverflowError("Stellar spectrum and opacity files have different lengths. Please double-check your "
+                                    "input files.")
         else:
             raise IOError("Unknown Stellar model. Please check your input.")
 
+    @staticmethod
+    def _profile_on(x_file, y_file, x_new):
+        """linear interpolation as the reference's `interp1d(..., fill_value=(y[-1], y[0]))` does it: beyond the low
+        end of x the LAST tabulated value, beyond the high end the FIRST (files are usually ordered top-down)"""
+        x_file, y_file, x_new = np.asarray(x_file, float), np.asarray(y_file, float), np.asarray(x_new, float)
+        order = np.argsort(x_file)
+        v = np.interp(x_new, x_file[order], y_file[order])
+        v = np.where(x_new < x_file.min(), y_file[-1], v)
+        return np.where(x_new > x_file.max(), y_file[0], v)
+
     def read_or_fill_surf_albedo_array(self, quant):
-        """scalar albedo clamped to [1e-8, 0.999] (read.py:1258-1264)"""
-        a = max(1e-8, min(0.999, float(self.input_surf_albedo)))
-        quant.surf_albedo = np.ones(int(quant.nbin)) * a
+        """scalar albedo clamped to [1e-8, 0.999], or a surface's column of an albedo file on the model's bins
+        (read.py:1238-1264; beyond the file's range its first / last value)"""
+        if str(self.input_surf_albedo) == "file":
+            tab = np.genfromtxt(self.albedo_file, names=True, dtype=None, skip_header=self.albedo_file_header_lines)
+            lam = np.array(tab[self.albedo_file_wavelength_name], float)
+            lam *= {"micron": 1e-4, "m": 1e2}.get(self.albedo_file_wavelength_unit, 1.0)
+            alb = np.array(tab[self.albedo_file_surface_name], float)
+            order = np.argsort(lam)
+            quant.surf_albedo = np.interp(np.asarray(quant.opac_wave, float), lam[order], alb[order],
+                                          left=alb[0], right=alb[-1])
+        else:
+            self.input_surf_albedo = max(1e-8, min(0.999, quant.fl_prec(self.input_surf_albedo)))
+            quant.surf_albedo = np.ones(int(quant.nbin)) * self.input_surf_albedo
+
+    @staticmethod
+    def interpolate_to_own_press(old_press, old_array, new_press):
+        return Read._profile_on(np.log10(np.asarray(old_press, float)), old_array, np.log10(np.asarray(new_press, float)))
 
     def read_temperature_file(self, quant):
-        """HELIOS `_tp.dat` restart format: two header lines, then 'BOA' + layer rows (read.py:1274-1322)"""
-        T = []
-        with open(self.temp_path) as f:
-            next(f)
-            next(f)
-            for line in f:
+        """a T-P profile for post-processing or restarts: `helios` (a `_tp.dat` output: two header lines; columns
+        layer, T, P), `TP` or `PT` (two numeric columns, pressure in cgs or bar); interpolated in log10 P onto
+        [BOA interface, layer centres] (read.py:1274-1322)"""
+        T, P = [], []
+        try:
+            with open(self.temp_path, "r") as f:
+                lines = f.readlines()
+        except IOError:
+            print("ABORT - TP file not found!")
+            raise SystemExit()
+        if self.temp_format == "helios":
+            for line in lines[2:]:
                 col = line.split()
-                if len(col) > 1:
-                    T.append(float(col[1]))
-        quant.T_restart = T
+                T.append(quant.fl_prec(col[1]))
+                P.append(quant.fl_prec(col[2]))
+        else:       # the reference's `elif temp_format == 'TP' or 'PT'` accepts anything else as two-column
+            for line in lines:
+                col = line.split()
+                try:
+                    float(col[0])
+                except (ValueError, IndexError):
+                    continue
+                if self.temp_format == "TP":
+                    T.append(quant.fl_prec(col[0]))
+                    P.append(quant.fl_prec(col[1]))
+                elif self.temp_format == "PT":
+                    P.append(quant.fl_prec(col[0]))
+                    T.append(quant.fl_prec(col[1]))
+            if self.temp_pressure_unit == "bar":
+                P = [p * 1e6 for p in P]
+        quant.T_restart = self.interpolate_to_own_press(P, T, [quant.p_int[0]] + list(quant.p_lay))
 
     def read_planet_database(self, quant):
         raise IOError("planet database look-ups are outside this build's scope; use planet = manual")

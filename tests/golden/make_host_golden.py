@@ -401,6 +401,57 @@ def species_record(quant):
     return rec
 
 
+def write_misc_inputs(workdir, seed=13):
+    """albedo file, T-P files in the three accepted formats, heating file, stellar spectrum container"""
+    rng = np.random.default_rng(seed)
+    with open(os.path.join(workdir, "albedo.dat"), "w") as f:
+        f.write("# surface albedos\n# source: synthetic\nWavelength Basaltic Granitoid\n")
+        for lam in (0.3, 0.5, 1.0, 2.0, 5.0, 12.0, 25.0):
+            f.write("%g %.5f %.5f\n" % (lam, rng.uniform(0.02, 0.4), rng.uniform(0.1, 0.7)))
+    press = 10.0 ** np.linspace(8.2, -0.5, 12)                      # cgs, bottom-up like a HELIOS output
+    temp = rng.uniform(400, 2200, 12)
+    with open(os.path.join(workdir, "tp_helios.dat"), "w") as f:
+        f.write("header one\nlayer temp press altitude\n")
+        f.write("BOA %.6f %.6e 0\n" % (temp[0], press[0]))
+        for i in range(1, 12):
+            f.write("%d %.6f %.6e %g\n" % (i - 1, temp[i], press[i], 1e5 * i))
+    with open(os.path.join(workdir, "tp_TP.dat"), "w") as f:
+        f.write("# T[K] P[bar]\n")
+        for t, p in zip(temp[::-1], press[::-1]):
+            f.write("%.6f %.6e\n" % (t, p / 1e6))
+    with open(os.path.join(workdir, "tp_PT.dat"), "w") as f:
+        f.write("pressure temperature\n")
+        for t, p in zip(temp, press):
+            f.write("%.6e %.6f\n" % (p, t))
+    with open(os.path.join(workdir, "heating.txt"), "w") as f:
+        f.write("extra heating\nPressure Heating Other\n")
+        for p in (1e-3, 1e-1, 1e1, 1e3):                          # bar
+            f.write("%g %.5e %g\n" % (p, 10.0 ** rng.uniform(-9, -5), 1.0))
+    np.savez(os.path.join(workdir, "star.npz"), **{"/grid/some_star": 10.0 ** rng.uniform(3, 7, 9)})
+
+
+def misc_state():
+    q = types.SimpleNamespace()
+    q.fl_prec = np.float64
+    q.nbin, q.nlayer = np.int32(9), np.int32(6)
+    q.opac_wave = 1e-4 * 0.2 * 2.2 ** np.arange(9)                 # 0.2 ... 110 micron: wider than the albedo file
+    lev = [3e7 * (2.0 / 3e7) ** (i / 11) for i in range(12)]
+    q.p_lay, q.p_int = lev[1::2], lev[0::2] + [1.5]
+    q.add_heating = np.int32(1)
+    q.add_heating_file_header_lines, q.add_heating_file_press_name = 1, "Pressure"
+    q.add_heating_file_press_unit, q.add_heating_file_data_name = "bar", "Heating"
+    q.add_heating_file_data_conv_factor = np.float64(1e7)
+    q.delta_z_lay = np.linspace(2e5, 9e6, 6)
+    q.F_add_heat_lay = np.zeros(6)
+    q.F_add_heat_sum = np.zeros(6)
+    # rocky-planet f approximation
+    q.name, q.R_star, q.a, q.T_star, q.p_boa, q.tau_lw, q.f_factor = "rock", 3.2e10, 3.5e11, 3300.0, 3e7, 1, 0.6667
+    q.delta_tau_band = 10.0 ** np.random.default_rng(5).uniform(-4, 1.5, 9 * 6)
+    q.opac_deltawave = q.opac_wave * 0.7
+    q.T_lay = np.linspace(900, 500, 7)
+    return q
+
+
 def reader_stub(out_dir):
     r = types.SimpleNamespace()
     r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
@@ -620,6 +671,39 @@ def main():
     data["speciesdb.names"] = np.array(list(ref_sdb.species_lib.keys()))
     data["speciesdb.fc"] = np.array([v.fc_name for v in ref_sdb.species_lib.values()])
     data["speciesdb.weight"] = np.array([v.weight for v in ref_sdb.species_lib.values()], float)
+    # albedo file, T-P files, heating file, stellar spectrum, rocky-planet f approximation
+    from source import additional_heating as ref_heat
+    with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):
+        write_misc_inputs(wd)
+        for surface in ("Basaltic", "Granitoid"):
+            q, r = misc_state(), ref_read2.Read()
+            r.input_surf_albedo, r.albedo_file = "file", os.path.join(wd, "albedo.dat")
+            r.albedo_file_header_lines, r.albedo_file_wavelength_name = 2, "Wavelength"
+            r.albedo_file_wavelength_unit, r.albedo_file_surface_name = "micron", surface
+            r.read_or_fill_surf_albedo_array(q)
+            data["misc.albedo." + surface] = np.array(q.surf_albedo, float)
+        for fmt, unit in (("helios", "[helios,"), ("TP", "bar"), ("PT", "cgs")):
+            q, r = misc_state(), ref_read2.Read()
+            r.temp_path, r.temp_format, r.temp_pressure_unit = os.path.join(wd, "tp_%s.dat" % fmt), fmt, unit
+            r.read_temperature_file(q)
+            data["misc.T_restart." + fmt] = np.array(q.T_restart, float)
+        q = misc_state()
+        q.add_heating_path = os.path.join(wd, "heating.txt")
+        ref_heat.load_heating_terms_or_not(q)
+        hs.calc_add_heating_flux(q)
+        data["misc.add_heat_dens"] = np.array(q.add_heat_dens, float)
+        data["misc.F_add_heat_lay"] = np.array(q.F_add_heat_lay, float)
+        data["misc.F_add_heat_sum"] = np.array(q.F_add_heat_sum, float)
+        q, r = misc_state(), ref_read2.Read()
+        r.stellar_model, r.stellar_path, r.stellar_data_set = "file", os.path.join(wd, "star.h5"), "/grid/some_star"
+        r.read_star(q)
+        data["misc.starflux"] = np.array(q.starflux, float)
+        q, r = misc_state(), types.SimpleNamespace(output_path=wd + "/")
+        os.makedirs(os.path.join(wd, "rock"))
+        hs.calc_tau_lw_sw(q, r)
+        data["misc.tau_file"] = np.array(open(os.path.join(wd, "rock", "rock_tau_lw_tau_sw_f_factor.dat")).read())
+        hs.approx_f_from_formula(q, r)
+        data["misc.f_factor"] = np.array([q.tau_lw, q.f_factor], float)
     # kappa / c_p / entropy tables and the constant-kappa shortcut
     for mode in ("file", "water_atmo", "0.2857"):
         with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):

@@ -181,3 +181,27 @@ def test_run_helios_on_the_fly_from_files(tmp_path):
     np.testing.assert_allclose(a.meanmolmass_lay, b.meanmolmass_lay, rtol=1e-12)
     from helios_amd import host_functions as hs
     assert abs(hs.global_energy_imbalance(a)) < 1e-3
+
+
+def test_run_helios_with_additional_heating(tmp_path):
+    """a heating-density file (e.g. UV heating of the upper atmosphere): per-stage loop, flux refreshed from the layer
+    heights every 10th iteration; in equilibrium the atmosphere radiates the extra energy away"""
+    wd = str(tmp_path)
+    with open(os.path.join(wd, "heating.txt"), "w") as f:      # default format: 1 header line, cgs pressure, x 1e7
+        f.write("heating density in J m^-3 s^-1... times 1e7\nPressure Heating\n")
+        for p, h in ((1e-1, 3e-12), (1e1, 1e-11), (1e3, 3e-12), (1e5, 1e-13), (1e9, 1e-16)):
+            f.write("%g %g\n" % (p, h))
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
+            "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "heat",
+            "-output_directory", wd + "/", "-radiative_equilibrium_criterion", "1e-5", "-convective_adjustment", "no"]
+    hot = _run_driver(argv + ["-include_additional_heating", "yes", "-path_to_heating_file",
+                              os.path.join(wd, "heating.txt")], True)
+    cold = _run_driver(argv, True)
+    extra = hot.F_add_heat_sum[-1]
+    assert extra > 0 and np.all(hot.add_heat_dens > 0)
+    L = int(hot.nlayer)
+    # net flux leaving the top = internal flux + everything deposited below
+    scale = hot.F_down_tot[L] + hot.F_intern
+    assert abs(hot.F_net[L] - (hot.F_intern + extra)) < 1e-4 * scale
+    assert abs(cold.F_net[L] - cold.F_intern) < 1e-4 * scale
+    assert hot.T_lay[:L].mean() > cold.T_lay[:L].mean()

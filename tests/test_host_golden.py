@@ -227,3 +227,43 @@ def test_species_readers(tmp_path):
             assert [str(v) for v in rec[k]] == [str(v) for v in want], k
         else:
             np.testing.assert_allclose(rec[k], want, rtol=1e-13, err_msg=k)
+
+
+def test_albedo_temperature_heating_star_files(tmp_path):
+    from helios_amd import additional_heating as heat
+    from helios_amd.read import Read
+    wd = str(tmp_path)
+    mk.write_misc_inputs(wd)
+    for surface in ("Basaltic", "Granitoid"):
+        q, r = mk.misc_state(), Read()
+        r.input_surf_albedo, r.albedo_file = "file", os.path.join(wd, "albedo.dat")
+        r.albedo_file_header_lines, r.albedo_file_wavelength_name = 2, "Wavelength"
+        r.albedo_file_wavelength_unit, r.albedo_file_surface_name = "micron", surface
+        r.read_or_fill_surf_albedo_array(q)
+        np.testing.assert_allclose(q.surf_albedo, Z["misc.albedo." + surface], rtol=1e-14)
+    for fmt, unit in (("helios", "[helios,"), ("TP", "bar"), ("PT", "cgs")):
+        q, r = mk.misc_state(), Read()
+        r.temp_path, r.temp_format, r.temp_pressure_unit = os.path.join(wd, "tp_%s.dat" % fmt), fmt, unit
+        r.read_temperature_file(q)
+        np.testing.assert_allclose(q.T_restart, Z["misc.T_restart." + fmt], rtol=1e-13, err_msg=fmt)
+    q = mk.misc_state()
+    q.add_heating_path = os.path.join(wd, "heating.txt")
+    heat.load_heating_terms_or_not(q)
+    hs.calc_add_heating_flux(q)
+    for k in ("add_heat_dens", "F_add_heat_lay", "F_add_heat_sum"):
+        np.testing.assert_allclose(getattr(q, k), Z["misc." + k], rtol=1e-13, err_msg=k)
+    q, r = mk.misc_state(), Read()
+    r.stellar_model, r.stellar_path, r.stellar_data_set = "file", os.path.join(wd, "star.npz"), "/grid/some_star"
+    r.read_star(q)
+    np.testing.assert_allclose(q.starflux, Z["misc.starflux"], rtol=0)
+    assert int(q.real_star) == 1
+
+
+def test_rocky_planet_f_approximation(tmp_path):
+    import types
+    q, r = mk.misc_state(), types.SimpleNamespace(output_path=str(tmp_path) + "/")
+    hs.calc_tau_lw_sw(q, r)
+    got = open(os.path.join(str(tmp_path), "rock", "rock_tau_lw_tau_sw_f_factor.dat")).read()
+    assert got == str(Z["misc.tau_file"])
+    hs.approx_f_from_formula(q, r)
+    np.testing.assert_allclose([q.tau_lw, q.f_factor], Z["misc.f_factor"], rtol=1e-14)
