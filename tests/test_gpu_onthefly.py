@@ -205,3 +205,23 @@ def test_run_helios_with_additional_heating(tmp_path):
     assert abs(hot.F_net[L] - (hot.F_intern + extra)) < 1e-4 * scale
     assert abs(cold.F_net[L] - cold.F_intern) < 1e-4 * scale
     assert hot.T_lay[:L].mean() > cold.T_lay[:L].mean()
+
+
+def test_run_helios_post_processing_of_a_converged_profile(tmp_path):
+    """`run type = post-processing`: the T-P profile of a finished run is read back from its `_tp.dat`, layers are
+    isothermal, one pass with 1000*scat+1 sweeps.  The converged multiple-scattering solution leaves the emission spectrum
+    of the iterative run (non-isothermal layers, persistent flux state) within a few per cent."""
+    wd = str(tmp_path)
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
+            "-number_of_layers", "40", "-maximum_number_of_iterations", "20000", "-output_directory", wd + "/",
+            "-radiative_equilibrium_criterion", "1e-5", "-convective_adjustment", "no"]
+    it = _run_driver(base + ["-name", "run"], True)
+    pp = _run_driver(base + ["-name", "run_post", "-run_type", "post-processing", "-path_to_temperature_file",
+                             os.path.join(wd, "run", "run_tp.dat")], True)
+    assert int(pp.singlewalk) == 1 and int(pp.iso) == 1
+    np.testing.assert_allclose(pp.T_lay, it.T_lay, rtol=1e-5)          # the text file carries 6 significant digits of T and P
+    X, L = int(it.nbin), int(it.nlayer)
+    a, b = pp.F_up_band[L * X:], it.F_up_band[L * X:]
+    assert np.all(np.isfinite(a)) and a.min() >= 0
+    assert abs(a @ it.opac_deltawave - b @ it.opac_deltawave) < 0.05 * (b @ it.opac_deltawave)
+    assert os.path.getsize(os.path.join(wd, "run_post", "run_post_contribution.dat")) > 100
