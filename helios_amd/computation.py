@@ -552,12 +552,84 @@ class Compute(object):
             dev = getattr(quant, "dev_" + n)
             setattr(quant, n, dev.get())
 
+    def _convection_loop_fused(self, quant, write=None, read=None):
+        """the convection loop on the device-resident state: convective adjustment, sweeps, layer marking, equilibrium
+        test and temperature step all run on the GPU (hx_rt_conv_*); the host only paces the loop in chunks that end at
+        refresh boundaries, criterion relaxations and the iteration limit (reference computation.py:992-1174)"""
+        rt = quant.rt
+        L = _i(quant.nlayer)
+        for n in ("T_lay", "F_net", "F_up_tot", "F_down_tot"):
+            setattr(quant, n, rt.get(n))
+        quant.p_lay, quant.p_int = np.asarray(quant.p_lay, float), np.asarray(quant.p_int, float)
+        hsfunc.conv_check(quant)
+        hsfunc.mark_convective_layers(quant, stitching=0)
+        condition = sum(quant.conv_unstable) > 0
+        quant.iter_value = np.int32(0)
+        if not condition:
+            print("\nAll layers convectively stable. No convective adjustment necessary.\n")
+            print("\nTime for rad.-conv. iteration [s]: {:.2f}".format(0.0))
+            print("Total number of iterative steps: " + str(quant.iter_value))
+            return
+        print("\nConvectively unstable layers found. Starting convective adjustment")
+        rt.set_state(0, "kappa_lay", np.asarray(quant.kappa_lay, np.float64))
+        rt.set_state(0, "kappa_int", np.asarray(quant.kappa_int, np.float64))
+        rt.set_state(0, "c_p_lay", np.asarray(quant.c_p_lay, np.float64))
+        rt.set_state(0, "conv_layer", np.asarray(quant.conv_layer, np.int32))
+        rt.set_state(0, "conv_unstable", np.asarray(quant.conv_unstable, np.int32))
+        dampara = -1.0 if quant.input_dampara == "automatic" else float(quant.input_dampara)
+        rt.set_state(0, "dampara", np.array([dampara], np.float64))
+        rt.set_state(0, "done", np.zeros(1, np.int32))
+        rt.set_convergence_limit(0, quant.rad_convergence_limit)
+        fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in quant.species_list)
+        self.ctx.timer_start()
+        it, done = 0, 0
+        while not done:
+            if it % 100 == 0:
+                print("\nWe are running \"" + str(quant.name) + "\" at iteration step nr. : " + str(it))
+            nxt = min(it + (10 - it % 10), _i(quant.max_nr_iterations) + 1)
+            for r in quant.crit_relaxation_numbers:
+                if it < r < nxt:
+                    nxt = int(r)
+            if quant.opacity_mixing == "on-the-fly" and it % 10 == 0 and fastchem:
+                # mixing ratios follow the profile: once before the adjustment (for the mean molecular mass), once
+                # for the adjusted profile that the refresh sees (computation.py:1030-1036, :1056-1061)
+                self._push_vmr(quant)
+                rt.conv_adjust(it)
+                self._push_vmr(quant)
+                rt.conv_advance(it)
+                rt.conv_run(it + 1, nxt - it - 1)
+            else:
+                rt.conv_run(it, nxt - it)
+            it = nxt
+            done = int(rt.get("done")[0])                        # one small D2H per <= 10 iterations
+            if done:
+                it = int(rt.get("iters_done")[0])
+            if it in quant.crit_relaxation_numbers:
+                hsfunc.relax_radiative_convergence_criterion(quant)
+                rt.set_convergence_limit(0, quant.rad_convergence_limit)
+            if it > quant.max_nr_iterations:
+                if write is not None:
+                    write.write_abort_file(quant, read)
+                print("\nRun exceeds allowed maximum allowed number of iteration steps. Aborting...")
+                raise SystemExit()
+        quant.iter_value = np.int32(it)
+        ms = self.ctx.timer_stop_ms()
+        quant.conv_layer = rt.get("conv_layer")
+        quant.conv_unstable = rt.get("conv_unstable")
+        quant.marked_red = rt.get("marked_red")
+        quant.dev_F_smooth_sum.set(rt.get("F_smooth_sum"))
+        print("\nTime for rad.-conv. iteration [s]: {:.2f}".format(ms * 1e-3))
+        print("Total number of iterative steps: " + str(quant.iter_value))
+        self.sync_store_from_rt(quant)
+
     def convection_loop(self, quant, write=None, read=None, rt_plot=None):
-        """alternate convective adjustment (host) and radiative steps (device), reference
-        computation.py:992-1174.  The device work goes through the per-stage entry points: the host
-        rewrites T_lay every iteration, so nothing can stay resident across iterations except the tables."""
+        """alternate convective adjustment and radiative steps, reference computation.py:992-1174: on the fused,
+        device-resident state when the radiation loop ran there, else through the per-stage entry points with the
+        adjustment on the host"""
         if not (quant.singlewalk == 0 and quant.convection == 1):
             return
+        if self._fused_supported(quant) and quant.rt is not None and quant.physical_tstep == 0:
+            return self._convection_loop_fused(quant, write, read)
         L = _i(quant.nlayer)
         self.interpolate_kappa_and_cp(quant)
         quant.T_lay = quant.dev_T_lay.get()

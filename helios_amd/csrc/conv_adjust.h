@@ -1,0 +1,221 @@
+// Convective adjustment on the device: the reference does this on the host between two
+// kernel launches of every convection-loop iteration (source/host_functions.py:337-635, :251-286; driver
+// source/computation.py:992-1174).  Here one workgroup per column runs it, so that the fused path needs no
+// host round trip inside the convection loop either.
+//
+// The logic is sequential over at most a few hundred layers and is executed by thread 0 exactly in the
+// order of helios_amd/host_functions.py (which tests/test_host_golden.py pins to the reference's Python);
+// only the pressure-ratio powers -- independent of temperature -- are tabulated by all threads first:
+//     lim+(i) = (T[i] * f1p[i]) * f2p[i]   adiabat through layer i, kappa * (1 + 1e-6)   (conv_check)
+//     lim-(i) = (T[i] * f1m[i]) * f2m[i]   the same with kappa * (1 - 1e-6)              (mark_convective_layers)
+//     up[i]   = (p_lay[i]/p_int[i])^kappa_int[i],  nxt[i] = (p_int[i+1]/p_lay[i])^kappa_lay[i]   (conv_correct)
+#pragma once
+#include "hx_common.h"
+
+namespace hx {
+
+constexpr int CONV_MAXL = 512;  // = the fused path's layer limit
+
+struct ConvTables {  // LDS
+    double f1p[CONV_MAXL], f2p[CONV_MAXL], f1m[CONV_MAXL], f2m[CONV_MAXL], up[CONV_MAXL], nxt[CONV_MAXL];
+    double surf_p, surf_m;
+    double fac[CONV_MAXL];              // scratch of conv_correct
+    int in_zone[CONV_MAXL + 2];         // scratch: flagged layers, index i + 1 (the surface is i = -1)
+    int starts[CONV_MAXL / 2 + 2], ends[CONV_MAXL / 2 + 2];
+};
+
+struct ConvColumn {  // pointers of ONE column
+    double* T;                           // [L+1], surface last
+    const double *p_lay, *p_int;         // [L], [L+1]
+    const double *kappa_lay, *kappa_int; // [L], [L+1]
+    const double *c_p, *mmm;             // [L]
+    const double *F_add_heat_sum, *F_smooth_sum;  // [L]
+    const double *F_down_tot, *F_up_tot, *F_net;  // [L+1]
+    int *conv_unstable, *conv_layer, *marked_red; // [L+1]
+    int L, itervalue;
+    double F_intern, T_star, dampara;    // dampara <= 0: automatic
+    double rad_convergence_limit;
+};
+
+// all threads; needs a barrier afterwards
+__device__ inline void conv_build_tables(const ConvColumn& c, ConvTables& t, int tid, int nthr) {
+    const int L = c.L;
+    for (int i = tid; i < L; i += nthr) {
+        t.up[i] = pow(c.p_lay[i] / c.p_int[i], c.kappa_int[i]);
+        t.nxt[i] = pow(c.p_int[i + 1] / c.p_lay[i], c.kappa_lay[i]);
+        if (i < L - 1) {
+            const double r1 = c.p_int[i + 1] / c.p_lay[i], r2 = c.p_lay[i + 1] / c.p_int[i + 1];
+            t.f1p[i] = pow(r1, c.kappa_lay[i] * (1 + 1e-6));
+            t.f2p[i] = pow(r2, c.kappa_int[i + 1] * (1 + 1e-6));
+            t.f1m[i] = pow(r1, c.kappa_lay[i] * (1 - 1e-6));
+            t.f2m[i] = pow(r2, c.kappa_int[i + 1] * (1 - 1e-6));
+        }
+    }
+    if (tid == 0) {
+        t.surf_p = pow(c.p_lay[0] / c.p_int[0], c.kappa_int[0] * (1 + 1e-6));
+        t.surf_m = pow(c.p_lay[0] / c.p_int[0], c.kappa_int[0] * (1 - 1e-6));
+    }
+}
+
+// ---- everything below: one thread -------------------------------------------------------------------------
+
+// host_functions.py:337-365; returns the number of flagged entries
+__device__ inline int conv_check(const ConvColumn& c, const ConvTables& t) {
+    const int L = c.L;
+    int n = 0;
+    for (int i = 0; i <= L; i++) c.conv_unstable[i] = 0;
+    for (int i = 0; i < L - 1; i++) {
+        if (c.p_lay[i] <= 1e1) break;  // the top of the atmosphere is left alone
+        if (c.T[i + 1] < (c.T[i] * t.f1p[i]) * t.f2p[i]) {
+            c.conv_unstable[i] = 1;
+            c.conv_unstable[i + 1] = 1;
+        }
+    }
+    if (c.T[0] < c.T[L] * t.surf_p) {
+        c.conv_unstable[L] = 1;
+        c.conv_unstable[0] = 1;
+    }
+    for (int i = 0; i <= L; i++) n += c.conv_unstable[i];
+    return n;
+}
+
+// host_functions.py:585-635: radiative gaps thinner than one scale height between two zones are closed
+__device__ inline void conv_stitch_holes(const ConvColumn& c, ConvTables& t) {
+    const int L = c.L;
+    int ns = 0, ne = 0;
+    if (c.conv_layer[L] == 1) {
+        t.starts[ns++] = -1;
+        if (c.conv_layer[0] == 0) t.ends[ne++] = -1;
+    }
+    for (int i = 0; i < L; i++) {
+        if (c.conv_layer[i] != 1) continue;
+        const int below = i > 0 ? c.conv_layer[i - 1] : c.conv_layer[L];
+        if (below == 0) t.starts[ns++] = i;
+        if (i == L - 1 || c.conv_layer[i + 1] == 0) t.ends[ne++] = i;
+    }
+    if (ns != ne) return;  // the reference aborts here; cannot happen for consistent flags
+    for (int n = 0; n + 1 < ns; n++) {
+        const double p_top = c.p_lay[t.starts[n + 1]];
+        const double p_bot = t.ends[n] != -1 ? c.p_lay[t.ends[n]] : c.p_int[0];
+        if (p_top / p_bot > 1 / 2.718281828459045)
+            for (int m = t.ends[n] + 1; m < t.starts[n + 1]; m++) c.conv_layer[m] = 1;
+    }
+}
+
+// host_functions.py:545-582
+__device__ inline void conv_mark_layers(const ConvColumn& c, ConvTables& t, int stitching) {
+    const int L = c.L;
+    c.conv_layer[L] = 0;
+    c.conv_layer[0] = 0;
+    for (int i = 0; i < L - 1; i++) {
+        if (c.p_lay[i] <= 1e1) break;
+        if (c.T[i + 1] < (c.T[i] * t.f1m[i]) * t.f2m[i]) {
+            c.conv_layer[i] = 1;
+            c.conv_layer[i + 1] = 1;
+        } else {
+            c.conv_layer[i + 1] = 0;
+        }
+    }
+    for (int i = 0; i < L - 1; i++)  // no temperature kinks at the top edge of a zone
+        if (c.T[i + 1] > c.T[i]) c.conv_layer[i] = 0;
+    if (c.T[0] < c.T[L] * t.surf_m) {
+        c.conv_layer[L] = 1;
+        c.conv_layer[0] = 1;
+    }
+    if (stitching == 1 && c.itervalue > 5000) conv_stitch_holes(c, t);
+}
+
+// contiguous runs of flagged layers, the surface "ghost layer" (index L) counted as layer -1
+__device__ inline int conv_zones(const ConvColumn& c, ConvTables& t) {
+    const int L = c.L;
+    for (int i = 0; i < L; i++) t.in_zone[i + 1] = (c.conv_unstable[i] == 1 || c.conv_layer[i] == 1) ? 1 : 0;
+    t.in_zone[0] = (c.conv_unstable[L] == 1 || c.conv_layer[L] == 1) ? 1 : 0;
+    t.in_zone[L + 1] = 0;
+    int ns = 0, ne = 0;
+    for (int i = -1; i < L; i++) {
+        if (!t.in_zone[i + 1]) continue;
+        if (i == -1 || !t.in_zone[i]) t.starts[ns++] = i;
+        if (!t.in_zone[i + 2]) t.ends[ne++] = i;
+    }
+    return ns == ne ? ns : 0;
+}
+
+// host_functions.py:368-506: every zone goes onto the adiabat of its enthalpy-conserving mean potential temperature
+__device__ inline void conv_correct(const ConvColumn& c, ConvTables& t, int fudging) {
+    const int L = c.L;
+    const int nz = conv_zones(c, t);
+    for (int n = 0; n < nz; n++) {
+        double fudge = 1.0;
+        if (fudging == 1) {
+            // flux test at an interface inside the radiative zone above zone n (or well above the top zone)
+            int test = 0;
+            for (int m = n; m < nz; m++) {
+                if (m != nz - 1) {
+                    const double p_top = c.p_lay[t.starts[m + 1]];
+                    const double p_bot = t.ends[m] != -1 ? c.p_lay[t.ends[m]] : c.p_int[0];
+                    if (p_top / p_bot < 1 / 2.718281828459045) {
+                        test = (int)((t.ends[m] + t.starts[m + 1]) / 2.0);
+                        break;
+                    }
+                } else {
+                    test = (int)(0.8 * t.ends[m] + 0.2 * L);  // ninterface - 1 = L
+                }
+            }
+            double dampara = c.dampara;
+            if (!(dampara > 0)) dampara = c.T_star > 10 ? (n < nz - 1 ? 0.5 : 4.0) : 8.0;
+            const int below = test - 1 >= 0 ? test - 1 : test - 1 + L;  // numpy wraps a negative index
+            const double ratio = (c.F_intern + c.F_add_heat_sum[below] + c.F_smooth_sum[below] + c.F_down_tot[test]) /
+                                 c.F_up_tot[test];
+            const double f = pow(ratio, 1.0 / dampara);
+            const double lo = f > 0.99 ? f : 0.99;  // Python's max(0.99, f): NaN -> 0.99
+            fudge = lo < 1.01 ? lo : 1.01;
+        }
+        const int a = t.starts[n] > 0 ? t.starts[n] : 0, b = t.ends[n] > 0 ? t.ends[n] : 0;
+        double num = 0.0, den = 0.0, chain = 1.0;
+        for (int i = a; i <= b; i++) {
+            const double cp_mu = c.c_p[i] / c.mmm[i], dp = c.p_int[i] - c.p_int[i + 1];
+            const double fac = chain * t.up[i];
+            t.fac[i] = fac;
+            num += cp_mu * c.T[i] * dp;
+            den += fac * cp_mu * dp;
+            chain *= t.up[i] * t.nxt[i];
+        }
+        const double theta = num / den * fudge;
+        for (int i = a; i <= b; i++) c.T[i] = theta * t.fac[i];
+        if (t.starts[n] == -1) c.T[L] = theta;
+    }
+}
+
+// host_functions.py:509-542
+__device__ inline void convective_adjustment(const ConvColumn& c, ConvTables& t) {
+    int unstable = conv_check(c, t);
+    int guard = 0;
+    while (unstable > 0 && guard++ < 100000) {
+        conv_mark_layers(c, t, 0);
+        conv_correct(c, t, 0);
+        unstable = conv_check(c, t);
+    }
+    conv_mark_layers(c, t, 1);
+    conv_correct(c, t, 1);
+}
+
+// host_functions.py:251-286: local radiative equilibrium of the non-convective layers; fills marked_red
+__device__ inline int conv_radiative_eq(const ConvColumn& c) {
+    const int L = c.L;
+    const double norm = c.F_down_tot[L] + c.F_intern;
+    int converged = 0, convective = 0;
+    for (int i = 0; i <= L; i++) {
+        c.marked_red[i] = 0;
+        convective += c.conv_layer[i];
+        if (c.conv_layer[i] != 0) continue;
+        const double dF = i < L ? fabs(c.F_intern + c.F_add_heat_sum[i] + c.F_smooth_sum[i] - c.F_net[i + 1])
+                                : fabs(c.F_intern - c.F_net[0]);
+        if (dF < c.rad_convergence_limit * norm)
+            converged++;
+        else
+            c.marked_red[i] = 1;
+    }
+    return converged == (L + 1) - convective ? 1 : 0;
+}
+
+}  // namespace hx

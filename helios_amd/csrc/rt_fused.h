@@ -94,6 +94,9 @@ struct hx_rt {
     double *F_add_heat_lay = nullptr, *F_add_heat_sum = nullptr, *F_smooth = nullptr,
            *F_smooth_sum = nullptr, *c_p_lay = nullptr;                                         // L
     int *abort_flags = nullptr, *conv_count = nullptr, *done = nullptr, *iters_done = nullptr;  // L+1,1,1,1
+    // convection loop (hx_rt_conv_*): adiabatic coefficients, layer flags, damping parameter of the flux fudging
+    double *kappa_lay = nullptr, *kappa_int = nullptr, *dampara = nullptr;                     // L, I, 1
+    int *conv_unstable = nullptr, *conv_layer = nullptr, *marked_red = nullptr;                  // L+1 each
 
     // profiling
     bool profiling = false;

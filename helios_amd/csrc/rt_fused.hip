@@ -252,6 +252,30 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
         default: fn<16>(rt, a); break;            \
     }
 
+// mean molecular mass of column c from its mixing ratios (layers, and interfaces if asked)
+int meanmolmass_from_vmr(hx_rt* rt, int c, bool interfaces) {
+    hx_context* ctx = rt->ctx;
+    const int S = rt->d.nspecies, I = rt->I;
+    const double* vl = rt->vmr_lay + (size_t)c * S * I;
+    const double* vi = rt->vmr_int + (size_t)c * S * I;
+    std::vector<double> w(S);
+    std::vector<int> inmu(S);
+    for (int s = 0; s < S; s++) { w[s] = rt->species[s].weight; inmu[s] = rt->species[s].in_mu; }
+    double* dw = nullptr; int* dm = nullptr;
+    HX_HIP(ctx, hipMalloc((void**)&dw, S * 8));
+    HX_HIP(ctx, hipMalloc((void**)&dm, S * 4));
+    h2d(rt, dw, w.data(), S * 8);
+    h2d(rt, dm, inmu.data(), S * 4);
+    k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vl, dw, dm, rt->mmm_lay + (size_t)c * I, S, I);
+    if (interfaces)
+        k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vi, dw, dm, rt->mmm_int + (size_t)c * I, S, I);
+    HX_LAUNCH_CHECK(ctx);
+    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dw);
+    (void)hipFree(dm);
+    return 0;
+}
+
 int set_flux_shmem_limits(hx_rt* rt) {
     const size_t shmem = flux_shmem_bytes(rt);
     if (shmem > 160 * 1024) return rt_fail(rt, HX_E_UNSUPPORTED, "workgroup LDS demand exceeds 160 KiB");
@@ -350,6 +374,8 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     RT_ALLOC(rt->F_add_heat_lay, C * L); RT_ALLOC(rt->F_add_heat_sum, C * L);
     RT_ALLOC(rt->F_smooth, C * L); RT_ALLOC(rt->F_smooth_sum, C * L); RT_ALLOC(rt->c_p_lay, C * L);
     RT_ALLOC(rt->abort_flags, C * (L + 1)); RT_ALLOC(rt->conv_count, C); RT_ALLOC(rt->done, C);
+    RT_ALLOC(rt->kappa_lay, C * L); RT_ALLOC(rt->kappa_int, C * I); RT_ALLOC(rt->dampara, C);
+    RT_ALLOC(rt->conv_unstable, C * (L + 1)); RT_ALLOC(rt->conv_layer, C * (L + 1)); RT_ALLOC(rt->marked_red, C * (L + 1));
     RT_ALLOC(rt->iters_done, C);
     {
         TPIndex* t1 = nullptr; TPIndex* t2 = nullptr;
@@ -638,22 +664,8 @@ int hx_rt_refresh(hx_rt* rt) {
             const int S = rt->d.nspecies;
             const double* vl = rt->vmr_lay + (size_t)c * S * I;
             const double* vi = rt->vmr_int + (size_t)c * S * I;
-            {   // mean molecular mass from the mixing ratios (host_functions.py:913-959)
-                std::vector<double> w(S);
-                std::vector<int> inmu(S);
-                for (int s = 0; s < S; s++) { w[s] = rt->species[s].weight; inmu[s] = rt->species[s].in_mu; }
-                double* dw = nullptr; int* dm = nullptr;
-                HX_HIP(ctx, hipMalloc((void**)&dw, S * 8));
-                HX_HIP(ctx, hipMalloc((void**)&dm, S * 4));
-                h2d(rt, dw, w.data(), S * 8);
-                h2d(rt, dm, inmu.data(), S * 4);
-                k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vl, dw, dm, mml, S, I);
-                k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vi, dw, dm, mmi, S, I);
-                HX_LAUNCH_CHECK(ctx);
-                HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                (void)hipFree(dw);
-                (void)hipFree(dm);
-            }
+            rc = meanmolmass_from_vmr(rt, c, true);   // host_functions.py:913-959
+            if (rc) return rc;
             hx_memset0(ctx, opl, wgI * 8);
             hx_memset0(ctx, opi, wgI * 8);
             hx_memset0(ctx, scl, bandI * 8);
@@ -810,6 +822,114 @@ int hx_rt_step(hx_rt* rt, int itervalue, int step_temperature) {
     return rt_step_kernels(rt, itervalue, step_temperature, nodes_done);
 }
 
+// ---- convection loop (reference computation.py:992-1174) -------------------------------------------------
+namespace {
+
+ConvKArgs make_conv_args(hx_rt* rt, int itervalue) {
+    ConvKArgs c;
+    memset(&c, 0, sizeof(c));
+    c.L = rt->L; c.C = rt->C; c.itervalue = itervalue;
+    c.colpar = rt->colpar;
+    c.T_lay = rt->T_lay; c.p_lay = rt->p_lay; c.p_int = rt->p_int;
+    c.kappa_lay = rt->kappa_lay; c.kappa_int = rt->kappa_int;
+    c.c_p = rt->c_p_lay; c.mmm_lay = rt->mmm_lay;
+    c.F_add_heat_sum = rt->F_add_heat_sum; c.F_smooth_sum = rt->F_smooth_sum;
+    c.F_down_tot = rt->F_down_tot; c.F_up_tot = rt->F_up_tot; c.F_net = rt->F_net;
+    c.conv_unstable = rt->conv_unstable; c.conv_layer = rt->conv_layer; c.marked_red = rt->marked_red;
+    c.dampara = rt->dampara;
+    c.done = rt->done;
+    return c;
+}
+
+}  // namespace
+
+// first half of one iteration: [every 10th: mean molecular mass at the current temperatures] and the convective
+// adjustment of the temperature profile (computation.py:1027-1047)
+int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
+    hx_context* ctx = rt->ctx;
+    HX_REQUIRE(ctx, rt->have_grid && rt->have_tables, HX_E_STATE, "hx_rt_conv_adjust before the tables are set");
+    if (itervalue % 10 == 0) {   // computation.py:1030-1036: mu of the profile BEFORE the adjustment
+        for (int c = 0; c < rt->C; c++) {
+            int rc = rt->d.nspecies == 0
+                         ? hx_meanmolmass_interpol(ctx, rt->T_lay + (size_t)c * (rt->L + 1), rt->ktemp,
+                                                   rt->mmm_lay + (size_t)c * rt->I, rt->opac_meanmass,
+                                                   rt->p_lay + (size_t)c * rt->L, rt->kpress, rt->d.npress,
+                                                   rt->d.ntemp, rt->L)
+                         : meanmolmass_from_vmr(rt, c, false);
+            if (rc) return rc;
+        }
+    }
+    ProfScope ps(rt, "rt_conv_adjust");
+    k_rt_conv_adjust<<<rt->C, 256, 0, ctx->stream>>>(make_conv_args(rt, itervalue));
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// second half: interface temperatures and Planck function of the adjusted profile, [every 10th: refresh], the
+// two-stream sweeps, totals, convective-layer marking, equilibrium test and -- unless that ends the loop -- the
+// temperature step (computation.py:1048-1145).  A column whose loop has ended is frozen (`done`, `iters_done`).
+int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
+    hx_context* ctx = rt->ctx;
+    bool nodes_done = false;
+    if (itervalue % 10 == 0 || !rt->refreshed) {
+        int rc = hx_rt_refresh(rt);
+        if (rc) return rc;
+        nodes_done = true;
+    }
+    KArgs a = make_args(rt);
+    if (!nodes_done) {
+        ProfScope ps(rt, "rt_nodes");
+        dim3 grid(hx_cdiv(rt->X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
+        k_rt_nodes<<<grid, 256, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "rt_flux");
+        DISPATCH_ROWS(launch_flux, rt, a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "rt_totals_a");
+        k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "rt_totals_c");
+        TotalsCArgs q;
+        q.a = a;
+        q.cv = make_conv_args(rt, itervalue);
+        memset(&q.ct, 0, sizeof(q.ct));
+        q.ct.F_net_diff = rt->F_net_diff;
+        q.ct.tlay = rt->T_lay;
+        q.ct.play = rt->p_lay;
+        q.ct.pint = rt->p_int;
+        q.ct.T_store = rt->T_store;
+        q.ct.deltat_prefactor = rt->prefactor;
+        q.ct.F_add_heat_lay = rt->F_add_heat_lay;
+        q.ct.F_smooth = rt->F_smooth;
+        q.ct.F_smooth_sum = rt->F_smooth_sum;
+        q.ct.nlayer = rt->L;
+        q.ct.itervalue = itervalue;
+        q.ct.smooth = rt->f.smooth;
+        q.done_w = rt->done;
+        q.iters_done = rt->iters_done;
+        q.physical_tstep_on = rt->cols[0].physical_tstep != 0 ? 1 : 0;
+        k_rt_totals_c<<<rt->C, 1024, 0, ctx->stream>>>(q);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    return 0;
+}
+
+int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps) {
+    for (int n = 0; n < nsteps; n++) {
+        int rc = hx_rt_conv_adjust(rt, itervalue + n);
+        if (rc) return rc;
+        rc = hx_rt_conv_advance(rt, itervalue + n);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
     for (int n = 0; n < nsteps; n++) {
         int rc = hx_rt_step(rt, itervalue + n, 1);
@@ -940,6 +1060,10 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
     if (n == "planck_grid")
         return get_plain(rt, rt->planck_grid, (size_t)(rt->d.plancktable_dim + 1) * X * 8, out, out_bytes);
     if (n == "done") return get_plain(rt, rt->done + c, 4, out, out_bytes);
+    if (n == "conv_layer") return get_plain(rt, rt->conv_layer + c * (L + 1), (L + 1) * 4, out, out_bytes);
+    if (n == "conv_unstable") return get_plain(rt, rt->conv_unstable + c * (L + 1), (L + 1) * 4, out, out_bytes);
+    if (n == "marked_red") return get_plain(rt, rt->marked_red + c * (L + 1), (L + 1) * 4, out, out_bytes);
+    if (n == "F_smooth_sum") return get_plain(rt, rt->F_smooth_sum + c * L, L * 8, out, out_bytes);
     if (n == "planckband_lay" || n == "planckband_int") {
         // from the node array Bn[x][H+3]: layers = odd nodes, then star, surface; interfaces = even
         const bool lay = n == "planckband_lay";
@@ -1016,6 +1140,18 @@ int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t
         } else if (n == "done") {
             if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "done expects one int32");
             rc |= h2d(rt, rt->done + c, in, 4);
+        } else if (n == "kappa_lay") {
+            if (in_bytes != L * 8) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for kappa_lay");
+            rc |= h2d(rt, rt->kappa_lay + c * L, in, in_bytes);
+        } else if (n == "kappa_int") {
+            if (in_bytes != (L + 1) * 8) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for kappa_int");
+            rc |= h2d(rt, rt->kappa_int + c * (L + 1), in, in_bytes);
+        } else if (n == "conv_layer" || n == "conv_unstable") {
+            if (in_bytes != (L + 1) * 4) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for %s", name);
+            rc |= h2d(rt, (n == "conv_layer" ? rt->conv_layer : rt->conv_unstable) + c * (L + 1), in, in_bytes);
+        } else if (n == "dampara") {
+            if (in_bytes != 8) return hx_fail(rt->ctx, HX_E_ARG, "dampara expects one double (<= 0: automatic)");
+            rc |= h2d(rt, rt->dampara + c, in, 8);
         } else {
             return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_set_state: unknown name '%s'", name);
         }

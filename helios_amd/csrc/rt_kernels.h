@@ -14,6 +14,7 @@
 // two-stream correction E == 1 and K = 2 pi eps is a constant, so the v' plane is not stored then.
 #pragma once
 #include "rt_fused.h"
+#include "conv_adjust.h"
 #include "temp_step.h"
 #include "two_stream.h"
 
@@ -710,6 +711,145 @@ __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
         q.done_w[col] = 1;  // the reference leaves radiation_loop once every flag is set
         q.iters_done[col] = r.itervalue + 1;
     }
+}
+
+// ---- convection loop on the device (reference computation.py:992-1174) ---------------------------------------
+struct ConvKArgs {
+    int L, C, itervalue;
+    const hx_rt_column* colpar;
+    double* T_lay;                          // [C][L+1]
+    const double *p_lay, *p_int;            // [C][L], [C][L+1]
+    const double *kappa_lay, *kappa_int;    // [C][L], [C][L+1]
+    const double *c_p, *mmm_lay;            // [C][L], [C][L+1]
+    const double *F_add_heat_sum, *F_smooth_sum;
+    const double *F_down_tot, *F_up_tot, *F_net;
+    int *conv_unstable, *conv_layer, *marked_red;  // [C][L+1]
+    const double* dampara;                  // [C], <= 0: automatic
+    const int* done;
+};
+
+__device__ __forceinline__ ConvColumn conv_column(const ConvKArgs& a, int col) {
+    const size_t L = a.L, I = a.L + 1;
+    const hx_rt_column cp = a.colpar[col];
+    ConvColumn c;
+    c.T = a.T_lay + col * I;
+    c.p_lay = a.p_lay + col * L;
+    c.p_int = a.p_int + col * I;
+    c.kappa_lay = a.kappa_lay + col * L;
+    c.kappa_int = a.kappa_int + col * I;
+    c.c_p = a.c_p + col * L;
+    c.mmm = a.mmm_lay + col * I;
+    c.F_add_heat_sum = a.F_add_heat_sum + col * L;
+    c.F_smooth_sum = a.F_smooth_sum + col * L;
+    c.F_down_tot = a.F_down_tot + col * I;
+    c.F_up_tot = a.F_up_tot + col * I;
+    c.F_net = a.F_net + col * I;
+    c.conv_unstable = a.conv_unstable + col * I;
+    c.conv_layer = a.conv_layer + col * I;
+    c.marked_red = a.marked_red + col * I;
+    c.L = a.L;
+    c.itervalue = a.itervalue;
+    c.F_intern = cp.F_intern;
+    c.T_star = cp.T_star;
+    c.dampara = a.dampara[col];
+    c.rad_convergence_limit = cp.rad_convergence_limit;
+    return c;
+}
+
+// step E of the loop: check -> mark -> correct until stable, then once more with stitching and flux fudging.
+// grid C, 256 threads: all of them tabulate the pressure-ratio powers, thread 0 walks the layers.
+__global__ void __launch_bounds__(256) k_rt_conv_adjust(ConvKArgs a) {
+    __shared__ ConvTables t;
+    const int col = blockIdx.x;
+    if (a.done[col]) return;
+    const ConvColumn c = conv_column(a, col);
+    conv_build_tables(c, t, threadIdx.x, blockDim.x);
+    __syncthreads();
+    if (threadIdx.x == 0) convective_adjustment(c, t);
+}
+
+struct TotalsCArgs {
+    KArgs a;
+    ConvKArgs cv;
+    ConvTempArgs ct;   // pointers of column 0
+    int* done_w;
+    int* iters_done;
+    int physical_tstep_on;
+};
+
+// steps H (totals), I, J, K: wavelength totals, mark the convective layers, test the radiative layers for local
+// equilibrium, and -- unless the column is done -- the radiative temperature step of the convection loop
+__global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
+    __shared__ ConvTables t;
+    __shared__ double seg[4][256];
+    __shared__ int s_go;
+    const KArgs& a = q.a;
+    const int col = blockIdx.x;
+    if (a.done[col]) return;
+    const int I = a.I, L = a.L;
+    double* up = a.F_up_tot + (size_t)col * I;
+    double* down = a.F_down_tot + (size_t)col * I;
+    double* net = a.F_net + (size_t)col * I;
+    for (int t0 = 0; t0 < 2 * I; t0 += 256) {
+        const int ts = t0 + (threadIdx.x & 255), sgm = threadIdx.x >> 8;
+        const int cper = (a.nchunk + 3) / 4, c0 = sgm * cper, c1 = min(a.nchunk, c0 + cper);
+        double s = 0.0;
+        if (ts < 2 * I) {
+            const double* __restrict__ part = a.tot_part + ((size_t)col * a.nchunk * 2) * I + ts;
+            for (int cb = c0; cb < c1; cb += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = part[(size_t)min(cb + u, c1 - 1) * 2 * I];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (cb + u < c1) s += v[u];
+            }
+        }
+        seg[sgm][threadIdx.x & 255] = s;
+        __syncthreads();
+        if (sgm == 0 && ts < 2 * I) {
+            const double tot = ((seg[0][threadIdx.x] + seg[1][threadIdx.x]) + seg[2][threadIdx.x]) + seg[3][threadIdx.x];
+            if (ts < I) down[ts] = tot; else up[ts - I] = tot;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < I; i += blockDim.x) net[i] = up[i] - down[i];
+    const ConvColumn c = conv_column(q.cv, col);
+    conv_build_tables(c, t, threadIdx.x, blockDim.x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        conv_mark_layers(c, t, 1);
+        int go = 0;
+        if (!q.physical_tstep_on) {  // with a physical time step the reference leaves the loop here
+            int convective = 0;
+            for (int i = 0; i <= L; i++) convective += c.conv_layer[i];
+            const int eq = conv_radiative_eq(c);
+            go = (!eq) || (c.itervalue < 400) || (convective == 0);
+        }
+        if (!go) {
+            q.done_w[col] = 1;
+            q.iters_done[col] = c.itervalue;   // no temperature step, no increment: the loop exits here
+        }
+        s_go = go;
+    }
+    __syncthreads();
+    if (!s_go) return;
+    const hx_rt_column cp = a.colpar[col];
+    ConvTempArgs r = q.ct;
+    r.F_net = net;
+    r.F_net_diff += (size_t)col * L;
+    r.tlay += (size_t)col * (L + 1);
+    r.play += (size_t)col * L;
+    r.pint += (size_t)col * I;
+    r.T_store += (size_t)col * (L + 1);
+    r.deltat_prefactor += (size_t)col * (L + 1);
+    r.marked_red = c.marked_red;
+    r.F_add_heat_lay += (size_t)col * L;
+    r.F_smooth += (size_t)col * L;
+    r.F_smooth_sum += (size_t)col * L;
+    r.adapt_interval = cp.adapt_interval;
+    r.F_intern = cp.F_intern;
+    conv_temp_step(r, threadIdx.x, blockDim.x);
 }
 
 // altitude of the layer centres from the layer thicknesses (host_functions.py:673-698), one thread

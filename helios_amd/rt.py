@@ -152,6 +152,15 @@ class RTBatch(object):
     def run(self, itervalue, nsteps):
         self._ck(self._l.hx_rt_run(self.handle, int(itervalue), int(nsteps)), "hx_rt_run")
 
+    def conv_adjust(self, itervalue):
+        self._ck(self._l.hx_rt_conv_adjust(self.handle, int(itervalue)), "hx_rt_conv_adjust")
+
+    def conv_advance(self, itervalue):
+        self._ck(self._l.hx_rt_conv_advance(self.handle, int(itervalue)), "hx_rt_conv_advance")
+
+    def conv_run(self, itervalue, nsteps):
+        self._ck(self._l.hx_rt_conv_run(self.handle, int(itervalue), int(nsteps)), "hx_rt_conv_run")
+
     def converged_layers(self):
         out = np.zeros(self.ncol, np.int32)
         self._ck(self._l.hx_rt_converged_layers(self.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))),
@@ -179,6 +188,8 @@ class RTBatch(object):
             "F_up_wg": (wg, np.float64), "F_down_wg": (wg, np.float64), "Fc_up_wg": (wg, np.float64),
             "Fc_down_wg": (wg, np.float64), "F_dir_wg": (wg, np.float64), "Fc_dir_wg": (wg, np.float64),
             "iters_done": (1, np.int32), "done": (1, np.int32),
+            "conv_layer": (L + 1, np.int32), "conv_unstable": (L + 1, np.int32), "marked_red": (L + 1, np.int32),
+            "F_smooth_sum": (L, np.float64),
             "planck_grid": ((self.dims.plancktable_dim + 1) * X, np.float64),
         }
         return table[name]

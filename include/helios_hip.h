@@ -356,13 +356,24 @@ int hx_rt_refresh(hx_rt* rt);
 int hx_rt_step(hx_rt* rt, int itervalue, int step_temperature);
 /* nsteps iterations starting at `itervalue`, refreshing whenever iter % 10 == 0; no host sync */
 int hx_rt_run(hx_rt* rt, int itervalue, int nsteps);
+/* Convection loop (computation.py:992-1174) without host round trips.  One iteration = hx_rt_conv_adjust (convective
+ * adjustment of the profile: host_functions.py:337-635 run by one workgroup per column) + hx_rt_conv_advance (T_int,
+ * Planck, [refresh], sweeps, totals, mark_convective_layers, check_for_radiative_eq, conv_temp_iter).  The two halves
+ * are separate so that a host step (FastChem mixing ratios of the adjusted profile) can sit between them; hx_rt_conv_run
+ * chains them.  When the reference's loop condition turns false the column is frozen ("done" = 1, "iters_done" = the
+ * reference's final iter_value).  Inputs beyond the radiation loop's: hx_rt_set_state "kappa_lay", "kappa_int",
+ * "conv_layer" (flags persist between iterations), "dampara" (<= 0: the reference's automatic choice). */
+int hx_rt_conv_adjust(hx_rt* rt, int itervalue);
+int hx_rt_conv_advance(hx_rt* rt, int itervalue);
+int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps);
 /* number of layers (+ghost layer) per column whose convergence flag is set: out[ncol] (blocks) */
 int hx_rt_converged_layers(hx_rt* rt, int* out_counts);
 /* named read-back in the reference's layout: "T_lay","T_int","F_up_band","F_down_band",
  * "F_dir_band","F_up_tot","F_down_tot","F_net","F_net_diff","planckband_lay","planckband_int",
  * "opac_wg_lay","opac_wg_int","scat_cross_lay","scat_cross_int","meanmolmass_lay",
  * "meanmolmass_int","F_up_wg","F_down_wg","Fc_up_wg","Fc_down_wg","F_dir_wg","Fc_dir_wg","abort",
- * "delta_z_lay","z_lay","g_0_tot_lay","g_0_tot_int","delta_t_prefactor","T_store".
+ * "delta_z_lay","z_lay","g_0_tot_lay","g_0_tot_int","delta_t_prefactor","T_store","F_smooth_sum",
+ * "conv_layer","conv_unstable","marked_red" (int32[nlayer+1]),"done","iters_done".
  * `out` is a HOST buffer of `out_bytes`; returns HX_E_ARG if the name is unknown or the size wrong. */
 int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes);
 int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes);

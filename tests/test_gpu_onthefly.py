@@ -225,3 +225,88 @@ def test_run_helios_post_processing_of_a_converged_profile(tmp_path):
     assert np.all(np.isfinite(a)) and a.min() >= 0
     assert abs(a @ it.opac_deltawave - b @ it.opac_deltawave) < 0.05 * (b @ it.opac_deltawave)
     assert os.path.getsize(os.path.join(wd, "run_post", "run_post_contribution.dat")) > 100
+
+
+CONV_ARGV = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",
+             "-number_of_layers", "25", "-maximum_number_of_iterations", "20000", "-name", "cv",
+             "-radiative_equilibrium_criterion", "1e-4", "-internal_temperature", "1500", "-kappa_value", "0.2"]
+
+
+@pytest.mark.parametrize("extra", [[], ["-direct_irradiation_beam", "yes", "-surface_albedo", "0.2"]])
+def test_convection_loop_on_device_reaches_the_host_driven_equilibrium(tmp_path, extra):
+    """the convection loop with the convective adjustment on the GPU (hx_rt_conv_*) against the per-stage loop whose
+    adjustment runs in helios_amd/host_functions.py.  The loop amplifies 1e-10 differences through its discrete
+    decisions (time-step adaptation, layer flags) -- trajectories part after ~50 iterations and meet again at the
+    equilibrium, so the END states are compared (the step-by-step identity is the next test)."""
+    argv = CONV_ARGV + ["-output_directory", str(tmp_path) + "/"] + extra
+    a = _run_driver(argv, True)
+    b = _run_driver(argv, False)
+    assert a.conv_layer.sum() > 2 and int(a.iter_value) >= 400 and int(b.iter_value) >= 400
+    assert abs(int(a.iter_value) - int(b.iter_value)) < 0.5 * int(b.iter_value)
+    np.testing.assert_array_equal(a.conv_layer, b.conv_layer)
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=2e-4)
+    np.testing.assert_allclose(a.F_up_band, b.F_up_band, rtol=2e-3, atol=1e-9 * b.F_up_band.max())
+    from helios_amd import host_functions as hs
+    for q in (a, b):
+        assert abs(hs.global_energy_imbalance(q)) < 1e-3
+        q.kappa_int = np.full(int(q.ninterface), 0.2)
+        hs.conv_check(q)
+        assert q.conv_unstable.sum() == 0
+
+
+@pytest.mark.parametrize("extra", [[], ["-tp_profile_smoothing", "yes"], ["-convective_damping_parameter", "2.5"]])
+def test_convection_steps_on_device_match_host_functions(tmp_path, extra):
+    """every half-step of the device loop against helios_amd/host_functions.py (pinned to the reference's Python) on
+    IDENTICAL inputs: the adjusted profile to round-off, unstable / convective / not-converged flags exactly; 25
+    iterations cross two refresh boundaries"""
+    import helios
+    from helios_amd import computation, host_functions as hs
+    captured = {}
+    orig = computation.Compute.convection_loop
+
+    def stop(self, quant, write=None, read=None, rt_plot=None):
+        captured["q"] = quant
+        raise KeyboardInterrupt
+    computation.Compute.convection_loop = stop
+    try:
+        helios.run_helios(CONV_ARGV + ["-output_directory", str(tmp_path) + "/"] + extra)
+    except KeyboardInterrupt:
+        pass
+    finally:
+        computation.Compute.convection_loop = orig
+    q = captured["q"]
+    rt = q.rt
+    for n in ("T_lay", "F_net", "F_up_tot", "F_down_tot", "F_smooth_sum", "meanmolmass_lay"):
+        setattr(q, n, rt.get(n))
+    q.p_lay, q.p_int = np.asarray(q.p_lay, float), np.asarray(q.p_int, float)
+    hs.conv_check(q)
+    hs.mark_convective_layers(q, stitching=0)
+    assert q.conv_unstable.sum() > 0
+    for name, v in (("kappa_lay", q.kappa_lay), ("kappa_int", q.kappa_int), ("c_p_lay", q.c_p_lay)):
+        rt.set_state(0, name, np.asarray(v, np.float64))
+    rt.set_state(0, "conv_layer", np.asarray(q.conv_layer, np.int32))
+    rt.set_state(0, "conv_unstable", np.asarray(q.conv_unstable, np.int32))
+    rt.set_state(0, "dampara", np.array([-1.0 if q.input_dampara == "automatic" else float(q.input_dampara)]))
+    rt.set_state(0, "done", np.zeros(1, np.int32))
+    for it in range(25):
+        for n in ("T_lay", "F_net", "F_up_tot", "F_down_tot", "F_smooth_sum"):
+            setattr(q, n, rt.get(n))
+        q.conv_layer = rt.get("conv_layer").copy()
+        q.iter_value = it
+        rt.conv_adjust(it)
+        q.meanmolmass_lay = rt.get("meanmolmass_lay")        # what the adjustment saw on the device
+        hs.convective_adjustment(q)
+        T_dev = rt.get("T_lay")
+        np.testing.assert_allclose(T_dev, q.T_lay, rtol=1e-13, err_msg="adjusted profile, iteration %d" % it)
+        np.testing.assert_array_equal(rt.get("conv_layer"), q.conv_layer)
+        np.testing.assert_array_equal(rt.get("conv_unstable"), q.conv_unstable)
+        rt.conv_advance(it)
+        for n in ("F_net", "F_up_tot", "F_down_tot"):
+            setattr(q, n, rt.get(n))
+        q.T_lay = T_dev.copy()
+        hs.mark_convective_layers(q, stitching=1)
+        crit = hs.check_for_radiative_eq(q)
+        np.testing.assert_array_equal(rt.get("conv_layer"), q.conv_layer)
+        np.testing.assert_array_equal(rt.get("marked_red"), q.marked_red)
+        assert int(rt.get("done")[0]) == 0 and crit in (0, 1)      # iter < 400: the loop must go on
+        assert np.abs(rt.get("T_lay") - T_dev).max() > 0            # and the temperature step was taken
