@@ -14,14 +14,12 @@
 
 namespace hx {
 
-constexpr int CONV_MAXL = 512;  // = the fused path's layer limit
-
-struct ConvTables {  // LDS
-    double f1p[CONV_MAXL], f2p[CONV_MAXL], f1m[CONV_MAXL], f2m[CONV_MAXL], up[CONV_MAXL], nxt[CONV_MAXL];
+struct ConvTables {  // all in LDS, carved by conv_stage_in
+    double *f1p, *f2p, *f1m, *f2m, *up, *nxt;
+    double* fac;                        // scratch of conv_correct
     double surf_p, surf_m;
-    double fac[CONV_MAXL];              // scratch of conv_correct
-    int in_zone[CONV_MAXL + 2];         // scratch: flagged layers, index i + 1 (the surface is i = -1)
-    int starts[CONV_MAXL / 2 + 2], ends[CONV_MAXL / 2 + 2];
+    int* in_zone;                       // scratch: flagged layers, index i + 1 (the surface is i = -1)
+    int *starts, *ends;
 };
 
 struct ConvColumn {  // pointers of ONE column
@@ -37,23 +35,72 @@ struct ConvColumn {  // pointers of ONE column
     double rad_convergence_limit;
 };
 
-// all threads; needs a barrier afterwards
-__device__ inline void conv_build_tables(const ConvColumn& c, ConvTables& t, int tid, int nthr) {
-    const int L = c.L;
+// LDS demand in bytes for a column of L layers
+__host__ __device__ inline size_t conv_smem_bytes(int L) {
+    return (size_t)(17 * (L + 2)) * sizeof(double) + (size_t)(5 * (L + 2)) * sizeof(int);
+}
+
+// All threads.  Copies the column's small arrays into LDS (the sequential walk of thread 0 would otherwise pay a
+// global-memory round trip per access), carves the tables and fills them; `c` then points into LDS, `g` keeps the
+// global pointers for conv_stage_out.  Ends with a barrier.
+__device__ inline void conv_stage_in(ConvColumn& c, ConvColumn& g, ConvTables& t, double* smem, int tid, int nthr) {
+    g = c;
+    const int L = c.L, n1 = L + 2;
+    double* d = smem;
+    t.f1p = d; d += n1; t.f2p = d; d += n1; t.f1m = d; d += n1; t.f2m = d; d += n1;
+    t.up = d; d += n1; t.nxt = d; d += n1; t.fac = d; d += n1;
+    double* T = d; d += n1;
+    double* p_lay = d; d += n1; double* p_int = d; d += n1; double* c_p = d; d += n1; double* mmm = d; d += n1;
+    double* fah = d; d += n1; double* fss = d; d += n1; double* fd = d; d += n1; double* fu = d; d += n1;
+    double* fn = d; d += n1;
+    int* ip = reinterpret_cast<int*>(d);
+    int* unstable = ip; ip += n1; int* layer = ip; ip += n1; int* red = ip; ip += n1;
+    t.in_zone = ip; ip += n1; t.starts = ip; ip += n1 / 2 + 1; t.ends = ip;
+    for (int i = tid; i <= L; i += nthr) {
+        T[i] = g.T[i];
+        p_int[i] = g.p_int[i];
+        fd[i] = g.F_down_tot[i];
+        fu[i] = g.F_up_tot[i];
+        fn[i] = g.F_net[i];
+        unstable[i] = g.conv_unstable[i];
+        layer[i] = g.conv_layer[i];
+        red[i] = g.marked_red[i];
+        if (i < L) {
+            p_lay[i] = g.p_lay[i];
+            c_p[i] = g.c_p[i];
+            mmm[i] = g.mmm[i];
+            fah[i] = g.F_add_heat_sum[i];
+            fss[i] = g.F_smooth_sum[i];
+        }
+    }
     for (int i = tid; i < L; i += nthr) {
-        t.up[i] = pow(c.p_lay[i] / c.p_int[i], c.kappa_int[i]);
-        t.nxt[i] = pow(c.p_int[i + 1] / c.p_lay[i], c.kappa_lay[i]);
+        t.up[i] = pow(g.p_lay[i] / g.p_int[i], g.kappa_int[i]);
+        t.nxt[i] = pow(g.p_int[i + 1] / g.p_lay[i], g.kappa_lay[i]);
         if (i < L - 1) {
-            const double r1 = c.p_int[i + 1] / c.p_lay[i], r2 = c.p_lay[i + 1] / c.p_int[i + 1];
-            t.f1p[i] = pow(r1, c.kappa_lay[i] * (1 + 1e-6));
-            t.f2p[i] = pow(r2, c.kappa_int[i + 1] * (1 + 1e-6));
-            t.f1m[i] = pow(r1, c.kappa_lay[i] * (1 - 1e-6));
-            t.f2m[i] = pow(r2, c.kappa_int[i + 1] * (1 - 1e-6));
+            const double r1 = g.p_int[i + 1] / g.p_lay[i], r2 = g.p_lay[i + 1] / g.p_int[i + 1];
+            t.f1p[i] = pow(r1, g.kappa_lay[i] * (1 + 1e-6));
+            t.f2p[i] = pow(r2, g.kappa_int[i + 1] * (1 + 1e-6));
+            t.f1m[i] = pow(r1, g.kappa_lay[i] * (1 - 1e-6));
+            t.f2m[i] = pow(r2, g.kappa_int[i + 1] * (1 - 1e-6));
         }
     }
     if (tid == 0) {
-        t.surf_p = pow(c.p_lay[0] / c.p_int[0], c.kappa_int[0] * (1 + 1e-6));
-        t.surf_m = pow(c.p_lay[0] / c.p_int[0], c.kappa_int[0] * (1 - 1e-6));
+        t.surf_p = pow(g.p_lay[0] / g.p_int[0], g.kappa_int[0] * (1 + 1e-6));
+        t.surf_m = pow(g.p_lay[0] / g.p_int[0], g.kappa_int[0] * (1 - 1e-6));
+    }
+    c.T = T; c.p_lay = p_lay; c.p_int = p_int; c.c_p = c_p; c.mmm = mmm;
+    c.F_add_heat_sum = fah; c.F_smooth_sum = fss; c.F_down_tot = fd; c.F_up_tot = fu; c.F_net = fn;
+    c.conv_unstable = unstable; c.conv_layer = layer; c.marked_red = red;
+    __syncthreads();
+}
+
+// All threads, after a barrier: profile and flags back to global memory
+__device__ inline void conv_stage_out(const ConvColumn& c, const ConvColumn& g, int tid, int nthr) {
+    for (int i = tid; i <= c.L; i += nthr) {
+        g.T[i] = c.T[i];
+        g.conv_unstable[i] = c.conv_unstable[i];
+        g.conv_layer[i] = c.conv_layer[i];
+        g.marked_red[i] = c.marked_red[i];
     }
 }
 
@@ -197,6 +244,113 @@ __device__ inline void convective_adjustment(const ConvColumn& c, ConvTables& t)
     }
     conv_mark_layers(c, t, 1);
     conv_correct(c, t, 1);
+}
+
+// ---- workgroup-cooperative forms (all threads call them; they contain barriers) -------------------------------
+// The element-wise parts of conv_check / conv_mark_layers are evaluated by all threads; what the reference's
+// sequential loops leave behind is reproduced exactly:
+//   check: unstable[j] = cond+[j-1] | cond+[j]                      (cond[i] for i < lim, lim = the loop's break index)
+//   mark : layer[0] = cond-[0]; layer[j] = cond-[j-1] | cond-[j] (1 <= j < lim); layer[lim] = cond-[lim-1];
+//          entries above keep their old value; then the kink rule, then the surface rule.
+struct ConvShared {
+    int lim;       // number of layer pairs the check / mark loops visit before p_lay <= 10
+    int count;
+};
+
+__device__ inline void conv_find_lim(const ConvColumn& c, ConvShared& sh, int tid) {
+    if (tid == 0) {
+        int lim = c.L - 1;
+        for (int i = 0; i < c.L - 1; i++)
+            if (c.p_lay[i] <= 1e1) { lim = i; break; }
+        sh.lim = lim < 0 ? 0 : lim;
+    }
+    __syncthreads();
+}
+
+__device__ inline int conv_check_wg(const ConvColumn& c, ConvTables& t, ConvShared& sh, int tid, int nthr) {
+    const int L = c.L, lim = sh.lim;
+    int* cond = t.in_zone;
+    for (int i = tid; i <= L; i += nthr) cond[i] = (i < lim && c.T[i + 1] < (c.T[i] * t.f1p[i]) * t.f2p[i]) ? 1 : 0;
+    if (tid == 0) sh.count = 0;
+    __syncthreads();
+    const int surf = c.T[0] < c.T[L] * t.surf_p ? 1 : 0;
+    int mine = 0;
+    for (int j = tid; j <= L; j += nthr) {
+        int u = 0;
+        if (j < L) u = cond[j] | (j > 0 ? cond[j - 1] : 0);
+        if (surf && (j == 0 || j == L)) u = 1;
+        c.conv_unstable[j] = u;
+        mine += u;
+    }
+    if (mine) atomicAdd(&sh.count, mine);
+    __syncthreads();
+    const int n = sh.count;
+    __syncthreads();
+    return n;
+}
+
+__device__ inline void conv_mark_layers_wg(const ConvColumn& c, ConvTables& t, ConvShared& sh, int stitching, int tid,
+                                           int nthr) {
+    const int L = c.L, lim = sh.lim;
+    int* cond = t.in_zone;
+    for (int i = tid; i <= L; i += nthr) cond[i] = (i < lim && c.T[i + 1] < (c.T[i] * t.f1m[i]) * t.f2m[i]) ? 1 : 0;
+    __syncthreads();
+    const int surf = c.T[0] < c.T[L] * t.surf_m ? 1 : 0;
+    for (int j = tid; j <= L; j += nthr) {
+        int v = c.conv_layer[j];
+        if (j == L || j == 0) v = 0;
+        if (lim >= 1) {
+            if (j == 0) v = cond[0];
+            else if (j < lim) v = cond[j - 1] | cond[j];
+            else if (j == lim) v = cond[lim - 1];
+        }
+        if (j < L - 1 && c.T[j + 1] > c.T[j]) v = 0;   // no temperature kinks at the top edge of a zone
+        if (surf && (j == 0 || j == L)) v = 1;
+        c.conv_layer[j] = v;
+    }
+    __syncthreads();
+    if (stitching == 1 && c.itervalue > 5000) {
+        if (tid == 0) conv_stitch_holes(c, t);
+        __syncthreads();
+    }
+}
+
+__device__ inline void convective_adjustment_wg(const ConvColumn& c, ConvTables& t, ConvShared& sh, int tid, int nthr) {
+    conv_find_lim(c, sh, tid);
+    int unstable = conv_check_wg(c, t, sh, tid, nthr);
+    int guard = 0;
+    while (unstable > 0 && guard++ < 100000) {
+        conv_mark_layers_wg(c, t, sh, 0, tid, nthr);
+        if (tid == 0) conv_correct(c, t, 0);
+        __syncthreads();
+        unstable = conv_check_wg(c, t, sh, tid, nthr);
+    }
+    conv_mark_layers_wg(c, t, sh, 1, tid, nthr);
+    if (tid == 0) conv_correct(c, t, 1);
+    __syncthreads();
+}
+
+// check_for_radiative_eq by all threads; returns the criterion (uniform)
+__device__ inline int conv_radiative_eq_wg(const ConvColumn& c, ConvShared& sh, int* s_convective, int tid, int nthr) {
+    const int L = c.L;
+    const double norm = c.F_down_tot[L] + c.F_intern;
+    if (tid == 0) { sh.count = 0; *s_convective = 0; }
+    __syncthreads();
+    int conv = 0, ok = 0;
+    for (int i = tid; i <= L; i += nthr) {
+        int red = 0;
+        conv += c.conv_layer[i];
+        if (c.conv_layer[i] == 0) {
+            const double dF = i < L ? fabs(c.F_intern + c.F_add_heat_sum[i] + c.F_smooth_sum[i] - c.F_net[i + 1])
+                                    : fabs(c.F_intern - c.F_net[0]);
+            if (dF < c.rad_convergence_limit * norm) ok++; else red = 1;
+        }
+        c.marked_red[i] = red;
+    }
+    if (ok) atomicAdd(&sh.count, ok);
+    if (conv) atomicAdd(s_convective, conv);
+    __syncthreads();
+    return sh.count == (L + 1) - *s_convective ? 1 : 0;
 }
 
 // host_functions.py:251-286: local radiative equilibrium of the non-convective layers; fills marked_red

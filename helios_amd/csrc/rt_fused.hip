@@ -860,7 +860,13 @@ int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
         }
     }
     ProfScope ps(rt, "rt_conv_adjust");
-    k_rt_conv_adjust<<<rt->C, 256, 0, ctx->stream>>>(make_conv_args(rt, itervalue));
+    const size_t shmem = conv_smem_bytes(rt->L);
+    if (shmem > 48 * 1024 && !rt->conv_shmem_raised) {
+        (void)hipFuncSetAttribute((const void*)k_rt_conv_adjust, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)k_rt_totals_c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        rt->conv_shmem_raised = true;
+    }
+    k_rt_conv_adjust<<<rt->C, 256, shmem, ctx->stream>>>(make_conv_args(rt, itervalue));
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -914,7 +920,7 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
         q.done_w = rt->done;
         q.iters_done = rt->iters_done;
         q.physical_tstep_on = rt->cols[0].physical_tstep != 0 ? 1 : 0;
-        k_rt_totals_c<<<rt->C, 1024, 0, ctx->stream>>>(q);
+        k_rt_totals_c<<<rt->C, 1024, conv_smem_bytes(rt->L), ctx->stream>>>(q);
         HX_LAUNCH_CHECK(ctx);
     }
     return 0;

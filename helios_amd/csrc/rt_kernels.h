@@ -759,13 +759,15 @@ __device__ __forceinline__ ConvColumn conv_column(const ConvKArgs& a, int col) {
 // step E of the loop: check -> mark -> correct until stable, then once more with stitching and flux fudging.
 // grid C, 256 threads: all of them tabulate the pressure-ratio powers, thread 0 walks the layers.
 __global__ void __launch_bounds__(256) k_rt_conv_adjust(ConvKArgs a) {
+    extern __shared__ __align__(16) double conv_smem[];
     __shared__ ConvTables t;
     const int col = blockIdx.x;
     if (a.done[col]) return;
-    const ConvColumn c = conv_column(a, col);
-    conv_build_tables(c, t, threadIdx.x, blockDim.x);
-    __syncthreads();
-    if (threadIdx.x == 0) convective_adjustment(c, t);
+    __shared__ ConvShared sh;
+    ConvColumn c = conv_column(a, col), g;
+    conv_stage_in(c, g, t, conv_smem, threadIdx.x, blockDim.x);
+    convective_adjustment_wg(c, t, sh, threadIdx.x, blockDim.x);
+    conv_stage_out(c, g, threadIdx.x, blockDim.x);
 }
 
 struct TotalsCArgs {
@@ -780,6 +782,7 @@ struct TotalsCArgs {
 // steps H (totals), I, J, K: wavelength totals, mark the convective layers, test the radiative layers for local
 // equilibrium, and -- unless the column is done -- the radiative temperature step of the convection loop
 __global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
+    extern __shared__ __align__(16) double conv_smem[];
     __shared__ ConvTables t;
     __shared__ double seg[4][256];
     __shared__ int s_go;
@@ -814,24 +817,27 @@ __global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
         __syncthreads();
     }
     for (int i = threadIdx.x; i < I; i += blockDim.x) net[i] = up[i] - down[i];
-    const ConvColumn c = conv_column(q.cv, col);
-    conv_build_tables(c, t, threadIdx.x, blockDim.x);
     __syncthreads();
+    ConvColumn c = conv_column(q.cv, col), g;
+    conv_stage_in(c, g, t, conv_smem, threadIdx.x, blockDim.x);
+    __shared__ ConvShared sh;
+    __shared__ int s_convective;
+    conv_find_lim(c, sh, threadIdx.x);
+    conv_mark_layers_wg(c, t, sh, 1, threadIdx.x, blockDim.x);
+    int go = 0;
+    if (!q.physical_tstep_on) {  // with a physical time step the reference leaves the loop here
+        const int eq = conv_radiative_eq_wg(c, sh, &s_convective, threadIdx.x, blockDim.x);
+        go = (!eq) || (c.itervalue < 400) || (s_convective == 0);
+    }
     if (threadIdx.x == 0) {
-        conv_mark_layers(c, t, 1);
-        int go = 0;
-        if (!q.physical_tstep_on) {  // with a physical time step the reference leaves the loop here
-            int convective = 0;
-            for (int i = 0; i <= L; i++) convective += c.conv_layer[i];
-            const int eq = conv_radiative_eq(c);
-            go = (!eq) || (c.itervalue < 400) || (convective == 0);
-        }
         if (!go) {
             q.done_w[col] = 1;
             q.iters_done[col] = c.itervalue;   // no temperature step, no increment: the loop exits here
         }
         s_go = go;
     }
+    __syncthreads();
+    conv_stage_out(c, g, threadIdx.x, blockDim.x);   // (T unchanged here) flags for the temperature step and the host
     __syncthreads();
     if (!s_go) return;
     const hx_rt_column cp = a.colpar[col];
@@ -843,7 +849,7 @@ __global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
     r.pint += (size_t)col * I;
     r.T_store += (size_t)col * (L + 1);
     r.deltat_prefactor += (size_t)col * (L + 1);
-    r.marked_red = c.marked_red;
+    r.marked_red = g.marked_red;
     r.F_add_heat_lay += (size_t)col * L;
     r.F_smooth += (size_t)col * L;
     r.F_smooth_sum += (size_t)col * L;

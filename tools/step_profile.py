@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--columns", type=int, default=1)
+    ap.add_argument("--convection", action="store_true", help="also time iterations of the convection loop")
     args = ap.parse_args()
     import bench
     from helios_amd.device import Context
@@ -45,6 +46,35 @@ def main():
         if n:
             out.append("%s %.1f us (n=%d)" % (k, ms * 1e3, n))
     print("step(no refresh) %.1f us | " % (ev * 1e3) + " | ".join(out))
+    if args.convection:
+        import numpy as np
+        from helios_amd import phys_const as pc
+        L = c.nlayer
+        kap = 2.0 / 7.0
+        T = 2500.0 * (np.asarray(c.p_lay) / c.p_lay[0]) ** 0.4          # super-adiabatic below, like a hot interior
+        T = np.maximum(T, 600.0)
+        rt.set_temperatures(0, np.append(T, 2600.0))
+        for name, v in (("kappa_lay", np.full(L, kap)), ("kappa_int", np.full(L + 1, kap)),
+                        ("c_p_lay", np.full(L, pc.R_UNIV / kap))):
+            rt.set_state(0, name, v)
+        rt.set_state(0, "conv_layer", np.zeros(L + 1, np.int32))
+        rt.set_state(0, "conv_unstable", np.zeros(L + 1, np.int32))
+        rt.set_state(0, "dampara", np.array([-1.0]))
+        rt.set_state(0, "done", np.zeros(1, np.int32))
+        rt.conv_run(0, 11)
+        ctx.synchronize()
+        rt.profile(True)
+        rt.conv_run(11, 9)
+        rt.profile(False)
+        out = []
+        for k in ("rt_conv_adjust", "rt_nodes", "rt_flux", "rt_totals_a", "rt_totals_c"):
+            ms, n = rt.profile_read(k)
+            out.append("%s %.1f us (n=%d)" % (k, ms * 1e3, n))
+        ctx.timer_start()
+        rt.conv_run(21, 9)
+        ev = ctx.timer_stop_ms() / 9
+        print("convection step(no refresh) %.1f us | " % (ev * 1e3) + " | ".join(out),
+              "| convective layers:", int(rt.get("conv_layer").sum()), "done:", int(rt.get("done")[0]))
     rt.close()
 
 
