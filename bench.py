@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--columns-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--phase", default="radiative", choices=["radiative", "convection"],
+                    help="which loop a step is taken from: radiation_loop (default, the headline number) or "
+                         "convection_loop (convective adjustment + sweeps + temperature step, all on the device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -224,12 +227,26 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    run = rt.run
+    if args.phase == "convection":
+        # a profile with a super-adiabatic interior, so that every iteration adjusts a deep convective zone
+        from helios_amd import phys_const as pc
+        kap = 2.0 / 7.0
+        T = np.maximum(2500.0 * (np.asarray(c.p_lay) / c.p_lay[0]) ** 0.4, 600.0)
+        for i in range(ncol):
+            rt.set_temperatures(i, np.append(T, 2600.0) * (1.0 + 0.01 * (rank * ncol + i)))
+        L = c.nlayer
+        for name, v in (("kappa_lay", np.full(L, kap)), ("kappa_int", np.full(L + 1, kap)),
+                        ("c_p_lay", np.full(L, pc.R_UNIV / kap)), ("conv_layer", np.zeros(L + 1, np.int32)),
+                        ("conv_unstable", np.zeros(L + 1, np.int32)), ("dampara", np.array([-1.0]))):
+            rt.set_state(-1, name, v)
+        run = rt.conv_run
     # warm-up: W untimed steps starting at iteration 0 (includes the first refresh)
-    rt.run(0, args.warmup)
+    run(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    rt.run(args.warmup, args.steps)
+    run(args.warmup, args.steps)
     ev_ms = ctx.timer_stop_ms()
     barrier()
     dt = time.perf_counter() - t0
@@ -247,10 +264,10 @@ def main():
     if args.profile_steps > 0:
         it0 = args.warmup + args.steps
         it0 += (-it0) % 10 + 1                      # start right after a refresh boundary
-        rt.run(args.warmup + args.steps, it0 - (args.warmup + args.steps))
+        run(args.warmup + args.steps, it0 - (args.warmup + args.steps))
         ctx.synchronize()
         rt.profile(True)
-        rt.run(it0, min(args.profile_steps, 9))     # E-iterations only
+        run(it0, min(args.profile_steps, 9))     # E-iterations only
         rt.profile(False)
         flux_ms, nflux = rt.profile_read("rt_flux")
         if c.species:   # one refresh under the profiler: where the on-the-fly mixing time goes
@@ -293,7 +310,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["desc"], "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
                    "opacity_table_TP_grid": [c.ntemp, c.npress], "columns_per_gpu": ncol,
-                   "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 4,
+                   "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 4, "loop": args.phase,
                    "parallelism": "columns sharded, %d per GPU" % ncol},
         "iterations_per_s_per_column": args.steps / dt,
         "stream_event_ms_per_step": ev_ms / args.steps,
