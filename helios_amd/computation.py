@@ -362,8 +362,7 @@ class Compute(object):
 
     def _fused_supported(self, quant):
         return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
-                and quant.flux_calc_method == "iteration" and not self._kappa_from_table(quant)
-                and quant.add_heating != 1)
+                and quant.flux_calc_method == "iteration" and not self._kappa_from_table(quant))
 
     def _make_rt(self, quant):
         """device-resident fused state for this Store (one column)"""
@@ -402,6 +401,8 @@ class Compute(object):
                                  q.g_0_all_clouds_lay, q.g_0_all_clouds_int)
         if q.c_p_lay is not None and len(np.atleast_1d(q.c_p_lay)) == _i(q.nlayer):
             rt.set_state(0, "c_p_lay", np.asarray(q.c_p_lay, np.float64))
+        if q.add_heating == 1:      # the flux follows the layer heights on the device (every refresh)
+            rt.set_state(0, "add_heat_dens", np.asarray(q.add_heat_dens, np.float64))
         rt.build_planck_table(1 if (q.energy_correction == 1 and q.T_star > 10) else 0)
         return rt
 
@@ -485,6 +486,10 @@ class Compute(object):
                 buf = np.zeros(dev.size)
                 buf[:v.size] = v
                 dev.set(buf)
+        if quant.add_heating == 1:
+            for n in ("F_add_heat_lay", "F_add_heat_sum"):
+                setattr(quant, n, rt.get(n))
+                getattr(quant, "dev_" + n).set(getattr(quant, n))
         quant.dev_delta_t_prefactor.set(rt.get("delta_t_prefactor"))
         quant.dev_T_store.set(rt.get("T_store"))
         quant.dev_planckband_grid.set(rt.get("planck_grid"))

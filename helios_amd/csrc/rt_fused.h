@@ -98,6 +98,8 @@ struct hx_rt {
     // convection loop (hx_rt_conv_*): adiabatic coefficients, layer flags, damping parameter of the flux fudging
     double *kappa_lay = nullptr, *kappa_int = nullptr, *dampara = nullptr;                     // L, I, 1
     int *conv_unstable = nullptr, *conv_layer = nullptr, *marked_red = nullptr;                  // L+1 each
+    double* add_heat_dens = nullptr;   // L: additional heating density [erg cm^-3 s^-1]; flux = density * layer height
+    bool has_heating = false;
 
     // profiling
     bool profiling = false;

@@ -733,6 +733,11 @@ int hx_rt_refresh(hx_rt* rt) {
     }
     k_rt_height<<<rt->C, 64, 0, ctx->stream>>>(rt->p_lay, rt->delta_z, rt->z_lay, L, rt->f.planet_type_gas, (size_t)L);
     HX_LAUNCH_CHECK(ctx);
+    if (rt->has_heating) {   // computation.py:913-918: refreshed with the layer heights, every 10th iteration
+        k_rt_heating<<<rt->C, 64, 0, ctx->stream>>>(rt->add_heat_dens, rt->delta_z, rt->F_add_heat_lay,
+                                                    rt->F_add_heat_sum, L, rt->done);
+        HX_LAUNCH_CHECK(ctx);
+    }
     if (rt->f.dir_beam) {
         ProfScope ps(rt, "direct_beam");
         k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, rt->C), 256, 0, ctx->stream>>>(a);
@@ -1070,6 +1075,8 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
     if (n == "conv_unstable") return get_plain(rt, rt->conv_unstable + c * (L + 1), (L + 1) * 4, out, out_bytes);
     if (n == "marked_red") return get_plain(rt, rt->marked_red + c * (L + 1), (L + 1) * 4, out, out_bytes);
     if (n == "F_smooth_sum") return get_plain(rt, rt->F_smooth_sum + c * L, L * 8, out, out_bytes);
+    if (n == "F_add_heat_lay") return get_plain(rt, rt->F_add_heat_lay + c * L, L * 8, out, out_bytes);
+    if (n == "F_add_heat_sum") return get_plain(rt, rt->F_add_heat_sum + c * L, L * 8, out, out_bytes);
     if (n == "planckband_lay" || n == "planckband_int") {
         // from the node array Bn[x][H+3]: layers = odd nodes, then star, surface; interfaces = even
         const bool lay = n == "planckband_lay";
@@ -1155,6 +1162,11 @@ int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t
         } else if (n == "conv_layer" || n == "conv_unstable") {
             if (in_bytes != (L + 1) * 4) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for %s", name);
             rc |= h2d(rt, (n == "conv_layer" ? rt->conv_layer : rt->conv_unstable) + c * (L + 1), in, in_bytes);
+        } else if (n == "add_heat_dens") {
+            if (in_bytes != L * 8) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for add_heat_dens");
+            if (!rt->add_heat_dens) RT_ALLOC(rt->add_heat_dens, (size_t)rt->C * L);
+            rc |= h2d(rt, rt->add_heat_dens + c * L, in, in_bytes);
+            rt->has_heating = true;
         } else if (n == "dampara") {
             if (in_bytes != 8) return hx_fail(rt->ctx, HX_E_ARG, "dampara expects one double (<= 0: automatic)");
             rc |= h2d(rt, rt->dampara + c, in, 8);

@@ -858,6 +858,22 @@ __global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
     conv_temp_step(r, threadIdx.x, blockDim.x);
 }
 
+// additional heating flux of the layers and its running sum from the TOP of the list down, i.e. index 0 upwards
+// (host_functions.py:701-711), one thread per column
+__global__ void k_rt_heating(const double* __restrict__ dens, const double* __restrict__ dz,
+                             double* __restrict__ F_lay, double* __restrict__ F_sum, int L, const int* done) {
+    const int col = blockIdx.x;
+    if (threadIdx.x != 0 || done[col]) return;
+    dens += (size_t)col * L; dz += (size_t)col * L; F_lay += (size_t)col * L; F_sum += (size_t)col * L;
+    double run = 0.0;
+    for (int i = 0; i < L; i++) {
+        const double f = dens[i] * dz[i];
+        F_lay[i] = f;
+        run = i == 0 ? f : run + f;
+        F_sum[i] = run;
+    }
+}
+
 // altitude of the layer centres from the layer thicknesses (host_functions.py:673-698), one thread
 __global__ void k_rt_height(const double* __restrict__ p_lay, const double* __restrict__ dz,
                             double* __restrict__ z, int L, int gas, size_t stride) {

@@ -189,7 +189,7 @@ class RTBatch(object):
             "Fc_down_wg": (wg, np.float64), "F_dir_wg": (wg, np.float64), "Fc_dir_wg": (wg, np.float64),
             "iters_done": (1, np.int32), "done": (1, np.int32),
             "conv_layer": (L + 1, np.int32), "conv_unstable": (L + 1, np.int32), "marked_red": (L + 1, np.int32),
-            "F_smooth_sum": (L, np.float64),
+            "F_smooth_sum": (L, np.float64), "F_add_heat_lay": (L, np.float64), "F_add_heat_sum": (L, np.float64),
             "planck_grid": ((self.dims.plancktable_dim + 1) * X, np.float64),
         }
         return table[name]

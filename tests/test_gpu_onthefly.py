@@ -194,9 +194,13 @@ def test_run_helios_with_additional_heating(tmp_path):
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
             "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "heat",
             "-output_directory", wd + "/", "-radiative_equilibrium_criterion", "1e-5", "-convective_adjustment", "no"]
-    hot = _run_driver(argv + ["-include_additional_heating", "yes", "-path_to_heating_file",
-                              os.path.join(wd, "heating.txt")], True)
+    heat = ["-include_additional_heating", "yes", "-path_to_heating_file", os.path.join(wd, "heating.txt")]
+    hot = _run_driver(argv + heat, True)                 # heating flux refreshed on the device (fused path)
+    hot_stagewise = _run_driver(argv + heat, False)      # ... and by the host in the per-stage loop
     cold = _run_driver(argv, True)
+    assert int(hot.iter_value) == int(hot_stagewise.iter_value)
+    np.testing.assert_allclose(hot.T_lay, hot_stagewise.T_lay, rtol=1e-7)
+    np.testing.assert_allclose(hot.F_add_heat_sum, hot_stagewise.F_add_heat_sum, rtol=1e-9)
     extra = hot.F_add_heat_sum[-1]
     assert extra > 0 and np.all(hot.add_heat_dens > 0)
     L = int(hot.nlayer)
