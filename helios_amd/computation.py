@@ -92,7 +92,7 @@ class Compute(object):
     @staticmethod
     def _kappa_from_table(quant):
         """`kappa value = file` or `water_atmo`: the reference tests "is the value a string" (computation.py:202)"""
-        return isinstance(quant.input_kappa_value, str)
+        return quant.convection == 1 and isinstance(quant.input_kappa_value, str) and len(quant.entr_kappa) > 1
 
     def interpolate_kappa_and_cp(self, quant):
         """only with a kappa/c_p table; a constant kappa needs no kernel (computation.py:199-250)"""
@@ -362,7 +362,7 @@ class Compute(object):
 
     def _fused_supported(self, quant):
         return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
-                and quant.flux_calc_method == "iteration" and not self._kappa_from_table(quant))
+                and quant.flux_calc_method == "iteration")
 
     def _make_rt(self, quant):
         """device-resident fused state for this Store (one column)"""
@@ -401,6 +401,8 @@ class Compute(object):
                                  q.g_0_all_clouds_lay, q.g_0_all_clouds_int)
         if q.c_p_lay is not None and len(np.atleast_1d(q.c_p_lay)) == _i(q.nlayer):
             rt.set_state(0, "c_p_lay", np.asarray(q.c_p_lay, np.float64))
+        if self._kappa_from_table(q):
+            rt.set_kappa_table(q.entr_temp, q.entr_press, q.entr_kappa, q.entr_c_p)
         if q.add_heating == 1:      # the flux follows the layer heights on the device (every refresh)
             rt.set_state(0, "add_heat_dens", np.asarray(q.add_heat_dens, np.float64))
         rt.build_planck_table(1 if (q.energy_correction == 1 and q.T_star > 10) else 0)
@@ -566,6 +568,10 @@ class Compute(object):
         for n in ("T_lay", "F_net", "F_up_tot", "F_down_tot"):
             setattr(quant, n, rt.get(n))
         quant.p_lay, quant.p_int = np.asarray(quant.p_lay, float), np.asarray(quant.p_int, float)
+        if self._kappa_from_table(quant):         # per-stage kernels on the Store's arrays (synced after the radiation loop)
+            self.interpolate_kappa_and_cp(quant)
+            quant.kappa_lay, quant.kappa_int = quant.dev_kappa_lay.get(), quant.dev_kappa_int.get()
+            quant.c_p_lay = quant.dev_c_p_lay.get()
         hsfunc.conv_check(quant)
         hsfunc.mark_convective_layers(quant, stitching=0)
         condition = sum(quant.conv_unstable) > 0
@@ -623,6 +629,9 @@ class Compute(object):
         quant.conv_unstable = rt.get("conv_unstable")
         quant.marked_red = rt.get("marked_red")
         quant.dev_F_smooth_sum.set(rt.get("F_smooth_sum"))
+        for n in ("kappa_lay", "kappa_int", "c_p_lay"):
+            setattr(quant, n, rt.get(n))
+            getattr(quant, "dev_" + n).set(getattr(quant, n))
         print("\nTime for rad.-conv. iteration [s]: {:.2f}".format(ms * 1e-3))
         print("Total number of iterative steps: " + str(quant.iter_value))
         self.sync_store_from_rt(quant)

@@ -98,6 +98,9 @@ struct hx_rt {
     // convection loop (hx_rt_conv_*): adiabatic coefficients, layer flags, damping parameter of the flux fudging
     double *kappa_lay = nullptr, *kappa_int = nullptr, *dampara = nullptr;                     // L, I, 1
     int *conv_unstable = nullptr, *conv_layer = nullptr, *marked_red = nullptr;                  // L+1 each
+    // kappa (= delad) / c_p table of `kappa value = file`: [p + npress * t] on (entr_temp, entr_press)
+    double *entr_temp = nullptr, *entr_press = nullptr, *entr_kappa = nullptr, *entr_c_p = nullptr;
+    int entr_ntemp = 0, entr_npress = 0;
     double* add_heat_dens = nullptr;   // L: additional heating density [erg cm^-3 s^-1]; flux = density * layer height
     bool has_heating = false;
 

@@ -766,6 +766,8 @@ int hx_rt_refresh(hx_rt* rt) {
     return 0;
 }
 
+namespace { int kappa_cp_from_table(hx_rt* rt, bool refresh_T_int); }
+
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
     hx_context* ctx = rt->ctx;
     KArgs a = make_args(rt);
@@ -784,6 +786,10 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         ProfScope ps(rt, "rt_totals_a");
         k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
+    }
+    if (rt->entr_kappa && rt->cols[0].physical_tstep != 0 && itervalue % 10 == 0) {   // computation.py:921-923
+        int rc = kappa_cp_from_table(rt, false);
+        if (rc) return rc;
     }
     {
         ProfScope ps(rt, "rt_totals_b");
@@ -848,6 +854,52 @@ ConvKArgs make_conv_args(hx_rt* rt, int itervalue) {
 
 }  // namespace
 
+namespace {
+
+// kappa_lay, kappa_int and c_p_lay from the table at the current temperatures (computation.py:199-250)
+int kappa_cp_from_table(hx_rt* rt, bool refresh_T_int) {
+    hx_context* ctx = rt->ctx;
+    const int L = rt->L, I = rt->I;
+    if (refresh_T_int) {
+        k_rt_tint<<<dim3(hx_cdiv(I, 64), rt->C), 64, 0, ctx->stream>>>(rt->T_lay, rt->T_int, L, rt->done);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    for (int c = 0; c < rt->C; c++) {
+        const double* T_lay = rt->T_lay + (size_t)c * (L + 1);
+        const double* T_int = rt->T_int + (size_t)c * I;
+        const double* p_lay = rt->p_lay + (size_t)c * L;
+        const double* p_int = rt->p_int + (size_t)c * I;
+        int rc = hx_kappa_interpol(ctx, T_lay, rt->entr_temp, p_lay, rt->entr_press, rt->kappa_lay + (size_t)c * L,
+                                   rt->entr_kappa, rt->entr_npress, rt->entr_ntemp, L);
+        if (rc) return rc;
+        rc = hx_kappa_interpol(ctx, T_int, rt->entr_temp, p_int, rt->entr_press, rt->kappa_int + (size_t)c * I,
+                               rt->entr_kappa, rt->entr_npress, rt->entr_ntemp, I);
+        if (rc) return rc;
+        rc = hx_cp_interpol(ctx, T_lay, rt->entr_temp, p_lay, rt->entr_press, rt->c_p_lay + (size_t)c * L,
+                            rt->entr_c_p, rt->entr_npress, rt->entr_ntemp, L);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, const double* entr_press,
+                          int entr_npress, const double* entr_kappa, const double* entr_c_p) {
+    HX_REQUIRE(rt->ctx, entr_ntemp > 1 && entr_npress > 1 && entr_temp && entr_press && entr_kappa && entr_c_p,
+               HX_E_ARG, "hx_rt_set_kappa_table: need a (T, P) grid of at least 2 x 2");
+    const size_t n = (size_t)entr_ntemp * entr_npress;
+    RT_ALLOC(rt->entr_temp, entr_ntemp); RT_ALLOC(rt->entr_press, entr_npress);
+    RT_ALLOC(rt->entr_kappa, n); RT_ALLOC(rt->entr_c_p, n);
+    int rc = h2d(rt, rt->entr_temp, entr_temp, entr_ntemp * 8);
+    rc |= h2d(rt, rt->entr_press, entr_press, entr_npress * 8);
+    rc |= h2d(rt, rt->entr_kappa, entr_kappa, n * 8);
+    rc |= h2d(rt, rt->entr_c_p, entr_c_p, n * 8);
+    rt->entr_ntemp = entr_ntemp;
+    rt->entr_npress = entr_npress;
+    return rc;
+}
+
 // first half of one iteration: [every 10th: mean molecular mass at the current temperatures] and the convective
 // adjustment of the temperature profile (computation.py:1027-1047)
 int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
@@ -863,6 +915,10 @@ int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
                          : meanmolmass_from_vmr(rt, c, false);
             if (rc) return rc;
         }
+    }
+    if (rt->entr_kappa) {   // computation.py:1037: kappa and c_p of the profile before the adjustment
+        int rc = kappa_cp_from_table(rt, true);
+        if (rc) return rc;
     }
     ProfScope ps(rt, "rt_conv_adjust");
     const size_t shmem = conv_smem_bytes(rt->L);
@@ -903,6 +959,10 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
         ProfScope ps(rt, "rt_totals_a");
         k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
+    }
+    if (rt->entr_kappa) {   // computation.py:1088: once more for the adjusted profile, before the layers are marked
+        int rc = kappa_cp_from_table(rt, false);
+        if (rc) return rc;
     }
     {
         ProfScope ps(rt, "rt_totals_c");
@@ -1075,6 +1135,9 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
     if (n == "conv_unstable") return get_plain(rt, rt->conv_unstable + c * (L + 1), (L + 1) * 4, out, out_bytes);
     if (n == "marked_red") return get_plain(rt, rt->marked_red + c * (L + 1), (L + 1) * 4, out, out_bytes);
     if (n == "F_smooth_sum") return get_plain(rt, rt->F_smooth_sum + c * L, L * 8, out, out_bytes);
+    if (n == "kappa_lay") return get_plain(rt, rt->kappa_lay + c * L, L * 8, out, out_bytes);
+    if (n == "kappa_int") return get_plain(rt, rt->kappa_int + c * (L + 1), (L + 1) * 8, out, out_bytes);
+    if (n == "c_p_lay") return get_plain(rt, rt->c_p_lay + c * L, L * 8, out, out_bytes);
     if (n == "F_add_heat_lay") return get_plain(rt, rt->F_add_heat_lay + c * L, L * 8, out, out_bytes);
     if (n == "F_add_heat_sum") return get_plain(rt, rt->F_add_heat_sum + c * L, L * 8, out, out_bytes);
     if (n == "planckband_lay" || n == "planckband_int") {

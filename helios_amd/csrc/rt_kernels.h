@@ -858,6 +858,13 @@ __global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
     conv_temp_step(r, threadIdx.x, blockDim.x);
 }
 
+// interface temperatures only (the node kernel does the same as part of its work)
+__global__ void k_rt_tint(const double* __restrict__ T_lay, double* __restrict__ T_int, int L, const int* done) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > L || done[col]) return;
+    T_int[(size_t)col * (L + 1) + i] = interface_T(T_lay + (size_t)col * (L + 1), i, L);
+}
+
 // additional heating flux of the layers and its running sum from the TOP of the list down, i.e. index 0 upwards
 // (host_functions.py:701-711), one thread per column
 __global__ void k_rt_heating(const double* __restrict__ dens, const double* __restrict__ dz,

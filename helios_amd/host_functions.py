@@ -223,8 +223,15 @@ def interpolate_vmr_to_opacity_grid(read, quant, vmr):
 def calculate_vmr_for_all_species(quant):
     """vertical VMR profiles of FastChem-tabulated species (host_functions.py:874-901)"""
     if quant.rt is not None:
+        # interface temperatures of the CURRENT profile (the device's T_int array is one iteration old -- or not yet
+        # written -- whenever the host looks): same arithmetic as temp_inter (kernels.cu:496-520)
         quant.T_lay = quant.rt.get("T_lay")
-        quant.T_int = quant.rt.get("T_int")
+        T, L = quant.T_lay, int(quant.nlayer)
+        T_int = np.empty(L + 1)
+        T_int[1:L] = T[:L - 1] + 0.5 * (T[1:L] - T[:L - 1])
+        T_int[0] = T[0] - 0.5 * (T[1] - T[0])
+        T_int[L] = T[L - 1] + 0.5 * (T[L - 1] - T[L - 2])
+        quant.T_int = T_int
     else:
         quant.T_lay = quant.dev_T_lay.get()
         quant.T_int = quant.dev_T_int.get()

@@ -152,6 +152,11 @@ class RTBatch(object):
     def run(self, itervalue, nsteps):
         self._ck(self._l.hx_rt_run(self.handle, int(itervalue), int(nsteps)), "hx_rt_run")
 
+    def set_kappa_table(self, entr_temp, entr_press, entr_kappa, entr_c_p):
+        a = [_f64(v) for v in (entr_temp, entr_press, entr_kappa, entr_c_p)]
+        self._ck(self._l.hx_rt_set_kappa_table(self.handle, _dp(a[0]), len(a[0]), _dp(a[1]), len(a[1]), _dp(a[2]),
+                                               _dp(a[3])), "hx_rt_set_kappa_table")
+
     def conv_adjust(self, itervalue):
         self._ck(self._l.hx_rt_conv_adjust(self.handle, int(itervalue)), "hx_rt_conv_adjust")
 
@@ -189,6 +194,7 @@ class RTBatch(object):
             "Fc_down_wg": (wg, np.float64), "F_dir_wg": (wg, np.float64), "Fc_dir_wg": (wg, np.float64),
             "iters_done": (1, np.int32), "done": (1, np.int32),
             "conv_layer": (L + 1, np.int32), "conv_unstable": (L + 1, np.int32), "marked_red": (L + 1, np.int32),
+            "kappa_lay": (L, np.float64), "kappa_int": (L + 1, np.float64), "c_p_lay": (L, np.float64),
             "F_smooth_sum": (L, np.float64), "F_add_heat_lay": (L, np.float64), "F_add_heat_sum": (L, np.float64),
             "planck_grid": ((self.dims.plancktable_dim + 1) * X, np.float64),
         }

@@ -363,6 +363,10 @@ int hx_rt_run(hx_rt* rt, int itervalue, int nsteps);
  * chains them.  When the reference's loop condition turns false the column is frozen ("done" = 1, "iters_done" = the
  * reference's final iter_value).  Inputs beyond the radiation loop's: hx_rt_set_state "kappa_lay", "kappa_int",
  * "conv_layer" (flags persist between iterations), "dampara" (<= 0: the reference's automatic choice). */
+/* kappa (= delad) and c_p tables of `kappa value = file | water_atmo` (read.py:1105-1193), value[p + npress * t]; with
+ * them kappa_lay / kappa_int / c_p_lay follow the profile on the device (kappa_interpol, cp_interpol) */
+int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, const double* entr_press,
+                          int entr_npress, const double* entr_kappa, const double* entr_c_p);
 int hx_rt_conv_adjust(hx_rt* rt, int itervalue);
 int hx_rt_conv_advance(hx_rt* rt, int itervalue);
 int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps);

@@ -140,12 +140,18 @@ def test_run_helios_with_kappa_table(tmp_path):
             "-number_of_layers", "20", "-maximum_number_of_iterations", "20000", "-name", "kap",
             "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
             "-internal_temperature", "1500"]
-    a = _run_driver(argv + ["-kappa_value", "file", "-kappa_file_path", path], True)
-    b = _run_driver(argv + ["-kappa_value", repr(kap)], False)
+    a = _run_driver(argv + ["-kappa_value", "file", "-kappa_file_path", path], True)     # fused: table on the device
+    b = _run_driver(argv + ["-kappa_value", repr(kap)], True)                            # fused: constant kappa
+    c = _run_driver(argv + ["-kappa_value", "file", "-kappa_file_path", path], False)    # per-stage loop, table
+    assert c.conv_layer.sum() > 0
+    np.testing.assert_allclose(c.kappa_lay, kap, rtol=1e-12)
+    np.testing.assert_array_equal(c.conv_layer, a.conv_layer)
+    np.testing.assert_allclose(c.T_lay, a.T_lay, rtol=2e-4)
     assert a.conv_layer.sum() > 0                      # the convection loop engaged
     np.testing.assert_allclose(a.kappa_lay, kap, rtol=1e-12)
     np.testing.assert_array_equal(a.conv_layer, b.conv_layer)
-    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-9)
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-9)      # same loop, same numbers: the table is constant
+    assert int(a.iter_value) == int(b.iter_value)
     assert a.entropy_lay.min() > 0                     # entropy diagnostic interpolated from the table
 
 
