@@ -199,10 +199,18 @@ def main():
 
     import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
     dist = None
+    # test hook for single-GPU machines: HELIOS_BENCH_BACKEND=gloo runs all ranks on GPU 0 with CPU-side collectives,
+    # so that the multi-rank logic can be exercised where RCCL cannot (one GPU cannot host two RCCL ranks)
+    backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else 0
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from helios_amd.device import Context
     from helios_amd.rt import batch_from_case
@@ -210,7 +218,7 @@ def main():
     w = WORKLOADS[args.workload]
     seed = 20240 + 2
     c = build_case(w, seed)
-    ctx = Context(local_rank)
+    ctx = Context(device_index)
     ncol = args.columns_per_gpu
     rt = make_batch(ctx, c, ncol)
     # every column of a sweep differs (here: internal temperature -> different T-P trajectories)
@@ -251,7 +259,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -294,7 +302,7 @@ def main():
     spec = np.stack([rt.get("F_up_band", i)[-c.nbin:] for i in range(ncol)])
     if dist is not None:
         tg = time.perf_counter()
-        mine = torch.from_numpy(spec).cuda()
+        mine = torch.from_numpy(spec).to(coll_device)
         out = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(out, mine)
         torch.cuda.synchronize()
