@@ -469,9 +469,12 @@ class Compute(object):
         print("Total number of iterative steps: " + str(quant.iter_value))
         self.sync_store_from_rt(quant)
 
-    def sync_store_from_rt(self, quant):
-        """make the Store's dev_* arrays (reference layouts) reflect the fused state"""
+    def sync_store_from_rt(self, quant, flux_state=False):
+        """make the Store's dev_* arrays (reference layouts) reflect the fused state.  Large arrays go device to device;
+        the persistent up-flux state (decoded from the tiles on the host) only when a per-stage loop is going to continue
+        from it (`flux_state`)."""
         rt = quant.rt
+        X, Y, L, I = _i(quant.nbin), _i(quant.ny), _i(quant.nlayer), _i(quant.ninterface)
         for n in ("T_lay", "T_int", "F_up_band", "F_down_band", "F_dir_band", "F_up_tot", "F_down_tot", "F_net",
                   "F_net_diff", "planckband_lay", "planckband_int", "scat_cross_lay", "scat_cross_int",
                   "meanmolmass_lay", "meanmolmass_int", "delta_z_lay", "z_lay", "abort", "g_0_tot_lay",
@@ -480,11 +483,20 @@ class Compute(object):
             dev = getattr(quant, "dev_" + n, None)
             if dev is not None and dev.size == v.size:
                 dev.set(v)
-        # wg arrays: the Store over-allocates the layer arrays to ninterface slabs (Q2)
-        for n in ("opac_wg_lay", "opac_wg_int", "F_dir_wg", "Fc_dir_wg", "F_up_wg", "Fc_up_wg"):
-            v = rt.get(n)
-            dev = getattr(quant, "dev_" + n, None)
-            if dev is not None:
+        # opacities of every spectral point: rebuilt on the device if the fused look-up skipped them, then copied d2d
+        # (the Store over-allocates the layer arrays to ninterface slabs, Q2)
+        for n, nlev in (("opac_wg_lay", L), ("opac_wg_int", I)):
+            getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n), Y * X * nlev * 8)
+        if quant.dir_beam == 1:
+            for n in ("F_dir_wg", "Fc_dir_wg"):
+                getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n), Y * X * I * 8)
+        else:
+            quant.dev_F_dir_wg.fill_zero()
+            quant.dev_Fc_dir_wg.fill_zero()
+        if flux_state:
+            for n in ("F_up_wg", "Fc_up_wg"):
+                v = rt.get(n)
+                dev = getattr(quant, "dev_" + n)
                 buf = np.zeros(dev.size)
                 buf[:v.size] = v
                 dev.set(buf)
@@ -494,7 +506,7 @@ class Compute(object):
                 getattr(quant, "dev_" + n).set(getattr(quant, n))
         quant.dev_delta_t_prefactor.set(rt.get("delta_t_prefactor"))
         quant.dev_T_store.set(rt.get("T_store"))
-        quant.dev_planckband_grid.set(rt.get("planck_grid"))
+        quant.dev_planckband_grid.copy_from_device(rt.device_ptr("planck_grid"), quant.dev_planckband_grid.nbytes)
         quant.T_lay = rt.get("T_lay")
         # transmission arrays for the post-loop diagnostics come from the per-stage kernel
         self.calculate_transmission(quant)
@@ -644,6 +656,8 @@ class Compute(object):
             return
         if self._fused_supported(quant) and quant.rt is not None and quant.physical_tstep == 0:
             return self._convection_loop_fused(quant, write, read)
+        if quant.rt is not None:      # the per-stage loop continues from the fused state
+            self.sync_store_from_rt(quant, flux_state=True)
         L = _i(quant.nlayer)
         self.interpolate_kappa_and_cp(quant)
         quant.T_lay = quant.dev_T_lay.get()

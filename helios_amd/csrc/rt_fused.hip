@@ -1251,6 +1251,8 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
     else if (n == "p_int") p = rt->p_int + c * I;
     else if (n == "opac_wg_lay") { int rc = materialize_opac(rt); if (rc) return rc; p = rt->opac_wg_lay + c * nc * I; }
     else if (n == "opac_wg_int") { int rc = materialize_opac(rt); if (rc) return rc; p = rt->opac_wg_int + c * nc * I; }
+    else if (n == "F_dir_wg" && rt->f.dir_beam) p = rt->F_dir_wg + c * nc * I;
+    else if (n == "Fc_dir_wg" && rt->f.dir_beam) p = rt->Fc_dir_wg + c * nc * I;
     else if (n == "scat_cross_lay") p = rt->scat_cross_lay + c * X * I;
     else if (n == "scat_cross_int") p = rt->scat_cross_int + c * X * I;
     else if (n == "meanmolmass_lay") p = rt->mmm_lay + c * I;

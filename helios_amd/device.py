@@ -108,6 +108,13 @@ class DeviceArray(object):
                                           self.nbytes), "hx_h2d")
         return self
 
+    def copy_from_device(self, src_ptr, nbytes):
+        """device-to-device copy of `nbytes` from a raw device pointer into the start of this array"""
+        if nbytes > self.nbytes:
+            raise ValueError("copy_from_device: %d bytes into an array of %d" % (nbytes, self.nbytes))
+        self.ctx.check(self.ctx._l.hx_d2d(self.ctx.handle, self.ptr, src_ptr, ctypes.c_size_t(nbytes)), "hx_d2d")
+        return self
+
     def fill_zero(self):
         self.ctx.check(self.ctx._l.hx_memset0(self.ctx.handle, self.ptr, self.nbytes), "hx_memset0")
         return self

@@ -10,68 +10,81 @@ arrays, never on these text files.
 import os
 import shutil
 
+import numpy as np
+
 from . import host_functions as hsfunc
 from . import phys_const as pc
 
 _BIN_HEAD = ("bin", "cent_lambda[um]", "low_int_lambda[um]", "delta_lambda[um]")
 
-# per-bin tables: suffix -> (title, 4th-header width, column label, label width, levels, cell format,
-#                            value(quant, x, i)); `levels` is a Store attribute name or a callable
+# per-bin tables: suffix -> (title, 4th-header width, column label, label width, levels, printf cell format,
+#                            matrix(quant) -> values[bin, level]).  Reference layouts: band arrays [x + nbin*i]
+#                            ("level-major"), Planck arrays [i + x*nlevel] ("bin-major").
+def _level_major(name, levels):
+    return lambda q: np.asarray(getattr(q, name), float)[:int(q.nbin) * int(getattr(q, levels))].reshape(
+        int(getattr(q, levels)), int(q.nbin)).T
+
+
+def _cloud_opacity(q):
+    L, X = int(q.nlayer), int(q.nbin)
+    return (np.asarray(q.abs_cross_all_clouds_lay, float)[:L * X].reshape(L, X)
+            / np.asarray(q.meanmolmass_lay, float)[:L, None]).T
+
+
 _BAND_FILES = {
     "_spec_upflux.dat": (
         "This file contains the upward spectral flux (per wavelength) at each interface. "
         "\nSpectral fluxes given in [erg s^-1 cm^-3].",
-        19, "F_up[", 5, "ninterface", "{:<16.8e}", lambda q, x, i: q.F_up_band[x + i * q.nbin]),
+        19, "F_up[", 5, "ninterface", "%-16.8e", _level_major("F_up_band", "ninterface")),
     "_spec_downflux.dat": (
         "This file contains the downward spectral flux (per wavelength) at each interface. "
         "\nSpectral fluxes given in [erg s^-1 cm^-3].",
-        19, "F_down[", 7, "ninterface", "{:<16.8e}", lambda q, x, i: q.F_down_band[x + i * q.nbin]),
+        19, "F_down[", 7, "ninterface", "%-16.8e", _level_major("F_down_band", "ninterface")),
     "_direct_beamflux.dat": (
         "This file contains the direct irradiation flux (per wavelength) at each interface. "
         "\nSpectral fluxes given in [erg s^-1 cm^-3].",
-        18, "F_dir[", 6, "ninterface", "{:<16.8e}", lambda q, x, i: q.F_dir_band[x + i * q.nbin]),
+        18, "F_dir[", 6, "ninterface", "%-16.8e", _level_major("F_dir_band", "ninterface")),
     "_planck_int.dat": (
         "This file contains the Planck (blackbody) function at each interface. "
         "\nPlanck function given in [erg s^-1 cm^-3 sr^-1].",
-        19, "B_int[", 6, "ninterface", "{:<16g}", lambda q, x, i: q.planckband_int[i + x * q.ninterface]),
+        19, "B_int[", 6, "ninterface", "%-16g",
+        lambda q: np.asarray(q.planckband_int, float).reshape(int(q.nbin), int(q.ninterface))),
     "_opacities.dat": (
         "This file contains the bin integrated opacities at each layer center "
         "\nOpacity given in [cm^2 g^-1].",
-        19, "opac_lay[", 9, "nlayer", "{:<15g}", lambda q, x, i: q.opac_band_lay[x + q.nbin * i]),
+        19, "opac_lay[", 9, "nlayer", "%-15g", _level_major("opac_band_lay", "nlayer")),
     "_cloud_opacities.dat": (
         "This file contains the cloud opacities at each layer center "
         "\nOpacity given in [cm^2 g^-1].",
-        19, "cloud_opac[", 11, "nlayer", "{:<17g}",
-        lambda q, x, i: q.abs_cross_all_clouds_lay[x + q.nbin * i] / q.meanmolmass_lay[i]),
+        19, "cloud_opac[", 11, "nlayer", "%-17g", _cloud_opacity),
     "_Rayleigh_cross_sect.dat": (
         "This file contains Rayleigh scattering cross sections per wavelength at each layer center. "
         "\nCross sections given in [cm^2].",
-        19, "scat_cross_sect_lay[", 20, "nlayer", "{:<24g}", lambda q, x, i: q.scat_cross_lay[x + q.nbin * i]),
+        19, "scat_cross_sect_lay[", 20, "nlayer", "%-24g", _level_major("scat_cross_lay", "nlayer")),
     "_cloud_scat_cross_sect.dat": (
         "This file contains the cloud scattering cross sections per wavelength at each layer center. "
         "\nCross sections given in [cm^2].",
-        19, "cloud_cross_sect_lay[", 21, "nlayer", "{:<25g}",
-        lambda q, x, i: q.scat_cross_all_clouds_lay[x + q.nbin * i]),
+        19, "cloud_cross_sect_lay[", 21, "nlayer", "%-25g", _level_major("scat_cross_all_clouds_lay", "nlayer")),
     "_g_0.dat": (
         "This file contains the scattering asymmetry parameter values per wavelength at each layer center."
         "\nValues are between -1 and 1.",
-        19, "g_0_lay[", 8, "nlayer", "{:<16g}", lambda q, x, i: q.g_0_tot_lay[x + q.nbin * i]),
+        19, "g_0_lay[", 8, "nlayer", "%-16g", _level_major("g_0_tot_lay", "nlayer")),
     "_transmission.dat": (
         "This file contains the transmission function for each layer and waveband.",
-        19, "transm_lay[", 11, "nlayer", "{:<18g}", lambda q, x, i: q.trans_band[x + i * q.nbin]),
+        19, "transm_lay[", 11, "nlayer", "%-18g", _level_major("trans_band", "nlayer")),
     "_optdepth.dat": (
         "This file contains the optical depth for each layer and waveband.",
-        19, "delta_tau_lay[", 14, "nlayer", "{:<20g}", lambda q, x, i: q.delta_tau_band[x + i * q.nbin]),
+        19, "delta_tau_lay[", 14, "nlayer", "%-20g", _level_major("delta_tau_band", "nlayer")),
     "_cloud_optdepth.dat": (
         "This file contains the cloud optical depth for each layer and waveband.",
-        19, "cloud_delta_tau[", 16, "nlayer", "{:<22g}", lambda q, x, i: q.delta_tau_all_clouds[x + i * q.nbin]),
+        19, "cloud_delta_tau[", 16, "nlayer", "%-22g", _level_major("delta_tau_all_clouds", "nlayer")),
     "_contribution.dat": (
         "This file contains the contribution function for each layer and waveband.",
-        19, "contr_func_lay[", 15, "nlayer", "{:<22g}", lambda q, x, i: q.contr_func_band[x + i * q.nbin]),
+        19, "contr_func_lay[", 15, "nlayer", "%-22g", _level_major("contr_func_band", "nlayer")),
     "_transweight.dat": (
         "This file contains the transmission weighting function for each layer and waveband. "
         "The units are [erg s^-1 cm^-3 sr^-1]",
-        19, "transm_weight_lay[", 18, "nlayer", "{:<25g}", lambda q, x, i: q.trans_weight_band[x + i * q.nbin]),
+        19, "transm_weight_lay[", 18, "nlayer", "%-25g", _level_major("trans_weight_band", "nlayer")),
 }
 
 
@@ -104,18 +117,22 @@ class Write(object):
 
     @staticmethod
     def _band_file(quant, read, suffix):
-        """one row per wavelength bin: bin geometry, then one cell per level"""
-        title, w4, label, lw, levels, cell, value = _BAND_FILES[suffix]
+        """one row per wavelength bin: bin geometry, then one cell per level (a whole row is formatted by one
+        printf-style call: the files hold up to millions of cells)"""
+        title, w4, label, lw, levels, cell, matrix = _BAND_FILES[suffix]
         nlev = int(getattr(quant, levels))
         X = int(quant.nbin)
+        values = matrix(quant)
+        row_fmt = cell * nlev
         with open(Write._path(quant, read, suffix), "w", encoding="utf-8") as f:
             f.write(title)
             f.write(("\n{:<8}{:<18}{:21}{:%d}" % w4).format(*_BIN_HEAD))
-            for i in range(nlev):
-                f.write(("{:<%d}{:g}{:<4}" % lw).format(label, i, "]"))
+            f.write("".join(("{:<%d}{:g}{:<4}" % lw).format(label, i, "]") for i in range(nlev)))
+            out = []
             for x in range(X):
-                f.write(Write._bin_prefix(quant, x))
-                f.write("".join(cell.format(value(quant, x, i)) for i in range(nlev)))
+                out.append(Write._bin_prefix(quant, x))
+                out.append(row_fmt % tuple(values[x].tolist()))
+            f.write("".join(out))
 
     @staticmethod
     def convert_1_0_to_yes_no(variable):
@@ -296,10 +313,9 @@ class Write(object):
             for i in range(L):
                 f.write("{:<6}{:g}{:<4}".format("B_lay[", i, "]"))
             f.write("{:<16}{:<16}".format("Planck_T_star", "Planck_T_intern"))
-            for x in range(X):
-                f.write(Write._bin_prefix(quant, x))
-                row = quant.planckband_lay[x * (L + 2):(x + 1) * (L + 2)]
-                f.write("".join("{:<16g}".format(v) for v in row))
+            rows = np.asarray(quant.planckband_lay, float).reshape(X, L + 2)
+            row_fmt = "%-16g" * (L + 2)
+            f.write("".join(Write._bin_prefix(quant, x) + row_fmt % tuple(rows[x].tolist()) for x in range(X)))
 
     @staticmethod
     def write_opacities(quant, read):
