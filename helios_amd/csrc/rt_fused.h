@@ -54,7 +54,7 @@ struct hx_rt {
     void* tp_int = nullptr;
     double *T_lay_ref = nullptr, *T_int_ref = nullptr;  // temperatures of the last refresh
     int nchunk;  // x-chunks of the totals reduction
-    int coef_tpb = 4, coef_pad = 0;  // k_rt_coef: tiles per workgroup, LDS row-pitch padding (doubles)
+    int coef_tpb = 4;  // k_rt_coef: tiles (wavefronts) per workgroup
     bool conv_shmem_raised = false;  // dynamic-LDS limit of the convection kernels lifted (deep atmospheres)
     bool coef_shmem_raised = false;  // k_rt_coef's dynamic-LDS limit lifted above 64 KiB (deep atmospheres)
 
@@ -87,7 +87,6 @@ struct hx_rt {
     double* Utile = nullptr;    // up-flux state tiles
     double* Dtile = nullptr;    // down-flux tiles (only with keep_down)
     double *U0 = nullptr, *boaK = nullptr, *Fdir0 = nullptr;  // per spectral point, Y*X
-    double* band_part = nullptr;  // [part][x][dir][i]
     double *F_down_band_n = nullptr, *F_up_band_n = nullptr;  // [x][i]
     double* tot_part = nullptr;  // [chunk][dir][i]
     double *F_up_tot = nullptr, *F_down_tot = nullptr, *F_net = nullptr, *F_net_diff = nullptr;  // I

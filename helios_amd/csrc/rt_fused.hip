@@ -104,7 +104,7 @@ KArgs make_args(hx_rt* rt) {
     memset(&a, 0, sizeof(a));
     const TileGeom& g = rt->g;
     a.X = rt->X; a.Y = rt->Y; a.L = rt->L; a.I = rt->I; a.H = rt->H; a.C = rt->C;
-    a.k = g.k; a.LPL = 0; a.ROWS = g.ROWS; a.S = g.S; a.nxb = g.nxb; a.ypb = g.ypb;
+    a.k = g.k; a.ROWS = g.ROWS; a.S = g.S; a.nxb = g.nxb; a.ypb = g.ypb;
     a.nparts = g.nparts; a.G = g.G; a.NW = g.NW; a.nblk_x = g.nblk_x; a.nblk = g.nblk;
     a.nplane = g.nplane; a.nchunk = rt->nchunk;
     a.has_vp = g.has_vp; a.pl_vp = g.pl_vp; a.pl_dd = g.pl_dd;
@@ -128,7 +128,7 @@ KArgs make_args(hx_rt* rt) {
     a.F_dir_wg = rt->F_dir_wg; a.Fc_dir_wg = rt->Fc_dir_wg; a.F_dir_band_n = rt->F_dir_band_n;
     a.gauss_w = rt->gauss_w; a.deltawave = rt->deltawave;
     a.T_int = rt->T_int; a.Bn = rt->Bn; a.coef = rt->coef; a.Utile = rt->Utile; a.Dtile = rt->Dtile;
-    a.U0 = rt->U0; a.boaK = rt->boaK; a.Fdir0 = rt->Fdir0; a.band_part = rt->band_part;
+    a.U0 = rt->U0; a.boaK = rt->boaK; a.Fdir0 = rt->Fdir0;
     a.dtau_u = rt->dtau_u; a.dtau_l = rt->dtau_l;
     a.F_down_band_n = rt->F_down_band_n; a.F_up_band_n = rt->F_up_band_n; a.tot_part = rt->tot_part;
     a.F_up_tot = rt->F_up_tot; a.F_down_tot = rt->F_down_tot; a.F_net = rt->F_net;
@@ -208,11 +208,9 @@ template <int ROWS, int TPB>
 void launch_coef_tpb(hx_rt* rt, KArgs a) {
     const TileGeom& g = rt->g;
     const int ntiles = g.nblk_x * g.nparts * g.NW;
-    const int TS = TPB * g.S, TSP = TS + rt->coef_pad;
+    const int TS = TPB * g.S, TSP = TS;
     const int NBX = g.nxb * ((TPB - 1) / (g.NW * g.nparts) + 2);
-    a.coef_pad = rt->coef_pad;
     a.coef_nbx = NBX;
-    a.coef_debug = getenv("HELIOS_RT_COEF_DEBUG") ? atoi(getenv("HELIOS_RT_COEF_DEBUG")) : 0;
     const size_t shmem = ((size_t)(rt->L + rt->I) * TSP + (size_t)rt->H * (NBX + 2)) * sizeof(double) + 2 * TS * sizeof(int);
     if (shmem > 64 * 1024 && !rt->coef_shmem_raised) {
         (void)hipFuncSetAttribute((const void*)k_rt_coef<ROWS, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -327,7 +325,6 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     }
     rt->nchunk = std::max(1, std::min(512, (rt->X + 31) / 32));
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
-    if (const char* e = getenv("HELIOS_RT_COEF_PAD")) rt->coef_pad = atoi(e);
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
     int rc = set_flux_shmem_limits(rt);

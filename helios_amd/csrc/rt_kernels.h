@@ -22,7 +22,7 @@ namespace hx {
 
 struct KArgs {
     int X, Y, L, I, H, C;
-    int k, LPL, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk, coef_pad, coef_debug, coef_nbx;
+    int k, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk, coef_nbx;
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
     int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
     double Kconst;             // 2 pi eps: source prefactor when E == 1 (scat_corr == 0)
@@ -33,7 +33,7 @@ struct KArgs {
     const double *opac_wg_lay, *opac_wg_int, *scat_cross_lay, *scat_cross_int, *mmm_lay, *mmm_int;
     const double *cl_abs_lay, *cl_abs_int, *cl_sc_lay, *cl_sc_int, *g0_tot_lay, *g0_tot_int;
     const double *F_dir_wg, *Fc_dir_wg, *F_dir_band_n, *gauss_w, *deltawave;
-    double *T_int, *Bn, *coef, *Utile, *Dtile, *U0, *boaK, *Fdir0, *band_part;
+    double *T_int, *Bn, *coef, *Utile, *Dtile, *U0, *boaK, *Fdir0;
     double *dtau_u, *dtau_l;
     double *F_down_band_n, *F_up_band_n, *tot_part, *F_up_tot, *F_down_tot, *F_net;
     size_t coef_col, flux_col;  // per-column strides (doubles) of coef / Utile / Dtile
@@ -71,25 +71,6 @@ __device__ __forceinline__ double interface_T(const double* T, int i, int L) {
 __host__ __device__ __forceinline__ size_t plane_off(int r, int lane, int ROWS) {
     (void)ROWS;
     return (size_t)r * 64 + lane;
-}
-
-template <int ROWS>
-struct RowRegs {
-    double v[ROWS];
-    __device__ __forceinline__ double& operator[](int r) { return v[r]; }
-    __device__ __forceinline__ double operator[](int r) const { return v[r]; }
-};
-
-template <int ROWS>
-__device__ __forceinline__ void load_plane(const double* __restrict__ plane, int lane, RowRegs<ROWS>& dst) {
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) dst.v[r] = plane[r * 64 + lane];
-}
-
-template <int ROWS>
-__device__ __forceinline__ void store_plane(double* __restrict__ plane, int lane, const RowRegs<ROWS>& src) {
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) plane[r * 64 + lane] = src.v[r];
 }
 
 // ---- per iteration: interface temperatures + Planck function at every node ------------------
@@ -220,7 +201,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ntiles = a.nblk_x * a.nparts * a.NW;
     const int TS = COEF_TPB * a.S;                  // spectral points staged per workgroup
-    const int TSP = TS + a.coef_pad;                // row pitch of the staged opacities
+    const int TSP = TS;                             // row pitch of the staged opacities (padding it was measured: slower)
     const int NBX = a.coef_nbx;                     // bins this workgroup's tiles can touch (upper bound)
     double* sh_lay = smem;                          // [L][TSP]  opacity at layer centres
     double* sh_int = sh_lay + (size_t)a.L * TSP;    // [I][TSP]  opacity at interfaces
@@ -272,7 +253,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
         // the same (T, P) cell of the table, whose four corners then stay in registers.  TS divides the
         // workgroup size (both are powers of two).
         const int q0 = threadIdx.x % TS, nrun = blockDim.x / TS, run = threadIdx.x / TS;
-        const int cq = a.coef_debug == 2 ? -1 : c_of_q[q0];
+        const int cq = c_of_q[q0];
         if (a.from_table) {
             // premixed k-table look-up done while staging (kernels.cu:561-608): the opacity arrays of
             // the reference are not materialised on this path (hx_rt_get rebuilds them on demand)
@@ -314,7 +295,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     }
     __syncthreads();
     const int tl = blockIdx.x * COEF_TPB + wave;
-    if (tl >= ntiles || a.coef_debug == 1) return;
+    if (tl >= ntiles) return;
     const int j = lane % a.k, q = wave * a.S + lane / a.k;
     const int c = c_of_q[q], x = x_of_q[q], xs = x - x_base;
     const bool valid = c >= 0;
