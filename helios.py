@@ -71,6 +71,9 @@ def run_helios(argv=None):
     hsfunc.calculate_conv_flux(keeper)
     hsfunc.calc_F_ratio(keeper)
     writer.write_all(keeper, reader)
+    if keeper.coupling == 1:
+        writer.write_tp_for_coupling(keeper, reader)
+        hsfunc.calculate_coupling_convergence(keeper, reader)
     if keeper.approx_f == 1:
         hsfunc.calc_tau_lw_sw(keeper, reader)
     hsfunc.success_message(keeper)

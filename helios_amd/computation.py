@@ -351,6 +351,23 @@ class Compute(object):
         quant.dev_z_lay.set(quant.z_lay)
         self.calculate_direct_beamflux(quant)
 
+    @staticmethod
+    def _stop_for_coupling_output(quant, it, nxt):
+        """coupled runs may ask for the current T-P profile every n iterations (computation.py:967-971): end the chunk
+        where the reference would write it"""
+        n = int(getattr(quant, "coupl_tp_write_interval", 0) or 0)
+        if quant.coupling == 1 and n > 0:
+            due = it + 1 + (n - 1 - (it + 1) % n) % n       # first iteration count > it with count % n == n - 1
+            nxt = min(nxt, due)
+        return nxt
+
+    @staticmethod
+    def _coupling_output(quant, it, write, read):
+        n = int(getattr(quant, "coupl_tp_write_interval", 0) or 0)
+        if quant.coupling == 1 and n > 0 and it % n == n - 1 and write is not None:
+            quant.T_lay = quant.rt.get("T_lay") if quant.rt is not None else quant.dev_T_lay.get()
+            write.write_tp_for_coupling(quant, read)
+
     def _refresh_additional_heating(self, quant):
         """heating flux of the layers from the heating density and the current layer heights, every 10th iteration
         (computation.py:913-918, :1127-1132)"""
@@ -438,6 +455,7 @@ class Compute(object):
             for r in quant.crit_relaxation_numbers:
                 if it < r < nxt:
                     nxt = int(r)
+            nxt = self._stop_for_coupling_output(quant, it, nxt)
             rt.run(it, nxt - it)
             it_prev, it = it, nxt
             counts = rt.converged_layers()                       # blocks: one small D2H per <=10 iterations
@@ -455,6 +473,7 @@ class Compute(object):
                 condition2 = T_surf < quant.plancktable_dim * quant.plancktable_step - 2
                 if not condition2:
                     quant.convection = 1
+            self._coupling_output(quant, it, write, read)
             if it in quant.crit_relaxation_numbers:
                 hsfunc.relax_radiative_convergence_criterion(quant)
                 rt.set_convergence_limit(0, quant.rad_convergence_limit)
@@ -552,6 +571,7 @@ class Compute(object):
                     if not condition2:
                         quant.convection = 1
                 quant.iter_value = np.int32(quant.iter_value + 1)
+                self._coupling_output(quant, int(quant.iter_value), write, read)
                 if quant.iter_value in quant.crit_relaxation_numbers:
                     hsfunc.relax_radiative_convergence_criterion(quant)
                 if quant.iter_value > quant.max_nr_iterations:
@@ -613,6 +633,7 @@ class Compute(object):
             for r in quant.crit_relaxation_numbers:
                 if it < r < nxt:
                     nxt = int(r)
+            nxt = self._stop_for_coupling_output(quant, it, nxt)
             if quant.opacity_mixing == "on-the-fly" and it % 10 == 0 and fastchem:
                 # mixing ratios follow the profile: once before the adjustment (for the mean molecular mass), once
                 # for the adjusted profile that the refresh sees (computation.py:1030-1036, :1056-1061)
@@ -627,6 +648,7 @@ class Compute(object):
             done = int(rt.get("done")[0])                        # one small D2H per <= 10 iterations
             if done:
                 it = int(rt.get("iters_done")[0])
+            self._coupling_output(quant, it, write, read)
             if it in quant.crit_relaxation_numbers:
                 hsfunc.relax_radiative_convergence_criterion(quant)
                 rt.set_convergence_limit(0, quant.rad_convergence_limit)

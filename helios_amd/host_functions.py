@@ -6,6 +6,8 @@ on-the-fly mixing ratios / mean molecular mass, convective adjustment, convergen
 names and the `quant` attributes they read/write follow the reference; the bodies are this project's
 own numpy code.  Everything here runs on the host on O(nlayer) vectors.
 """
+import os
+
 import numpy as np
 from numpy.polynomial.legendre import leggauss
 
@@ -497,6 +499,23 @@ def global_energy_imbalance(quant):
     n = int(quant.ninterface)
     return (quant.F_intern + quant.F_add_heat_sum[n - 2] + quant.F_smooth_sum[n - 2] - quant.F_net[n - 1]) / \
            (quant.F_down_tot[n - 1] + quant.F_intern)
+
+
+def calculate_coupling_convergence(quant, read):
+    """coupled run converged when every temperature of this coupling step is within the criterion of the previous
+    step's; the verdict (0/1) goes to `<name>_coupling_convergence.dat` for the outer script (host_functions.py:962-1018)"""
+    from .write import Write
+    verdict = 0
+    step = int(quant.coupling_iter_nr)
+    if step > 0 and quant.singlewalk == 0:
+        previous = Write.read_coupling_tp(Write._coupling_tp_path(quant, read, step - 1, previous=True), quant.fl_prec)
+        current = Write.read_coupling_tp(Write._coupling_tp_path(quant, read, step), quant.fl_prec)
+        ok = [abs(previous[t] - current[t]) / current[t] < quant.coupl_convergence_limit for t in range(len(current))]
+        verdict = 1 if all(ok) else 0
+        name = str(quant.name)
+        with open(os.path.join(read.output_path, name, name + "_coupling_convergence.dat"), "w") as f:
+            f.write(str(verdict))
+    return verdict
 
 
 def success_message(quant):

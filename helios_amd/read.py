@@ -70,6 +70,13 @@ _OPTIONS = [
     ("manual --> cloud bottom pressure [10^-6 bar]", "p_cloud_bot", "cloud_bottom_pressure", "1e5 1e3"),
     ("manual --> cloud bottom mixing ratio", "f_cloud_bot", "cloud_bottom_mixing_ratio", "1e-19 1e-19"),
     ("manual --> cloud to gas scale height ratio", "cloud_to_gas_scale_height", "cloud_to_gas_scale_height_ratio", "0.5 0.5"),
+    ("coupling mode", "coupling", "coupling_mode", "no"),
+    ("yes --> full output each iteration step", "coupling_full_output", "full_output_each_iteration_step", "no"),
+    ("yes --> force eq chem for first iteration", "force_eq_chem", "force_eq_chem_for_first_iteration", "yes"),
+    ("yes --> coupling speed up", "coupling_speed_up", "coupling_speed_up", "yes"),
+    ("yes --> coupling iteration step", "coupling_iter_nr", "coupling_iteration_step", "0"),
+    ("coupling --> write TP profile during run", "write_tp_during_run", "write_tp_profile_during_run", "no"),
+    ("coupling --> convergence criterion", "coupl_convergence_limit", "convergence_criterion", "1e-4"),
     ("debugging feedback", "debug", "debugging_feedback", "no"),
     ("precision", "prec", "precision", "double"),
     ("number of layers", "nlayer", "number_of_layers", "automatic"),
@@ -268,7 +275,14 @@ class Read(object):
         quant.add_heating_file_press_name, quant.add_heating_file_press_unit = hf[1], hf[2]
         quant.add_heating_file_data_name, quant.add_heating_file_data_conv_factor = hf[3], f64(hf[4])
         quant.force_start_tp_from_file = _yes_no(val["force_start_tp_from_file"])
-        quant.coupling = i32(0)
+        # photochemical-kinetics coupling: a file protocol around the run (read.py:521-535, :631-635, :789-803)
+        quant.coupling = _yes_no(val["coupling"])
+        quant.coupling_full_output = _yes_no(val["coupling_full_output"])
+        self.force_eq_chem = val["force_eq_chem"]
+        quant.coupling_speed_up = _yes_no(val["coupling_speed_up"])
+        quant.coupling_iter_nr = i32(val["coupling_iter_nr"])
+        quant.coupl_convergence_limit = f64(val["coupl_convergence_limit"])
+        quant.coupl_tp_write_interval = 0 if val["write_tp_during_run"] == "no" else int(val["write_tp_during_run"])
         quant.realtime_plot = i32(0)
         self.synthetic_spec = val["synthetic_spec"]
 
@@ -287,6 +301,10 @@ class Read(object):
         if self.cloud.nr_cloud_decks < 0:
             raise IOError("\nParameter Error: Number of cloud decks must be >=0. Please correct input value.")
         quant.clouds = i32(1 if self.cloud.nr_cloud_decks > 0 else 0)
+        if quant.coupling == 1 and quant.opacity_mixing == "premixed":
+            raise IOError("ERROR: Coupling mode cannot be set when a premixed opacity table is used.")
+        if quant.coupling == 1 and quant.coupling_full_output == 1:      # one output directory per coupling step
+            quant.name = str(quant.name) + "_" + str(quant.coupling_iter_nr)
         if quant.nlayer == "automatic":
             quant.nlayer = i32(np.ceil(10.5 * np.log10(quant.p_boa / quant.p_toa)))
         else:

@@ -397,6 +397,37 @@ class Write(object):
                 else:
                     f.write("{:<12}\n".format("not_avail."))
 
+    # ---- photochemical-kinetics coupling: the T-P profile handed to the chemistry code (write.py:717-771) ---------
+    @staticmethod
+    def _coupling_tp_path(quant, read, step, previous=False):
+        """`<name>_tp_coupling_<step>.dat`; with one output directory per coupling step the previous step lives in
+        `<base>_<step>/`"""
+        name = str(quant.name)
+        if previous and quant.coupling_full_output == 1:
+            name = name[:name.rfind("_") + 1] + str(step)
+        return os.path.join(read.output_path, name, name + "_tp_coupling_" + str(step) + ".dat")
+
+    @staticmethod
+    def read_coupling_tp(path, prec=float):
+        with open(path, "r") as f:
+            return [prec(ln.split()[1]) for ln in f.readlines()[1:] if len(ln.split()) > 1]
+
+    @staticmethod
+    def write_tp_for_coupling(quant, read):
+        """surface first, then the layers; from the second coupling step on the mean of this and the previous profile
+        when the speed-up is on"""
+        L, step = int(quant.nlayer), int(quant.coupling_iter_nr)
+        T_new = [quant.T_lay[L]] + [quant.T_lay[i] for i in range(L)]
+        if quant.coupling_speed_up == 1 and step > 0:
+            T_prev = Write.read_coupling_tp(Write._coupling_tp_path(quant, read, step - 1, previous=True), quant.fl_prec)
+            T_new = [0.5 * T_new[i] + 0.5 * T_prev[i] for i in range(len(T_prev))]
+        Write._dir(quant, read)
+        with open(Write._coupling_tp_path(quant, read, step), "w") as f:
+            f.write("{:<24}{:<18}".format("press.[10^-6bar]", "temp.[K]"))
+            f.write("\n{:<24g}{:<18g}".format(quant.p_int[0], T_new[0]))
+            for i in range(L):
+                f.write("\n{:<24g}{:<18g}".format(quant.p_lay[i], T_new[i + 1]))
+
     # ---- everything, in the reference's order (helios.py:100-126) --------------------------------------
     def write_all(self, quant, read):
         Write.create_output_dir_and_copy_param_file(read, quant)

@@ -452,6 +452,34 @@ def misc_state():
     return q
 
 
+def run_coupling(hs, Write, workdir, full_output, speed_up=1):
+    """three coupling steps of a fake run whose profile settles; returns the text of every file the protocol leaves"""
+    rng = np.random.default_rng(17)
+    L = 6
+    base = rng.uniform(500, 2000, L + 1)
+    texts = []
+    for step, wobble in enumerate((0.05, 1e-6, 1e-7)):
+        q = types.SimpleNamespace()
+        q.fl_prec = np.float64
+        q.nlayer = np.int32(L)
+        q.name = "cpl_%d" % step if full_output else "cpl"
+        q.coupling_iter_nr, q.coupling_speed_up = np.int32(step), np.int32(speed_up)
+        q.coupling_full_output = np.int32(full_output)
+        q.coupl_convergence_limit, q.singlewalk = 1e-4, np.int32(0)
+        q.T_lay = base * (1 + wobble * rng.uniform(-1, 1, L + 1))
+        q.p_int = 10.0 ** np.linspace(8, 0, L + 1)
+        q.p_lay = np.sqrt(q.p_int[1:] * q.p_int[:-1])
+        r = types.SimpleNamespace(output_path=workdir + "/")
+        os.makedirs(os.path.join(workdir, q.name), exist_ok=True)
+        Write.write_tp_for_coupling(q, r)
+        hs.calculate_coupling_convergence(q, r)
+        d = os.path.join(workdir, q.name)
+        for fn in sorted(os.listdir(d)):
+            if ("_tp_coupling_%d" % step) in fn or "convergence" in fn:
+                texts.append(fn + "\n" + open(os.path.join(d, fn)).read())
+    return texts
+
+
 def reader_stub(out_dir):
     r = types.SimpleNamespace()
     r.output_path = out_dir if out_dir.endswith("/") else out_dir + "/"
@@ -704,6 +732,11 @@ def main():
         data["misc.tau_file"] = np.array(open(os.path.join(wd, "rock", "rock_tau_lw_tau_sw_f_factor.dat")).read())
         hs.approx_f_from_formula(q, r)
         data["misc.f_factor"] = np.array([q.tau_lw, q.f_factor], float)
+    # photochemistry coupling: T-P hand-over files of three consecutive coupling steps and the convergence verdicts
+    for full, speed in ((0, 1), (1, 0)):
+        with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):
+            texts = run_coupling(hs, ref_write.Write, wd, full, speed)
+        data["coupling.full%d" % full] = np.array(texts)
     # kappa / c_p / entropy tables and the constant-kappa shortcut
     for mode in ("file", "water_atmo", "0.2857"):
         with tempfile.TemporaryDirectory() as wd, contextlib.redirect_stdout(io.StringIO()):

@@ -122,16 +122,7 @@ def test_start_up(tag, db, ts):
 # options of the reference this build deliberately does not carry (SURVEY.md 2.1 out-of-scope items: plotting,
 # photochemistry coupling, heating-file and albedo-file formats, Mie/FastChem paths, post-processing file formats)
 _READER_NOT_CARRIED = {
-    "quant.F_sens", "quant.tau_lw", "quant.n_plot", "quant.approx_f", "quant.kappa_file_format", "quant.star_corr_factor",
-    "quant.coupl_convergence_limit", "quant.coupl_tp_write_interval", "quant.coupling_full_output",
-    "quant.coupling_iter_nr", "quant.coupling_speed_up", "quant.add_heating_file_data_conv_factor",
-    "quant.add_heating_file_data_name", "quant.add_heating_file_header_lines", "quant.add_heating_file_press_name",
-    "quant.add_heating_file_press_unit", "quant.add_heating_path", "quant.real_star",
-    "read.albedo_file", "read.albedo_file_header_lines", "read.albedo_file_surface_name",
-    "read.albedo_file_wavelength_name", "read.albedo_file_wavelength_unit",
-    "read.fastchem_path", "read.force_eq_chem", "read.opacity_path", "read.species_file", "read.stellar_data_set",
-    "read.stellar_path", "read.temp_format", "read.temp_pressure_unit", "read.vertical_vmr_file",
-    "read.vertical_vmr_file_header_lines", "read.vertical_vmr_file_press_name", "read.vertical_vmr_file_press_units",
+    "quant.F_sens", "quant.n_plot", "quant.kappa_file_format", "quant.star_corr_factor", "quant.real_star",
 }
 
 
@@ -162,7 +153,7 @@ def test_parameter_file_and_command_line(case):
         else:
             np.testing.assert_allclose(float(got), want, rtol=1e-15, err_msg=key)
         checked += 1
-    assert checked >= 55
+    assert checked >= 85
 
 
 @pytest.mark.parametrize("tag", ["manual", "file"])
@@ -267,3 +258,13 @@ def test_rocky_planet_f_approximation(tmp_path):
     assert got == str(Z["misc.tau_file"])
     hs.approx_f_from_formula(q, r)
     np.testing.assert_allclose([q.tau_lw, q.f_factor], Z["misc.f_factor"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("full,speed", [(0, 1), (1, 0)])
+def test_coupling_protocol_files(tmp_path, full, speed):
+    """T-P hand-over files of three coupling steps (with and without averaging over the previous step, one output
+    directory per step or a shared one) and the convergence verdict files"""
+    texts = mk.run_coupling(hs, Write, str(tmp_path), full, speed)
+    assert texts == [str(t) for t in Z["coupling.full%d" % full]]
+    verdicts = [t[-1] for t in texts if "convergence" in t.split("\n")[0]]
+    assert verdicts == (["0", "0"] if speed else ["0", "1"])
