@@ -138,3 +138,30 @@ def test_random_overlap_requires_ny20(hip):
     with pytest.raises(HeliosHipError):
         hip.add_to_mixed_opac(np.ones(nlev), np.ones(n), np.ones(n), np.ones(nlev), np.ones(ny),
                               np.linspace(0.1, 0.9, ny), 1.0, 1, 1, ny, nbin, nlev)
+
+
+def test_integration_stub_from_the_docs_runs():
+    """the PyCUDA-replacement stub printed in INTEGRATION.md section 1, executed as written (library path aside): a
+    reference-style launch `f(args..., block=..., grid=...)` of temp_inter and planck_interpol_interface"""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"## 1\. The stub.*?```python\n(.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libhelios_hip.so")',
+                        'ctypes.CDLL(%r)' % os.path.join(root, "helios_amd", "libhelios_hip.so"))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    ns["_lib"].hx_last_error.restype = __import__("ctypes").c_char_p
+    mod = ns["_Module"]()
+    L = 7
+    T_lay = np.linspace(900.0, 400.0, L + 1)
+    d_T, d_Ti = ns["to_gpu"](T_lay), ns["mem_alloc"]((L + 1) * 8)
+    d_Ti.dtype, d_Ti.shape = np.float64, (L + 1,)
+    mod.get_function("temp_inter")(d_T, d_Ti, np.int32(L + 1), np.int32(0), block=(16, 1, 1), grid=(1, 1, 1))
+    T_int = d_Ti.get()
+    want = np.empty(L + 1)
+    want[1:L] = T_lay[:L - 1] + 0.5 * (T_lay[1:L] - T_lay[:L - 1])
+    want[0] = T_lay[0] - 0.5 * (T_lay[1] - T_lay[0])
+    want[L] = T_lay[L - 1] + 0.5 * (T_lay[L - 1] - T_lay[L - 2])
+    np.testing.assert_allclose(T_int, want, rtol=1e-15)
