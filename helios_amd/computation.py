@@ -10,6 +10,8 @@ device-side convergence count instead of copying flags back every iteration.
 """
 import ctypes
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -32,7 +34,8 @@ class Compute(object):
 
     def __init__(self, ctx=None):
         self._l = _lib.lib()          # raises HeliosHipError when the extension is missing
-        self.ctx = ctx or Context(0)
+        # one process drives one GPU: HELIOS_DEVICE selects it (multi-GPU launchers set it from LOCAL_RANK)
+        self.ctx = ctx or Context(int(os.environ.get("HELIOS_DEVICE", "0")))
         self.use_fused = True
 
     def _call(self, name, *args):
@@ -381,24 +384,37 @@ class Compute(object):
         return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
                 and quant.flux_calc_method == "iteration")
 
+    @staticmethod
+    def _rt_flags(q):
+        return dict(scat=_i(q.scat), dir_beam=_i(q.dir_beam), clouds=_i(q.clouds), scat_corr=_i(q.scat_corr),
+                    geom_zenith_corr=_i(q.geom_zenith_corr), smooth=_i(q.smooth), real_star=_i(q.real_star),
+                    planet_type_gas=1 if q.planet_type == "gas" else 0,
+                    kcoeff_mixing_ro=0 if q.kcoeff_mixing == "correlated-k" else 1, epsi=_f(q.epsi),
+                    epsi2=_f(q.epsi2), g_0=_f(q.g_0), i2s_transition=_f(q.i2s_transition),
+                    w_0_limit=_f(q.w_0_limit), w_0_scat_limit=_f(q.w_0_scat_limit),
+                    delta_tau_limit=_f(q.delta_tau_limit))
+
+    @staticmethod
+    def _rt_column(q):
+        return dict(g=_f(q.g), a=_f(q.a), R_planet=_f(q.R_planet), R_star=_f(q.R_star), T_star=_f(q.T_star),
+                    f_factor=_f(q.f_factor), mu_star=_f(q.mu_star), F_intern=_f(q.F_intern),
+                    rad_convergence_limit=_f(q.rad_convergence_limit), physical_tstep=_f(q.physical_tstep),
+                    adapt_interval=_i(q.adapt_interval), foreplay=_i(q.foreplay), no_atmo=_i(q.no_atmo_mode))
+
     def _make_rt(self, quant):
         """device-resident fused state for this Store (one column)"""
-        q = quant
+        return self.make_rt_batch([quant])
+
+    def make_rt_batch(self, quants):
+        """device-resident fused state of several Stores that share wavelength grid, opacity tables and the physics
+        switches and differ in their per-column parameters (planet, star, orbit, internal flux, albedo, clouds, start
+        profile): column c of the batch belongs to quants[c] (`quant.rt`, `quant.rt_col`)"""
+        q = quants[0]
         on_the_fly = q.opacity_mixing == "on-the-fly"
-        flags = dict(scat=_i(q.scat), dir_beam=_i(q.dir_beam), clouds=_i(q.clouds), scat_corr=_i(q.scat_corr),
-                     geom_zenith_corr=_i(q.geom_zenith_corr), smooth=_i(q.smooth), real_star=_i(q.real_star),
-                     planet_type_gas=1 if q.planet_type == "gas" else 0,
-                     kcoeff_mixing_ro=0 if q.kcoeff_mixing == "correlated-k" else 1, epsi=_f(q.epsi),
-                     epsi2=_f(q.epsi2), g_0=_f(q.g_0), i2s_transition=_f(q.i2s_transition),
-                     w_0_limit=_f(q.w_0_limit), w_0_scat_limit=_f(q.w_0_scat_limit),
-                     delta_tau_limit=_f(q.delta_tau_limit))
-        col = dict(g=_f(q.g), a=_f(q.a), R_planet=_f(q.R_planet), R_star=_f(q.R_star), T_star=_f(q.T_star),
-                   f_factor=_f(q.f_factor), mu_star=_f(q.mu_star), F_intern=_f(q.F_intern),
-                   rad_convergence_limit=_f(q.rad_convergence_limit), physical_tstep=_f(q.physical_tstep),
-                   adapt_interval=_i(q.adapt_interval), foreplay=_i(q.foreplay), no_atmo=_i(q.no_atmo_mode))
         nspecies = len(q.species_list) if on_the_fly else 0
-        rt = RTBatch(self._ctx_of(q), _i(q.nbin), _i(q.ny), _i(q.nlayer), 1, _i(q.ntemp), _i(q.npress),
-                     _i(q.plancktable_dim), _i(q.plancktable_step), flags, [col], nspecies=nspecies)
+        rt = RTBatch(self._ctx_of(q), _i(q.nbin), _i(q.ny), _i(q.nlayer), len(quants), _i(q.ntemp), _i(q.npress),
+                     _i(q.plancktable_dim), _i(q.plancktable_step), self._rt_flags(q),
+                     [self._rt_column(c) for c in quants], nspecies=nspecies)
         rt.set_grid(q.opac_interwave, q.opac_deltawave, q.opac_wave, q.gauss_y, q.gauss_weight, q.ktemp, q.kpress)
         if on_the_fly:
             for s, sp in enumerate(q.species_list):
@@ -410,18 +426,20 @@ class Compute(object):
                                is_cia=1 if "CIA" in sp.name else 0, in_mu=1 if hsfunc._counts_for_mu(sp) else 0)
         else:
             rt.set_premixed_tables(q.opac_k, q.opac_scat_cross, q.opac_meanmass)
-        rt.set_column_profile(0, q.p_lay, q.p_int, q.T_lay, q.surf_albedo,
-                              q.starflux if len(np.atleast_1d(q.starflux)) == _i(q.nbin) else None)
-        if q.clouds == 1:
-            rt.set_column_clouds(0, q.abs_cross_all_clouds_lay, q.abs_cross_all_clouds_int,
-                                 q.scat_cross_all_clouds_lay, q.scat_cross_all_clouds_int,
-                                 q.g_0_all_clouds_lay, q.g_0_all_clouds_int)
-        if q.c_p_lay is not None and len(np.atleast_1d(q.c_p_lay)) == _i(q.nlayer):
-            rt.set_state(0, "c_p_lay", np.asarray(q.c_p_lay, np.float64))
         if self._kappa_from_table(q):
             rt.set_kappa_table(q.entr_temp, q.entr_press, q.entr_kappa, q.entr_c_p)
-        if q.add_heating == 1:      # the flux follows the layer heights on the device (every refresh)
-            rt.set_state(0, "add_heat_dens", np.asarray(q.add_heat_dens, np.float64))
+        for c, qc in enumerate(quants):
+            qc.rt, qc.rt_col = rt, c
+            rt.set_column_profile(c, qc.p_lay, qc.p_int, qc.T_lay, qc.surf_albedo,
+                                  qc.starflux if len(np.atleast_1d(qc.starflux)) == _i(qc.nbin) else None)
+            if qc.clouds == 1:
+                rt.set_column_clouds(c, qc.abs_cross_all_clouds_lay, qc.abs_cross_all_clouds_int,
+                                     qc.scat_cross_all_clouds_lay, qc.scat_cross_all_clouds_int,
+                                     qc.g_0_all_clouds_lay, qc.g_0_all_clouds_int)
+            if qc.c_p_lay is not None and len(np.atleast_1d(qc.c_p_lay)) == _i(qc.nlayer):
+                rt.set_state(c, "c_p_lay", np.asarray(qc.c_p_lay, np.float64))
+            if qc.add_heating == 1:      # the flux follows the layer heights on the device (every refresh)
+                rt.set_state(c, "add_heat_dens", np.asarray(qc.add_heat_dens, np.float64))
         rt.build_planck_table(1 if (q.energy_correction == 1 and q.T_star > 10) else 0)
         return rt
 
@@ -431,7 +449,7 @@ class Compute(object):
         L, I = _i(quant.nlayer), _i(quant.ninterface)
         vl = np.array([np.asarray(sp.vmr_layer, np.float64)[:L] for sp in quant.species_list])
         vi = np.array([np.asarray(sp.vmr_interface, np.float64)[:I] for sp in quant.species_list])
-        quant.rt.set_column_vmr(0, vl, vi)
+        quant.rt.set_column_vmr(int(getattr(quant, "rt_col", 0)), vl, vi)
 
     def radiation_loop(self, quant, write=None, read=None, rt_plot=None):
         """iterate to radiative equilibrium (reference computation.py:827-990)"""
@@ -492,41 +510,41 @@ class Compute(object):
         """make the Store's dev_* arrays (reference layouts) reflect the fused state.  Large arrays go device to device;
         the persistent up-flux state (decoded from the tiles on the host) only when a per-stage loop is going to continue
         from it (`flux_state`)."""
-        rt = quant.rt
+        rt, col = quant.rt, int(getattr(quant, "rt_col", 0))
         X, Y, L, I = _i(quant.nbin), _i(quant.ny), _i(quant.nlayer), _i(quant.ninterface)
         for n in ("T_lay", "T_int", "F_up_band", "F_down_band", "F_dir_band", "F_up_tot", "F_down_tot", "F_net",
                   "F_net_diff", "planckband_lay", "planckband_int", "scat_cross_lay", "scat_cross_int",
                   "meanmolmass_lay", "meanmolmass_int", "delta_z_lay", "z_lay", "abort", "g_0_tot_lay",
                   "g_0_tot_int"):
-            v = rt.get(n)
+            v = rt.get(n, col)
             dev = getattr(quant, "dev_" + n, None)
             if dev is not None and dev.size == v.size:
                 dev.set(v)
         # opacities of every spectral point: rebuilt on the device if the fused look-up skipped them, then copied d2d
         # (the Store over-allocates the layer arrays to ninterface slabs, Q2)
         for n, nlev in (("opac_wg_lay", L), ("opac_wg_int", I)):
-            getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n), Y * X * nlev * 8)
+            getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n, col), Y * X * nlev * 8)
         if quant.dir_beam == 1:
             for n in ("F_dir_wg", "Fc_dir_wg"):
-                getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n), Y * X * I * 8)
+                getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n, col), Y * X * I * 8)
         else:
             quant.dev_F_dir_wg.fill_zero()
             quant.dev_Fc_dir_wg.fill_zero()
         if flux_state:
             for n in ("F_up_wg", "Fc_up_wg"):
-                v = rt.get(n)
+                v = rt.get(n, col)
                 dev = getattr(quant, "dev_" + n)
                 buf = np.zeros(dev.size)
                 buf[:v.size] = v
                 dev.set(buf)
         if quant.add_heating == 1:
             for n in ("F_add_heat_lay", "F_add_heat_sum"):
-                setattr(quant, n, rt.get(n))
+                setattr(quant, n, rt.get(n, col))
                 getattr(quant, "dev_" + n).set(getattr(quant, n))
-        quant.dev_delta_t_prefactor.set(rt.get("delta_t_prefactor"))
-        quant.dev_T_store.set(rt.get("T_store"))
+        quant.dev_delta_t_prefactor.set(rt.get("delta_t_prefactor", col))
+        quant.dev_T_store.set(rt.get("T_store", col))
         quant.dev_planckband_grid.copy_from_device(rt.device_ptr("planck_grid"), quant.dev_planckband_grid.nbytes)
-        quant.T_lay = rt.get("T_lay")
+        quant.T_lay = rt.get("T_lay", col)
         # transmission arrays for the post-loop diagnostics come from the per-stage kernel
         self.calculate_transmission(quant)
 

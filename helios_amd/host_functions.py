@@ -227,7 +227,7 @@ def calculate_vmr_for_all_species(quant):
     if quant.rt is not None:
         # interface temperatures of the CURRENT profile (the device's T_int array is one iteration old -- or not yet
         # written -- whenever the host looks): same arithmetic as temp_inter (kernels.cu:496-520)
-        quant.T_lay = quant.rt.get("T_lay")
+        quant.T_lay = quant.rt.get("T_lay", int(getattr(quant, "rt_col", 0)))
         T, L = quant.T_lay, int(quant.nlayer)
         T_int = np.empty(L + 1)
         T_int[1:L] = T[:L - 1] + 0.5 * (T[1:L] - T[:L - 1])

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Parameter sweep over independent atmosphere columns, batched on the device and sharded over the GPUs of a node.
+
+    python sweep.py -sweep "internal_temperature=100,300,1000;f_factor=0.25,0.5" -opacity_mixing synthetic -name grid
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 sweep.py -sweep "..." ...
+
+All other options are those of helios.py.  Column k writes its files to <output>/<name>_<k>/; rank 0 also writes
+<output>/<name>_sweep_spectra.npz with the emission spectra of all columns and the swept parameter values.
+"""
+import os
+import sys
+
+import numpy as np
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if "-sweep" not in argv:
+        raise SystemExit("usage: sweep.py -sweep \"key=v1,v2;key2=...\" [helios.py options]")
+    k = argv.index("-sweep")
+    spec = argv[k + 1]
+    base = argv[:k] + argv[k + 2:]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist, coll_device = None, "cpu"
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")     # "gloo": all ranks on GPU 0 (single-GPU machines)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            coll_device = "cuda"
+            os.environ["HELIOS_DEVICE"] = str(local_rank)
+        else:
+            dist.init_process_group(backend)
+    from helios_amd import sweep as sw
+    overrides = sw.expand_sweep(spec)
+    columns, spectra = sw.run_sweep(base, overrides, dist, coll_device)
+    rank = dist.get_rank() if dist is not None else 0
+    if rank == 0 and columns:
+        q = columns[0]
+        out_dir = None
+        for i, a in enumerate(base):
+            if a == "-output_directory":
+                out_dir = base[i + 1]
+        out_dir = out_dir or "./output/"
+        os.makedirs(out_dir, exist_ok=True)
+        keys = sorted({k_ for o in overrides for k_ in o})
+        np.savez(os.path.join(out_dir, sw._base_name(base) + "_sweep_spectra.npz"), F_up_TOA=spectra,
+                 wavelength=np.asarray(q.opac_wave), **{"param_" + k_: np.array([str(o.get(k_, "")) for o in overrides])
+                                                        for k_ in keys})
+        print("\nSweep of %d columns on %d GPU(s) finished." % (len(overrides), world))
+    if dist is not None:
+        dist.destroy_process_group()
+    return columns, spectra
+
+
+if __name__ == "__main__":
+    main()

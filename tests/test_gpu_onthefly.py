@@ -320,3 +320,56 @@ def test_convection_steps_on_device_match_host_functions(tmp_path, extra):
         np.testing.assert_array_equal(rt.get("marked_red"), q.marked_red)
         assert int(rt.get("done")[0]) == 0 and crit in (0, 1)      # iter < 400: the loop must go on
         assert np.abs(rt.get("T_lay") - T_dev).max() > 0            # and the temperature step was taken
+
+
+def test_sweep_batch_equals_individual_runs(tmp_path):
+    """six columns (3 internal temperatures x 2 heat-redistribution factors) through one device batch: every column ends
+    where its own single run ends, with the same files"""
+    import sweep
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "24 6 5 13",
+            "-number_of_layers", "14", "-maximum_number_of_iterations", "20000", "-name", "sw",
+            "-radiative_equilibrium_criterion", "1e-4", "-convective_adjustment", "no"]
+    out = str(tmp_path) + "/"
+    cols, spectra = sweep.main(["-sweep", "internal_temperature=100,400,900;f_factor=0.25,0.6"] + base +
+                               ["-output_directory", out + "batch/"])
+    assert len(cols) == 6 and spectra.shape == (6, 24)
+    z = np.load(os.path.join(out, "batch", "sw_sweep_spectra.npz"))
+    assert list(z["param_internal_temperature"]) == ["100", "100", "400", "400", "900", "900"]
+    k = 0
+    for T_int in ("100", "400", "900"):
+        for f in ("0.25", "0.6"):
+            single = _run_driver(base + ["-output_directory", out + "single/", "-name", "s%d" % k,
+                                         "-internal_temperature", T_int, "-f_factor", f], True)
+            q = cols[k]
+            assert int(q.iter_value) == int(single.iter_value), k
+            np.testing.assert_allclose(q.T_lay, single.T_lay, rtol=1e-12, err_msg="column %d" % k)
+            np.testing.assert_allclose(spectra[k], single.F_up_band[-24:], rtol=1e-12)
+            a = open(os.path.join(out, "batch", "sw_%d" % k, "sw_%d_tp.dat" % k)).read()
+            b = open(os.path.join(out, "single", "s%d" % k, "s%d_tp.dat" % k)).read()
+            assert a == b
+            k += 1
+
+
+def test_sweep_with_convection_and_two_ranks(tmp_path):
+    """a sweep with convective columns, sharded over two ranks (gloo hook: both on GPU 0): spectra gathered in sweep
+    order and equal to the single-process sweep"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "20 6 5 11",
+            "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "cvs",
+            "-radiative_equilibrium_criterion", "1e-4", "-kappa_value", "0.2"]
+    spec = "internal_temperature=200,1500,1800"
+    import sweep
+    cols, spectra = sweep.main(["-sweep", spec] + base + ["-output_directory", str(tmp_path) + "/one/"])
+    assert [int(c.conv_layer.sum() > 0) if c.conv_layer is not None else 0 for c in cols] == [0, 1, 1]
+    env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29523", "sweep.py", "-sweep", spec] + base +
+                       ["-output_directory", str(tmp_path) + "/two/"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    z = np.load(os.path.join(str(tmp_path), "two", "cvs_sweep_spectra.npz"))
+    np.testing.assert_allclose(z["F_up_TOA"], spectra, rtol=1e-12)
+    for k in range(3):
+        assert os.path.getsize(os.path.join(str(tmp_path), "two", "cvs_%d" % k, "cvs_%d_tp.dat" % k)) > 100

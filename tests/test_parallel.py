@@ -49,3 +49,14 @@ def test_gather_spectra_gloo_world2(ncol):
     want = np.array([[c * 100.0 + k for k in range(5)] for c in range(ncol)])
     for _rank, full in res:
         np.testing.assert_array_equal(full, want)
+
+
+def test_expand_sweep():
+    from helios_amd.sweep import expand_sweep
+    cols = expand_sweep("internal_temperature=100,300; f_factor=0.25,0.5,1")
+    assert len(cols) == 6 and cols[0] == {"internal_temperature": "100", "f_factor": "0.25"}
+    assert cols[-1] == {"internal_temperature": "300", "f_factor": "1"}
+    assert expand_sweep("") == [{}]
+    import pytest
+    with pytest.raises(ValueError):
+        expand_sweep("number_of_layers=10,20")        # changes the batch itself, cannot vary inside it
