@@ -193,7 +193,12 @@ def _convection_loop(computer, quants, rt):
 
 def _finish_column(computer, q, reader, writer):
     """post-loop diagnostics and output files of one column (helios.py:88-126), on the Store's own device arrays"""
+    tables = {n: getattr(q, n, None) for n in ("opac_k", "opac_scat_cross", "opac_meanmass")}
+    for n in tables:                  # the look-up tables live in the batch; the diagnostics do not touch them
+        setattr(q, n, np.zeros(1))
     q.copy_host_to_device()
+    for n, v in tables.items():
+        setattr(q, n, v)
     q.allocate_on_device()
     computer.sync_store_from_rt(q)
     if getattr(q, "conv_layer", None) is not None:
@@ -244,20 +249,33 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
         if not computer._fused_supported(q):
             raise IOError("sweeps run on the fused path: iterative run type, non-isothermal layers, flux iteration method")
         groups.setdefault(_batch_signature(q), []).append((q, reader))
+    import time
+    timing = dict(batch=0.0, loops=0.0, finish=0.0)
     for members in groups.values():
         quants = [q for q, _ in members]
+        t0 = time.perf_counter()
         rt = computer.make_rt_batch(quants)
+        computer.ctx.synchronize()
+        t1 = time.perf_counter()
         _radiation_loop(computer, quants, rt)
         _convection_loop(computer, quants, rt)
+        computer.ctx.synchronize()
+        t2 = time.perf_counter()
+        timing["batch"] += t1 - t0
+        timing["loops"] += t2 - t1
         for q, reader in members:
             if write_output:
                 _finish_column(computer, q, reader, writer)
             else:
                 q.T_lay = rt.get("T_lay", q.rt_col)
                 q.F_up_band = rt.get("F_up_band", q.rt_col)
+        timing["finish"] += time.perf_counter() - t2
         for q in quants:
             q.rt = None
         rt.close()
+    if rank == 0:
+        print("\nSweep timing [s]: batch set-up %.2f, iteration loops %.2f, diagnostics + output files %.2f"
+              % (timing["batch"], timing["loops"], timing["finish"]))
     X = int(columns[0][0].nbin) if columns else 0
     local = np.array([np.asarray(q.F_up_band)[-X:] for q, _ in columns]).reshape(len(columns), X)
     spectra = gather_spectra(local, dist, coll_device)
