@@ -1,6 +1,8 @@
 // Per-stage entry points, part 4: on-the-fly opacity mixing (correlated-k and random overlap),
 // H2O Rayleigh scattering, scattering-cross-section accumulation, total asymmetry parameter.
 #include "two_stream.h"
+#include <cstdlib>
+#include <cstring>
 
 using namespace hx;
 
@@ -13,26 +15,134 @@ constexpr int RO_PER_LANE = 7;       // 64 * 7 = 448 >= 400
 
 // add_to_mixed_opac (kernels.cu:3263-3399).  ONE wavefront (= one 64-thread
 // workgroup) per (bin x, level i): the 20+20 k-coefficients, the 400 pair sums and their sorted
-// copies live in LDS (13 KB per workgroup) instead of the reference's 9.9 KB of per-thread scratch.
+// copies live in LDS (12 KB per workgroup) instead of the reference's 9.9 KB of per-thread scratch.
 //
 // Sorting: the reference repeats adjacent-swap passes with a strict '<' (a stable sort of the
-// fill-ordered array).  Here every pair sum gets its rank directly: rank(e) = #{f : K_f < K_e} +
-// #{f < e : K_f == K_e} with e, f the positions in the reference's fill order -- the same permutation
-// (the order inside a group of equal sums matters: it decides which weight sits at the group's edge).
-// The sums are read from LDS as broadcasts (all lanes, one address, two sums per 128-bit read) and each
-// lane ranks its 7 sums with one fp64 compare + add per pair.  If two sums are exactly equal their ranks
-// collide (detected by writing the positions into the rank slots and reading them back, a wave-uniform
-// decision); only then a second pass adds the tie-break.  (Measured alternatives, both slower on gfx950:
-// 64-bit integer keys -- v_cmp_lt_u64 issues at a fraction of the fp64 compare rate; a first pass on the
-// upper 32 key bits -- pair sums of a dominant and a minor absorber agree to < 1e-6 far too often.)
-__global__ void __launch_bounds__(64)
+// fill-ordered array), i.e. position(e) = #{f : K_f < K_e} + #{f < e : K_f == K_e} with e, f the positions
+// in the reference's fill order (the order inside a group of equal sums matters: it decides which weight
+// sits at the group's edge).  Two implementations of that permutation:
+//  * BITONIC (default): a 512-slot bitonic network over (sum, fill position), 8 slots per lane in registers
+//    (slot p = 8*lane + s; 112 pads of +inf).  24 of its 45 steps stay inside a lane, 21 exchange with lane^m
+//    through ds_bpermute (the LDS crossbar, which leaves the VALU free).  Every phase opens with the mirrored
+//    step (p against p^(k-1)), so all compare-exchanges put the smaller sum at the lower slot and no direction
+//    masks are needed.  The exchanges keep both entries when the sums are equal, so the result is a permutation
+//    with equal sums adjacent; only if such a pair exists (wave-uniform test) the fill positions inside each
+//    group of equal sums are put in ascending order afterwards.  ~1.4 k VALU instructions per problem.
+//  * RANK (HELIOS_RO_SORT=rank; the cross-check): every pair sum is ranked against all 400 (LDS broadcasts,
+//    one fp64 compare + add per pair): 5.6 k VALU instructions per problem, 160 000 compares.
+// (Measured alternatives for the rank form, both slower on gfx950: 64-bit integer keys -- v_cmp_lt_u64 issues
+// at a fraction of the fp64 compare rate; a first pass on the upper 32 key bits -- pair sums of a dominant and
+// a minor absorber agree to < 1e-6 far too often.)
+constexpr int BT_PER_LANE = 8;
+constexpr int BT_N = 64 * BT_PER_LANE;  // 512 slots
+
+struct BtSlots {
+    double k[BT_PER_LANE];
+    int id[BT_PER_LANE];
+};
+
+__device__ __forceinline__ void bt_ce(BtSlots& v, int lo, int hi) {  // inside a lane: smaller sum to slot lo
+    const double a = v.k[lo], b = v.k[hi];
+    const int ia = v.id[lo], ib = v.id[hi];
+    const bool sw = b < a;
+    // v_min/v_max agree with the swap decision for ordered, unequal sums and change nothing for equal ones
+    asm("v_min_f64 %0, %1, %2" : "=v"(v.k[lo]) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, %2" : "=v"(v.k[hi]) : "v"(a), "v"(b));
+    v.id[lo] = sw ? ib : ia;
+    v.id[hi] = sw ? ia : ib;
+}
+
+template <int J>
+__device__ __forceinline__ void bt_lane_step(BtSlots& v) {  // slot s against s^J
+#pragma unroll
+    for (int s = 0; s < BT_PER_LANE; s++)
+        if ((s & J) == 0) bt_ce(v, s, s | J);
+}
+
+template <int W>
+__device__ __forceinline__ void bt_lane_mirror(BtSlots& v) {  // slot s against s^(W-1) inside blocks of W
+#pragma unroll
+    for (int s = 0; s < BT_PER_LANE; s++)
+        if ((s & (W - 1)) < W / 2) bt_ce(v, s, s ^ (W - 1));
+}
+
+// the value lane^M holds: DPP moves (VALU) where one or two of them express the permutation, ds_bpermute (LDS
+// crossbar) for M = 16, 31, 63.  With every exchange on the crossbar the kernel was bound by it (PMC: LDS unit 68 % busy
+// at 4.6 cycles per ds_bpermute, VALU 48 %).
+template <int M>
+__device__ __forceinline__ int bt_xor_lane(int addr, int x) {
+    if constexpr (M == 1) return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return __builtin_amdgcn_mov_dpp(x, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (M == 15) return __builtin_amdgcn_mov_dpp(x, 0x140, 0xF, 0xF, true); // row_mirror
+    else if constexpr (M == 8) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);  // row_ror:8
+    else if constexpr (M == 4)                                                              // 7 ^ 3
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+    else return __builtin_amdgcn_ds_bpermute(addr, x);
+}
+
+template <int M>
+__device__ __forceinline__ double bt_xor_lane(int addr, double x) {
+    const int lo = bt_xor_lane<M>(addr, __double2loint(x));
+    const int hi = bt_xor_lane<M>(addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double bt_fetch(int addr, double x) { return bt_xor_lane<0>(addr, x); }
+
+// exchange with lane^M: slot s meets the partner's slot s (plain step) or 7-s (MIRROR, first step of a phase)
+template <int M, bool MIRROR>
+__device__ __forceinline__ void bt_cross_step(BtSlots& v, int lane) {
+    constexpr int TOP = MIRROR ? (M + 1) / 2 : M;  // the lane bit that tells the upper partner from the lower
+    constexpr unsigned long long UPPER = TOP == 1 ? 0xAAAAAAAAAAAAAAAAull : TOP == 2 ? 0xCCCCCCCCCCCCCCCCull :
+                                         TOP == 4 ? 0xF0F0F0F0F0F0F0F0ull : TOP == 8 ? 0xFF00FF00FF00FF00ull :
+                                         TOP == 16 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
+    const int addr = (lane ^ M) << 2;
+    BtSlots n;
+#pragma unroll
+    for (int s = 0; s < BT_PER_LANE; s++) {
+        const int ps = MIRROR ? BT_PER_LANE - 1 - s : s;
+        const double pk = bt_xor_lane<M>(addr, v.k[ps]);
+        const int pid = bt_xor_lane<M>(addr, v.id[ps]);
+        // lower partner takes the smaller sum, upper partner the larger one; equal sums stay where they are.
+        // The lane masks are combined on the scalar unit.
+        const unsigned long long ge = __ballot(pk >= v.k[s]), le = __ballot(pk <= v.k[s]);
+        const bool keep = __builtin_amdgcn_inverse_ballot_w64((le & UPPER) | (ge & ~UPPER));
+        n.k[s] = keep ? v.k[s] : pk;
+        n.id[s] = keep ? v.id[s] : pid;  // partner first: lets the DPP move fold into the v_cndmask
+    }
+    v = n;
+}
+
+__device__ __forceinline__ void bt_sort(BtSlots& v, int lane) {
+    bt_lane_step<1>(v);                                                            // k = 2
+    bt_lane_mirror<4>(v); bt_lane_step<1>(v);                                      // k = 4
+    bt_lane_mirror<8>(v); bt_lane_step<2>(v); bt_lane_step<1>(v);                  // k = 8
+#define BT_LANE_TAIL bt_lane_step<4>(v); bt_lane_step<2>(v); bt_lane_step<1>(v);
+    bt_cross_step<1, true>(v, lane); BT_LANE_TAIL                                  // k = 16
+    bt_cross_step<3, true>(v, lane); bt_cross_step<1, false>(v, lane); BT_LANE_TAIL  // k = 32
+    bt_cross_step<7, true>(v, lane); bt_cross_step<2, false>(v, lane); bt_cross_step<1, false>(v, lane);
+    BT_LANE_TAIL                                                                   // k = 64
+    bt_cross_step<15, true>(v, lane); bt_cross_step<4, false>(v, lane); bt_cross_step<2, false>(v, lane);
+    bt_cross_step<1, false>(v, lane); BT_LANE_TAIL                                 // k = 128
+    bt_cross_step<31, true>(v, lane); bt_cross_step<8, false>(v, lane); bt_cross_step<4, false>(v, lane);
+    bt_cross_step<2, false>(v, lane); bt_cross_step<1, false>(v, lane); BT_LANE_TAIL  // k = 256
+    bt_cross_step<63, true>(v, lane); bt_cross_step<16, false>(v, lane); bt_cross_step<8, false>(v, lane);
+    bt_cross_step<4, false>(v, lane); bt_cross_step<2, false>(v, lane); bt_cross_step<1, false>(v, lane);
+    BT_LANE_TAIL                                                                   // k = 512
+#undef BT_LANE_TAIL
+}
+
+template <bool BITONIC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITONIC ? 4 : 1)))
 k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ opac_spec,
                     double* __restrict__ opac_wg, const double* __restrict__ meanmolmass,
                     const double* __restrict__ gauss_weight, const double* __restrict__ gauss_y,
                     double mass_spec, int s, int ro_method, int ny, int nbin, int nlev) {
     __shared__ double s_mix[RO_NY], s_add[RO_NY], s_hw[RO_NY], s_gy[RO_NY];
-    __shared__ double s_G[RO_N], s_Ks[RO_N + 64], s_Y[RO_N + 64];
-    __shared__ __align__(16) double s_K[RO_N];
+    __shared__ double s_G[BITONIC ? 1 : RO_N], s_Ks[BT_N], s_Y[BT_N];
+    __shared__ __align__(16) double s_K[BITONIC ? 2 : RO_N];
     __shared__ int s_w[RO_NY];
     int* s_slot = (int*)s_Ks;  // rank slots alias the sorted-sum buffer (used before it is filled)
     const int lane = threadIdx.x;
@@ -71,20 +181,75 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
         const int yx = cmask ? 63 - __clzll((long long)cmask) : ny;
         const bool mix_first = s_mix[0] > s_add[0];
         // fill in the reference's order (:3332-3365)
+        // e / yx and e / 20 for e < 512 as multiply-shift (exact: e * d < 2^20 / d for d <= 20), full-rate 24-bit
+        // multiplies instead of the generic 32-bit division sequence
+        const int nfirst = RO_NY * yx;
+        const int inv_yx = (1048576 + yx - 1) / yx;  // yx is wave-uniform: once per problem
+        auto pair_of = [&](int e, int& y1, int& y2) {  // y1 indexes the running mix, y2 the new species
+            const bool first = e < nfirst;
+            const int q = (int)(__umul24(e, first ? inv_yx : 52429) >> 20);  // e / yx  or  e / 20
+            const int rem = e - __umul24(q, first ? yx : RO_NY);
+            const bool q_is_mix = mix_first == first;
+            y1 = q_is_mix ? q : rem;
+            y2 = q_is_mix ? rem : q;
+        };
+        if constexpr (BITONIC) {
+            BtSlots v;
+#pragma unroll
+            for (int r = 0; r < BT_PER_LANE; r++) {
+                const int e = lane * BT_PER_LANE + r;
+                v.id[r] = e << 10;  // payload: fill position (the tie-break) above the two Gauss indices
+                v.k[r] = __builtin_inf();
+                if (e < RO_N) {
+                    int y1, y2;
+                    pair_of(e, y1, y2);
+                    v.k[r] = s_mix[y1] + s_add[y2];
+                    v.id[r] = e << 10 | y1 << 5 | y2;
+                }
+            }
+            bt_sort(v, lane);
+            // equal sums next to each other (slots 0..400)?
+            bool tie = false;
+#pragma unroll
+            for (int r = 0; r + 1 < BT_PER_LANE; r++)
+                tie = tie || (lane * BT_PER_LANE + r + 1 <= RO_N && v.k[r] == v.k[r + 1]);
+            const double knext = bt_fetch(((lane + 1) & 63) << 2, v.k[0]);
+            tie = tie || (lane * BT_PER_LANE + BT_PER_LANE <= RO_N && v.k[BT_PER_LANE - 1] == knext);
+            if (__ballot(tie) != 0) {  // rare: inside each group of equal sums, ascending fill position
+                int* s_id = (int*)s_Y;
+                int* s_id2 = s_id + BT_N;
+#pragma unroll
+                for (int r = 0; r < BT_PER_LANE; r++) {
+                    s_Ks[lane * BT_PER_LANE + r] = v.k[r];
+                    s_id[lane * BT_PER_LANE + r] = v.id[r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < BT_PER_LANE; r++) {
+                    const int p = lane * BT_PER_LANE + r;
+                    int gs = p, below = 0;
+                    while (gs > 0 && s_Ks[gs - 1] == v.k[r]) gs--;
+                    for (int f = gs; f < BT_N && s_Ks[f] == v.k[r]; f++) below += s_id[f] < v.id[r] ? 1 : 0;
+                    s_id2[gs + below] = v.id[r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < BT_PER_LANE; r++) v.id[r] = s_id2[lane * BT_PER_LANE + r];
+            }
+#pragma unroll
+            for (int r = 0; r < BT_PER_LANE; r++) {
+                const int w = lane * BT_PER_LANE + r;
+                s_Ks[w] = v.k[r];
+                s_Y[w] = w < RO_N ? s_hw[(v.id[r] >> 5) & 31] * s_hw[v.id[r] & 31] : 0.0;
+            }
+        } else {
         double ke[RO_PER_LANE];
         for (int r = 0; r < RO_PER_LANE; r++) {
             const int e = lane + 64 * r;
             ke[r] = 0.0;
             if (e < RO_N) {
-                int y1, y2;  // y1 indexes the running mix, y2 the new species
-                const int nfirst = ny * yx;
-                if (mix_first) {
-                    if (e < nfirst) { y1 = e / yx; y2 = e - yx * y1; }
-                    else            { y2 = e / ny; y1 = e - ny * y2; }
-                } else {
-                    if (e < nfirst) { y2 = e / yx; y1 = e - yx * y2; }
-                    else            { y1 = e / ny; y2 = e - ny * y1; }
-                }
+                int y1, y2;
+                pair_of(e, y1, y2);
                 ke[r] = s_mix[y1] + s_add[y2];
                 s_G[e] = s_hw[y1] * s_hw[y2];
                 s_K[e] = ke[r];
@@ -104,7 +269,8 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
                 for (int r = 0; r < RO_PER_LANE; r++) rank[r] += (kf.x < ke[r] ? 1 : 0) + (kf.y < ke[r] ? 1 : 0);
             }
         }
-        // equal sums collide on a rank slot
+        // equal sums collide on a rank slot (detected by writing the positions into the rank slots and reading
+        // them back, a wave-uniform decision); only then a second pass adds the tie-break
         for (int r = 0; r < RO_PER_LANE; r++) {
             const int e = lane + 64 * r;
             if (e < RO_N) s_slot[rank[r]] = e;
@@ -131,6 +297,7 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
                 s_Ks[rank[r]] = ke[r];
                 s_Y[rank[r]] = s_G[e];
             }
+        }
         }
         __syncthreads();
         // cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376): lane-contiguous
@@ -246,9 +413,18 @@ int hx_add_to_mixed_opac(hx_context* ctx, const double* vmr, const double* opac_
         return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 (got %d)", ny);
     const long long npair = (long long)nbin * nlay_or_nint;
     const int grid = (int)min(npair, (long long)256 * 12 * 16);
-    k_add_to_mixed_opac<<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass,
-                                                     gauss_weight, gauss_y, mass_spec, s, ro_method,
-                                                     ny, nbin, nlay_or_nint);
+    static const bool rank_sort = [] {  // cross-check / A-B knob, read once
+        const char* e = getenv("HELIOS_RO_SORT");
+        return e != nullptr && strcmp(e, "rank") == 0;
+    }();
+    if (rank_sort)
+        k_add_to_mixed_opac<false><<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
+                                                                gauss_y, mass_spec, s, ro_method, ny, nbin,
+                                                                nlay_or_nint);
+    else
+        k_add_to_mixed_opac<true><<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
+                                                               gauss_y, mass_spec, s, ro_method, ny, nbin,
+                                                               nlay_or_nint);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -140,6 +140,62 @@ def test_random_overlap_requires_ny20(hip):
                               np.linspace(0.1, 0.9, ny), 1.0, 1, 1, ny, nbin, nlev)
 
 
+def _ro_cases():
+    """random-overlap problems that stress the ordering of the 400 pair sums: generic, one absorber dominant (whole
+    runs of sums round to the same double), coarse values (many exact ties in both operands), constant curves"""
+    ny, nbin, nlev = 20, 96, 5
+    rng = np.random.default_rng(17)
+    shape = (nlev, nbin, ny)
+    fac = 1e-3 * 18.0 / 2.3
+    generic = np.sort(10.0 ** rng.uniform(-4, 0, shape), axis=2)
+    out = {}
+    out["generic"] = (generic, np.sort(10.0 ** rng.uniform(-4, 0, shape), axis=2) / fac)
+    out["wide"] = (np.sort(10.0 ** rng.uniform(-12, 6, shape), axis=2),
+                   np.sort(10.0 ** rng.uniform(-12, 6, shape), axis=2) / fac)     # sums absorb the small partner
+    out["coarse"] = (np.round(generic, 1) + 0.1, (np.round(generic[::-1], 1) + 0.1) / fac)
+    out["flat_mix"] = (np.full(shape, 0.25), out["generic"][1])
+    out["flat_both"] = (np.full(shape, 0.25), np.full(shape, 0.5) / fac)
+    out["unsorted"] = (10.0 ** rng.uniform(-2, 0, shape), 10.0 ** rng.uniform(-2, 0, shape) / fac)
+    return (ny, nbin, nlev), out
+
+
+def _ro_run(impl):
+    from helios_amd import phys_const as pc
+    from helios_amd import synthetic as syn
+    (ny, nbin, nlev), cs = _ro_cases()
+    gy, gw = syn.gauss_points(ny)
+    res = {}
+    for name, (mix0, spec) in cs.items():
+        mix = np.ascontiguousarray(mix0.reshape(-1)).copy()
+        impl.add_to_mixed_opac(np.full(nlev, 1e-3), np.ascontiguousarray(spec.reshape(-1)), mix,
+                               np.full(nlev, 2.3 * pc.AMU), gw, gy, 18.0 * pc.AMU, 1, 1, ny, nbin, nlev)
+        res[name] = mix
+    return res
+
+
+def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
+    """the bitonic network (default) against the oracle's adjacent-swap sort, incl. problems full of equal sums, and
+    against the all-pairs ranking kernel (HELIOS_RO_SORT=rank, read once per process -> child process): the two
+    device variants must agree bit for bit"""
+    import os
+    import subprocess
+    import sys
+    got = _ro_run(hip)
+    want = _ro_run(port)
+    for k in want:
+        assert np.all(np.isfinite(got[k])), k
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-12, err_msg=k)
+    out = tmp_path / "rank.npz"
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import test_gpu_stages as t; from impls import hip_impl; "
+            "np.savez(%r, **t._ro_run(hip_impl()))" % (here, str(out)))
+    env = dict(os.environ, HELIOS_RO_SORT="rank")
+    subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=os.path.dirname(here), timeout=600)
+    z = np.load(out)
+    for k in want:
+        np.testing.assert_array_equal(got[k], z[k], err_msg=k)
+
+
 def test_integration_stub_from_the_docs_runs():
     """the PyCUDA-replacement stub printed in INTEGRATION.md section 1, executed as written (library path aside): a
     reference-style launch `f(args..., block=..., grid=...)` of temp_inter and planck_interpol_interface"""
