@@ -40,7 +40,9 @@ def main(paths):
         print("   -- fp64 arithmetic / VALU          %.3f" % (f64 / g("SQ_INSTS_VALU")))
         print("   -- VALU instructions per wave      %.1f" % (g("SQ_INSTS_VALU") / g("SQ_WAVES")))
         print("   -- wait cycles / wave cycles       %.3f" % (g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")))
-        print("   -- VALU-active / busy cycles       %.3f" % (g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CYCLES")))
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs, the SQ_ACTIVE_* counters count quad-cycles summed over all SIMDs:
+        # 1024 SIMDs * (GRBM / 8) / 4 quad-cycles are available per launch
+        print("   -- VALU-active share of SIMD time  %.3f" % (g("SQ_ACTIVE_INST_VALU") / (g("GRBM_GUI_ACTIVE") * 32.0)))
         print("   -- LDS bank conflict / LDS active  %.3f" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
         print("   -- mean resident waves (LEVEL/CYC) %.2f" % (g("SQ_LEVEL_WAVES") / g("SQ_CYCLES")))
 
