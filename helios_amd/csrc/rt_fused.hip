@@ -42,7 +42,25 @@ int h2d(hx_rt* rt, void* dst, const void* src, size_t bytes) {
     return hx_h2d(rt->ctx, dst, src, bytes);
 }
 
-bool choose_geometry(int L, int Y, int X, int dir_beam, int scat_corr, TileGeom& g) {
+// ypb = Gauss points per pass (a divisor of ny), nxb = bins per workgroup: fill the lanes of a workgroup of at most
+// max_threads
+void choose_workgroup(int Y, int X, int max_threads, TileGeom& g) {
+    g.ypb = 0;
+    double best_util = -1.0;
+    for (int v = 1; v <= Y; v++) {
+        if (Y % v != 0 || v * g.k > max_threads) continue;
+        const int nx = std::min(std::max(1, max_threads / (v * g.k)), X);
+        const int lanes = nx * v * g.k;
+        const double util = (double)lanes / (((lanes + 63) / 64) * 64);
+        if (util >= best_util) {
+            best_util = util;
+            g.ypb = v;
+            g.nxb = nx;
+        }
+    }
+}
+
+bool choose_geometry(int L, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g) {
     const int H = 2 * L;
     int best_k = 0, best_rows = 0, best_pad = 1 << 30;
     int force_k = 0;
@@ -62,24 +80,19 @@ bool choose_geometry(int L, int Y, int X, int dir_beam, int scat_corr, TileGeom&
     g.k = best_k;
     g.ROWS = best_rows;
     g.S = 64 / g.k;
-    // Workgroup shape.  Single-wavefront workgroups measured fastest on MI355X (8 independent
-    // wavefronts per CU drift out of phase, so loads of one overlap the sweeps of another);
-    // HELIOS_RT_MAXTHREADS is a tuning knob (64..320).
+    // Workgroup shape.  With enough bins, single-wavefront workgroups that walk through the Gauss-point groups of their
+    // bins one after the other measured fastest on MI355X (8 independent wavefronts per CU drift out of phase, so
+    // loads of one overlap the sweeps of another: 0.40 vs 0.66 ms at 10 000 bins).  A small spectral grid cannot fill
+    // the 1024 SIMDs that way (300 bins x 50 layers: 150 wavefronts, 50 us); then 5-wavefront workgroups take all
+    // Gauss points of their bins at once (18 us).  Measured cross-over: about one single-wavefront workgroup per SIMD.
+    // HELIOS_RT_MAXTHREADS (64..320) overrides the choice.
     int max_threads = 64;
-    if (const char* e = getenv("HELIOS_RT_MAXTHREADS")) max_threads = std::max(64, std::min(320, atoi(e)));
-    // ypb = Gauss points per pass (a divisor of ny), nxb = bins per workgroup: fill the lanes
-    g.ypb = 0;
-    double best_util = -1.0;
-    for (int v = 1; v <= Y; v++) {
-        if (Y % v != 0 || v * g.k > max_threads) continue;
-        const int nx = std::min(std::max(1, max_threads / (v * g.k)), X);
-        const int lanes = nx * v * g.k;
-        const double util = (double)lanes / (((lanes + 63) / 64) * 64);
-        if (util >= best_util) {
-            best_util = util;
-            g.ypb = v;
-            g.nxb = nx;
-        }
+    if (const char* e = getenv("HELIOS_RT_MAXTHREADS")) {
+        max_threads = std::max(64, std::min(320, atoi(e)));
+        choose_workgroup(Y, X, max_threads, g);
+    } else {
+        choose_workgroup(Y, X, 64, g);
+        if (g.ypb && (long long)((X + g.nxb - 1) / g.nxb) * C < 1024) choose_workgroup(Y, X, 320, g);
     }
     if (!g.ypb) return false;
     g.nparts = Y / g.ypb;
@@ -318,7 +331,7 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     rt->C = dims->ncol;
     rt->nsweep = 3 * (flags->scat ? 1 : 0) + 1;  // computation.py:531-537 (iterative run type)
     if (const char* e = getenv("HELIOS_RT_DEBUG_NSWEEP")) rt->nsweep = atoi(e);  // profiling experiments only
-    if (!choose_geometry(rt->L, rt->Y, rt->X, flags->dir_beam, flags->scat_corr, rt->g)) {
+    if (!choose_geometry(rt->L, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g)) {
         delete rt;
         return hx_fail(ctx, HX_E_UNSUPPORTED,
                        "fused path supports nlayer <= 512; use the per-stage API");

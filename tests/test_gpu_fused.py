@@ -47,6 +47,17 @@ def test_fused_vs_oracle(ctx, port, name):
         fh.compare(f, o, c0, rtol=rtol)
 
 
+@pytest.mark.parametrize("name", ["default", "dirbeam", "clouds_g0", "L100", "L50", "L200", "L400", "L200_i2s"])
+def test_fused_vs_oracle_single_wavefront_workgroups(ctx, port, name, monkeypatch):
+    """small spectral grids default to 5-wavefront workgroups (all Gauss points of a bin at once); the shape large
+    grids get -- one wavefront walking through the Gauss-point groups -- is pinned here on the same cases"""
+    monkeypatch.setenv("HELIOS_RT_MAXTHREADS", "64")
+    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    f, grid = fh.run_fused(ctx, c0, 12, with_planck_grid=True)
+    o = fh.run_oracle(port, c0, 12, planck_grid=grid)
+    fh.compare(f, o, c0, rtol=1e-7)
+
+
 @pytest.mark.parametrize("name", [n for n in gc.CHAIN_NAMES if not n.startswith("iso")])
 def test_fused_golden(ctx, name):
     """the fused path against the reference-generated golden vectors (non-isothermal configs)"""

@@ -17,11 +17,17 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--columns", type=int, default=1)
+    ap.add_argument("--nbin", type=int, default=0, help="override the workload's number of bins")
+    ap.add_argument("--nlayer", type=int, default=0, help="override the workload's number of layers")
     ap.add_argument("--convection", action="store_true", help="also time iterations of the convection loop")
     args = ap.parse_args()
     import bench
     from helios_amd.device import Context
-    w = bench.WORKLOADS[args.workload]
+    w = dict(bench.WORKLOADS[args.workload])
+    if args.nbin:
+        w["nbin"] = args.nbin
+    if args.nlayer:
+        w["nlayer"] = args.nlayer
     c = bench.build_case(w, 20242)
     ctx = Context(0)
     rt = bench.make_batch(ctx, c, args.columns)
