@@ -57,6 +57,33 @@ class Compute(object):
             self._call("hx_corr_inc_energy", quant.dev_planckband_grid.d, quant.dev_starflux.d,
                        quant.dev_opac_deltawave.d, _i(quant.real_star), _i(quant.nbin), _f(quant.T_star),
                        _i(quant.plancktable_dim))
+            self.print_energy_correction()
+
+    def print_energy_correction(self):
+        """the message the reference's kernel prints from the device (kernels.cu:453-457)"""
+        corr = self.ctx.diag()["energy_correction"]
+        if corr > 1:
+            print("\nEnergy budget corrected (increased) by %.2f percent." % (100.0 * (corr - 1.0)))
+        elif 0 < corr < 1:
+            print("\nEnergy budget corrected (decreased) by %.2f percent." % (100.0 * (1.0 - corr)))
+
+    def report_diagnostics(self, quant, always=False):
+        """debugging feedback: what the reference's kernels print line by line when `debug = 1` (negative fluxes,
+        kernels.cu:1458 ff.; limited G functions, :227) arrives here as counts since the last report; the
+        malfunction message of the random-overlap re-binning (:3385) is reported whenever it occurred"""
+        if not (always or _i(quant.debug or 0) == 1):
+            return None
+        d = self.ctx.diag()
+        self.ctx.diag_reset()
+        if d["negative_down_flux"] or d["negative_up_flux"]:
+            print("WARNING WARNING WARNING WARNING -- negative flux found: %d downward, %d upward values !!!"
+                  % (d["negative_down_flux"], d["negative_up_flux"]))
+        if d["g_limited"]:
+            print("WARNING: G_functions are being artificially limited!!! (%d values)" % d["g_limited"])
+        if d["ro_rebin_skipped"]:
+            print("ERROR ERROR ERROR: Rebinning algorithm in k-table RO method is malfunctioning. "
+                  "Please double-check source code!!! (%d Gauss points)" % d["ro_rebin_skipped"])
+        return d
 
     # ---- every iteration -----------------------------------------------------------------------------
     def interpolate_temperatures(self, quant):
@@ -392,7 +419,7 @@ class Compute(object):
                     kcoeff_mixing_ro=0 if q.kcoeff_mixing == "correlated-k" else 1, epsi=_f(q.epsi),
                     epsi2=_f(q.epsi2), g_0=_f(q.g_0), i2s_transition=_f(q.i2s_transition),
                     w_0_limit=_f(q.w_0_limit), w_0_scat_limit=_f(q.w_0_scat_limit),
-                    delta_tau_limit=_f(q.delta_tau_limit))
+                    delta_tau_limit=_f(q.delta_tau_limit), debug=_i(q.debug or 0))
 
     @staticmethod
     def _rt_column(q):
@@ -441,6 +468,8 @@ class Compute(object):
             if qc.add_heating == 1:      # the flux follows the layer heights on the device (every refresh)
                 rt.set_state(c, "add_heat_dens", np.asarray(qc.add_heat_dens, np.float64))
         rt.build_planck_table(1 if (q.energy_correction == 1 and q.T_star > 10) else 0)
+        if _i(q.debug or 0) == 1:
+            rt.keep_down_fluxes(True)     # so that the negative-flux count covers the downward fluxes too
         return rt
 
     def _push_vmr(self, quant):
@@ -475,6 +504,7 @@ class Compute(object):
                     nxt = int(r)
             nxt = self._stop_for_coupling_output(quant, it, nxt)
             rt.run(it, nxt - it)
+            self.report_diagnostics(quant)
             it_prev, it = it, nxt
             counts = rt.converged_layers()                       # blocks: one small D2H per <=10 iterations
             done = int(rt.get("done")[0])
@@ -566,6 +596,7 @@ class Compute(object):
                 print("Flux calculation method unclear. Check parameter file for typos. Aborting...")
                 raise SystemExit()
             self.integrate_flux(quant)
+            self.report_diagnostics(quant)
             if quant.singlewalk == 0:
                 abortsum = 0
                 quant.marked_red = np.zeros(L + 1, np.int32)
@@ -662,6 +693,7 @@ class Compute(object):
                 rt.conv_run(it + 1, nxt - it - 1)
             else:
                 rt.conv_run(it, nxt - it)
+            self.report_diagnostics(quant)
             it = nxt
             done = int(rt.get("done")[0])                        # one small D2H per <= 10 iterations
             if done:
@@ -740,6 +772,7 @@ class Compute(object):
             else:
                 self.solve_for_spectral_fluxes_via_matrix(quant)
             self.integrate_flux(quant)
+            self.report_diagnostics(quant)
             self._pull_for_convection(quant)
             hsfunc.mark_convective_layers(quant, stitching=1)
             if quant.physical_tstep != 0:

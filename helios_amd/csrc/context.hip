@@ -3,6 +3,8 @@
 // (source/quantities.py:463-665, source/computation.py:24).
 #include "hx_common.h"
 
+#include <algorithm>
+
 extern "C" {
 
 int hx_abi_version(void) { return 1; }
@@ -26,6 +28,13 @@ int hx_create(int device_id, hx_context** out_ctx) {
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    ctx->diag = nullptr;
+    e = hipMalloc((void**)&ctx->diag, HX_DIAG_SLOTS * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->diag, 0, HX_DIAG_SLOTS * sizeof(unsigned long long), ctx->stream);
+    if (e != hipSuccess) {
+        (void)hx_destroy(ctx);
+        return -(int)e;
+    }
     *out_ctx = ctx;
     return 0;
 }
@@ -37,7 +46,54 @@ int hx_destroy(hx_context* ctx) {
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->diag) (void)hipFree(ctx->diag);
     delete ctx;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+template <bool ABS>
+__global__ void __launch_bounds__(256) k_count(const double* __restrict__ a, size_t n, double limit,
+                                                unsigned long long* __restrict__ slot) {
+    unsigned long long mine = 0;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+        mine += ABS ? (fabs(a[k]) >= limit ? 1 : 0) : (a[k] < 0.0 ? 1 : 0);
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(slot, mine);
+}
+}  // namespace
+
+extern "C" {
+
+int hx_internal_count_negative(hx_context* ctx, const double* a, size_t n, int slot) {
+    if (!a || !n) return 0;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    k_count<false><<<grid, 256, 0, ctx->stream>>>(a, n, 0.0, ctx->diag + slot);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_internal_count_abs_ge(hx_context* ctx, const double* a, size_t n, double limit, int slot) {
+    if (!a || !n) return 0;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+    k_count<true><<<grid, 256, 0, ctx->stream>>>(a, n, limit, ctx->diag + slot);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int hx_diag_read(hx_context* ctx, hx_diag* out) {
+    static_assert(sizeof(hx_diag) == HX_DIAG_SLOTS * sizeof(unsigned long long), "hx_diag layout");
+    if (!ctx || !out) return HX_E_ARG;
+    HX_HIP(ctx, hipMemcpyAsync(out, ctx->diag, sizeof(hx_diag), hipMemcpyDeviceToHost, ctx->stream));
+    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hx_diag_reset(hx_context* ctx) {
+    if (!ctx) return HX_E_ARG;
+    HX_HIP(ctx, hipMemsetAsync(ctx->diag, 0, HX_DIAG_SLOTS * sizeof(unsigned long long), ctx->stream));
     return 0;
 }
 

@@ -13,7 +13,16 @@ struct hx_context {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     char err[512];
+    unsigned long long* diag;  // device record behind hx_diag_read: HX_DIAG_* slots
 };
+
+// slots of hx_context::diag (the layout of hx_diag in include/helios_hip.h)
+enum { HX_DIAG_NEG_DOWN = 0, HX_DIAG_NEG_UP = 1, HX_DIAG_G_LIMITED = 2, HX_DIAG_RO_REBIN = 3, HX_DIAG_ENERGY = 4,
+       HX_DIAG_SLOTS = 8 };
+
+// post-pass counters used by the debug = 1 variants of the per-stage and fused solvers (context.hip)
+extern "C" int hx_internal_count_negative(hx_context* ctx, const double* a, size_t n, int slot);
+extern "C" int hx_internal_count_abs_ge(hx_context* ctx, const double* a, size_t n, double limit, int slot);
 
 inline int hx_fail(hx_context* ctx, int code, const char* fmt, ...) {
     if (ctx) {

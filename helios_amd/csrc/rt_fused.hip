@@ -140,6 +140,7 @@ KArgs make_args(hx_rt* rt) {
     a.cl_sc_int = rt->cl_sc_int; a.g0_tot_lay = rt->g0_tot_lay; a.g0_tot_int = rt->g0_tot_int;
     a.F_dir_wg = rt->F_dir_wg; a.Fc_dir_wg = rt->Fc_dir_wg; a.F_dir_band_n = rt->F_dir_band_n;
     a.gauss_w = rt->gauss_w; a.deltawave = rt->deltawave;
+    a.diag = rt->f.debug == 1 ? rt->ctx->diag : nullptr;
     a.T_int = rt->T_int; a.Bn = rt->Bn; a.coef = rt->coef; a.Utile = rt->Utile; a.Dtile = rt->Dtile;
     a.U0 = rt->U0; a.boaK = rt->boaK; a.Fdir0 = rt->Fdir0;
     a.dtau_u = rt->dtau_u; a.dtau_l = rt->dtau_l;
@@ -778,6 +779,15 @@ int hx_rt_refresh(hx_rt* rt) {
 
 namespace { int kappa_cp_from_table(hx_rt* rt, bool refresh_T_int); }
 
+// debug = 1: the negative-flux warnings of fband_noniso (kernels.cu:1663 ff.) as counts over the state the sweeps leave
+// behind (up-fluxes always, down-fluxes when they are kept: hx_rt_set_state "keep_down")
+static int count_negative_fluxes(hx_rt* rt) {
+    const size_t n = (size_t)rt->C * rt->g.flux_elems_per_col;
+    int rc = hx_internal_count_negative(rt->ctx, rt->Utile, n, HX_DIAG_NEG_UP);
+    if (!rc && rt->keep_down && rt->Dtile) rc = hx_internal_count_negative(rt->ctx, rt->Dtile, n, HX_DIAG_NEG_DOWN);
+    return rc;
+}
+
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
     hx_context* ctx = rt->ctx;
     KArgs a = make_args(rt);
@@ -791,6 +801,10 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         ProfScope ps(rt, "rt_flux");
         DISPATCH_ROWS(launch_flux, rt, a);
         HX_LAUNCH_CHECK(ctx);
+    }
+    if (rt->f.debug == 1) {
+        int rc = count_negative_fluxes(rt);
+        if (rc) return rc;
     }
     {
         ProfScope ps(rt, "rt_totals_a");
@@ -964,6 +978,10 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
         ProfScope ps(rt, "rt_flux");
         DISPATCH_ROWS(launch_flux, rt, a);
         HX_LAUNCH_CHECK(ctx);
+    }
+    if (rt->f.debug == 1) {
+        int rc = count_negative_fluxes(rt);
+        if (rc) return rc;
     }
     {
         ProfScope ps(rt, "rt_totals_a");

@@ -42,6 +42,7 @@ struct KArgs {
     const double *ktable, *crosstable, *ktemp, *kpress;
     const TPIndex *tp_lay, *tp_int;  // [C][I] fractional table indices of the levels
     int ntemp, npress, from_table;
+    unsigned long long* diag;  // hx_context::diag when the batch runs with debug = 1, else nullptr
 };
 
 // the subset k_rt_flux needs (a leaner argument block keeps its SGPR pressure -- and with it the VGPR
@@ -336,6 +337,10 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             const double dtau = dtau_gas + dcol * (cab + csc) / mu;
             const Slab s = slab_coeffs(w0, dtau, g0, a.epsi, a.epsi2, cp.mu_star, a.scat_corr, a.i2s,
                                        a.dir_beam == 1);
+            if (a.diag != nullptr && a.dir_beam == 1) {  // G_limiter's warning (kernels.cu:217-231) as a count
+                const int nlim = (fabs(s.Gp) >= 1e8 ? 1 : 0) + (fabs(s.Gm) >= 1e8 ? 1 : 0);
+                if (nlim) atomicAdd(a.diag + HX_DIAG_G_LIMITED, (unsigned long long)nlim);
+            }
             const double invM = 1.0 / s.M;
             alpha = s.P * invM;
             beta = -s.N * invM;

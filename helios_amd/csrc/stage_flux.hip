@@ -253,12 +253,17 @@ int hx_fband_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, const doub
                  double f_factor, double mu_star, int ny, double epsi, int dir_beam, int clouds,
                  int scat_corr, int debug, double i2s_transition) {
     (void)singlewalk;
-    (void)debug;
     k_fband_iso<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
         F_down_wg, F_up_wg, F_dir_wg, planckband_lay, w_0, M_term, N_term, P_term, G_plus, G_minus,
         surf_albedo, g_0_tot_lay, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
         dir_beam, clouds, scat_corr, i2s_transition);
     HX_LAUNCH_CHECK(ctx);
+    if (debug == 1) {  // the negative-flux warnings (kernels.cu:1458, :1512) as counts
+        const size_t n = (size_t)ny * nbin * numinterfaces;
+        int rc = hx_internal_count_negative(ctx, F_down_wg, n, HX_DIAG_NEG_DOWN);
+        if (!rc) rc = hx_internal_count_negative(ctx, F_up_wg, n, HX_DIAG_NEG_UP);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -278,7 +283,6 @@ int hx_fband_noniso(hx_context* ctx, double* F_down_wg, double* F_up_wg, double*
                     double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit,
                     int dir_beam, int clouds, int scat_corr, int debug, double i2s_transition) {
     (void)singlewalk;
-    (void)debug;
     NonisoCoef q = {w_0_upper, w_0_lower, delta_tau_wg_upper, delta_tau_wg_lower,
                     delta_tau_all_clouds_upper, delta_tau_all_clouds_lower, M_upper, M_lower,
                     N_upper, N_lower, P_upper, P_lower, G_plus_upper, G_plus_lower, G_minus_upper,
@@ -288,6 +292,14 @@ int hx_fband_noniso(hx_context* ctx, double* F_down_wg, double* F_up_wg, double*
         q, surf_albedo, g_0_tot_lay, g_0_tot_int, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star,
         ny, epsi, delta_tau_limit, dir_beam, clouds, scat_corr, i2s_transition);
     HX_LAUNCH_CHECK(ctx);
+    if (debug == 1) {  // kernels.cu:1663, :1690, :1767, :1794
+        const size_t nc = (size_t)ny * nbin;
+        int rc = hx_internal_count_negative(ctx, F_down_wg, nc * numinterfaces, HX_DIAG_NEG_DOWN);
+        if (!rc) rc = hx_internal_count_negative(ctx, Fc_down_wg, nc * (numinterfaces - 1), HX_DIAG_NEG_DOWN);
+        if (!rc) rc = hx_internal_count_negative(ctx, F_up_wg, nc * numinterfaces, HX_DIAG_NEG_UP);
+        if (!rc) rc = hx_internal_count_negative(ctx, Fc_up_wg, nc * (numinterfaces - 1), HX_DIAG_NEG_UP);
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -47,7 +47,7 @@ k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
 // fixed order (the reference lets every thread redo the whole sum), then rescales.
 __global__ void __launch_bounds__(1024)
 k_corr_inc_energy(double* __restrict__ spec, const double* __restrict__ dlambda, int realstar,
-                  int nbin, double Tstar) {
+                  int nbin, double Tstar, double* __restrict__ factor_out) {
     __shared__ double part[1024];
     double s = 0.0;
     for (int x = threadIdx.x; x < nbin; x += blockDim.x)
@@ -59,6 +59,7 @@ k_corr_inc_energy(double* __restrict__ spec, const double* __restrict__ dlambda,
         __syncthreads();
     }
     const double corr = HX_STEFANBOLTZMANN * pow(Tstar, 4.0) / part[0];
+    if (threadIdx.x == 0) *factor_out = corr;  // the reference prints it (kernels.cu:455); here: hx_diag_read
     for (int x = threadIdx.x; x < nbin; x += blockDim.x) spec[x] *= corr;
 }
 
@@ -171,7 +172,8 @@ int hx_internal_planck_star_row(hx_context* ctx, double* row, const double* lamb
 int hx_corr_inc_energy(hx_context* ctx, double* planck_grid, double* starflux,
                        const double* deltalambda, int realstar, int nwave, double Tstar, int dim) {
     double* spec = realstar == 1 ? starflux : planck_grid + (size_t)dim * nwave;
-    k_corr_inc_energy<<<1, 1024, 0, ctx->stream>>>(spec, deltalambda, realstar, nwave, Tstar);
+    k_corr_inc_energy<<<1, 1024, 0, ctx->stream>>>(spec, deltalambda, realstar, nwave, Tstar,
+                                                   reinterpret_cast<double*>(ctx->diag + HX_DIAG_ENERGY));
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -252,13 +252,18 @@ int hx_fband_matrix_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, con
                         double epsi, int dir_beam, int clouds, int scat_corr, int debug,
                         double i2s_transition) {
     (void)singlewalk;
-    (void)debug;
     k_fband_matrix_iso<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
         F_down_wg, F_up_wg, F_dir_wg, planckband_lay, w_0, M_term, N_term, P_term, G_plus, G_minus,
         g_0_tot_lay, alpha, beta, source_term_down, source_term_up, c_prime, d_prime, scat_trigger,
         trans_wg, surf_albedo, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
         dir_beam, clouds, scat_corr, i2s_transition);
     HX_LAUNCH_CHECK(ctx);
+    if (debug == 1) {  // kernels.cu:1990, :2018 (the solution vector of :2268 lands in these arrays)
+        const size_t n = (size_t)ny * nbin * numinterfaces;
+        int rc = hx_internal_count_negative(ctx, F_down_wg, n, HX_DIAG_NEG_DOWN);
+        if (!rc) rc = hx_internal_count_negative(ctx, F_up_wg, n, HX_DIAG_NEG_UP);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -278,7 +283,6 @@ int hx_fband_matrix_noniso(
     int nbin, double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit,
     int dir_beam, int clouds, int scat_corr, int debug, double i2s_transition) {
     (void)singlewalk;
-    (void)debug;
     MatrixNoniso q = {w_0_upper, w_0_lower, delta_tau_wg_upper, delta_tau_wg_lower,
                       delta_tau_all_clouds_upper, delta_tau_all_clouds_lower, M_upper, M_lower,
                       N_upper, N_lower, P_upper, P_lower, G_plus_upper, G_plus_lower, G_minus_upper,
@@ -289,6 +293,14 @@ int hx_fband_matrix_noniso(
         q, scat_trigger, surf_albedo, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
         delta_tau_limit, dir_beam, clouds, scat_corr, i2s_transition);
     HX_LAUNCH_CHECK(ctx);
+    if (debug == 1) {  // kernels.cu:2268, :2329, :2351, :2397, :2418
+        const size_t nc = (size_t)ny * nbin;
+        int rc = hx_internal_count_negative(ctx, F_down_wg, nc * numinterfaces, HX_DIAG_NEG_DOWN);
+        if (!rc) rc = hx_internal_count_negative(ctx, Fc_down_wg, nc * (numinterfaces - 1), HX_DIAG_NEG_DOWN);
+        if (!rc) rc = hx_internal_count_negative(ctx, F_up_wg, nc * numinterfaces, HX_DIAG_NEG_UP);
+        if (!rc) rc = hx_internal_count_negative(ctx, Fc_up_wg, nc * (numinterfaces - 1), HX_DIAG_NEG_UP);
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITONIC
 k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ opac_spec,
                     double* __restrict__ opac_wg, const double* __restrict__ meanmolmass,
                     const double* __restrict__ gauss_weight, const double* __restrict__ gauss_y,
-                    double mass_spec, int s, int ro_method, int ny, int nbin, int nlev) {
+                    double mass_spec, int s, int ro_method, int ny, int nbin, int nlev,
+                    unsigned long long* __restrict__ rebin_skipped) {
     __shared__ double s_mix[RO_NY], s_add[RO_NY], s_hw[RO_NY], s_gy[RO_NY];
     __shared__ double s_G[BITONIC ? 1 : RO_N], s_Ks[BT_N], s_Y[BT_N];
     __shared__ __align__(16) double s_K[BITONIC ? 2 : RO_N];
@@ -332,9 +333,17 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
             s_w[lane] = lo;
         }
         __syncthreads();
-        if (lane == 0)
+        if (lane == 0) {
+            // a Gauss point that falls into the interval of its predecessor takes the next one; the reference reports
+            // this as a malfunction of the re-binning (:3383-3387), here it is counted (hx_diag_read)
+            int skipped = 0;
             for (int q = 1; q < ny; q++)
-                if (s_w[q] <= s_w[q - 1]) s_w[q] = s_w[q - 1] + 1;
+                if (s_w[q] <= s_w[q - 1]) {
+                    s_w[q] = s_w[q - 1] + 1;
+                    skipped++;
+                }
+            if (skipped) atomicAdd(rebin_skipped, (unsigned long long)skipped);
+        }
         __syncthreads();
         if (lane < ny) {
             const int w = s_w[lane];
@@ -420,11 +429,11 @@ int hx_add_to_mixed_opac(hx_context* ctx, const double* vmr, const double* opac_
     if (rank_sort)
         k_add_to_mixed_opac<false><<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
                                                                 gauss_y, mass_spec, s, ro_method, ny, nbin,
-                                                                nlay_or_nint);
+                                                                nlay_or_nint, ctx->diag + HX_DIAG_RO_REBIN);
     else
         k_add_to_mixed_opac<true><<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
                                                                gauss_y, mass_spec, s, ro_method, ny, nbin,
-                                                               nlay_or_nint);
+                                                               nlay_or_nint, ctx->diag + HX_DIAG_RO_REBIN);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -1,5 +1,6 @@
 // Per-stage entry points, part 2: transmission coefficients, layer thickness, direct beam.
 #include "two_stream.h"
+#include <initializer_list>
 
 using namespace hx;
 
@@ -198,7 +199,6 @@ int hx_calc_trans_iso(hx_context* ctx, double* trans_wg, double* delta_tau_wg, d
                       double epsi, double epsi2, double mu_star, double w_0_limit,
                       double w_0_scat_limit, int scat, int nbin, int ny, int nlayer, int clouds,
                       int scat_corr, int debug, double i2s_transition) {
-    (void)debug;
     dim3 grid(hx_cdiv((long long)ny * nbin, 256), nlayer);
     k_calc_trans_iso<<<grid, 256, 0, ctx->stream>>>(
         trans_wg, delta_tau_wg, M_term, N_term, P_term, G_plus, G_minus, delta_colmass, opac_wg_lay,
@@ -206,6 +206,13 @@ int hx_calc_trans_iso(hx_context* ctx, double* trans_wg, double* delta_tau_wg, d
         delta_tau_all_clouds, w_0, g_0_tot_lay, scat_trigger, g_0, epsi, epsi2, mu_star, w_0_limit,
         w_0_scat_limit, scat, nbin, ny, nlayer, clouds, scat_corr, i2s_transition);
     HX_LAUNCH_CHECK(ctx);
+    if (debug == 1) {  // G_limiter's warning (kernels.cu:217-231) as a count: clipped values are exactly +-1e8
+        const size_t n = (size_t)ny * nbin * nlayer;
+        for (const double* G : {G_plus, G_minus}) {
+            const int rc = hx_internal_count_abs_ge(ctx, G, n, 1e8, HX_DIAG_G_LIMITED);
+            if (rc) return rc;
+        }
+    }
     return 0;
 }
 
@@ -223,7 +230,6 @@ int hx_calc_trans_noniso(
     const double* g_0_tot_lay, const double* g_0_tot_int, int* scat_trigger, double g_0, double epsi,
     double epsi2, double mu_star, double w_0_limit, double w_0_scat_limit, int scat, int nbin, int ny,
     int nlayer, int clouds, int scat_corr, int debug, double i2s_transition) {
-    (void)debug;
     NonisoOut o = {trans_wg_upper, trans_wg_lower, delta_tau_wg_upper, delta_tau_wg_lower, M_upper,
                    M_lower, N_upper, N_lower, P_upper, P_lower, G_plus_upper, G_plus_lower,
                    G_minus_upper, G_minus_lower, delta_tau_all_clouds_upper,
@@ -237,6 +243,13 @@ int hx_calc_trans_noniso(
                                                       w_0_scat_limit, scat, nbin, ny, nlayer, clouds,
                                                       scat_corr, i2s_transition);
     HX_LAUNCH_CHECK(ctx);
+    if (debug == 1) {
+        const size_t n = (size_t)ny * nbin * nlayer;
+        for (const double* G : {G_plus_upper, G_plus_lower, G_minus_upper, G_minus_lower}) {
+            const int rc = hx_internal_count_abs_ge(ctx, G, n, 1e8, HX_DIAG_G_LIMITED);
+            if (rc) return rc;
+        }
+    }
     return 0;
 }
 

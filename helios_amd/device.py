@@ -9,6 +9,13 @@ import numpy as np
 from . import _lib
 
 
+class HxDiag(ctypes.Structure):
+    """hx_diag of include/helios_hip.h"""
+    _fields_ = [("negative_down_flux", ctypes.c_uint64), ("negative_up_flux", ctypes.c_uint64),
+                ("g_limited", ctypes.c_uint64), ("ro_rebin_skipped", ctypes.c_uint64),
+                ("energy_correction", ctypes.c_double), ("reserved", ctypes.c_uint64 * 3)]
+
+
 class Context(object):
     """one HIP device + one stream (include/helios_hip.h section 1)"""
 
@@ -37,6 +44,16 @@ class Context(object):
         free, total = ctypes.c_size_t(), ctypes.c_size_t()
         self.check(self._l.hx_mem_info(self.handle, ctypes.byref(free), ctypes.byref(total)))
         return free.value, total.value
+
+    def diag(self):
+        """the conditions the reference reports through device-side printf, as counts (hx_diag in helios_hip.h);
+        blocks until the stream has drained"""
+        d = HxDiag()
+        self.check(self._l.hx_diag_read(self.handle, ctypes.byref(d)), "hx_diag_read")
+        return {k: getattr(d, k) for k, _ in HxDiag._fields_ if k != "reserved"}
+
+    def diag_reset(self):
+        self.check(self._l.hx_diag_reset(self.handle), "hx_diag_reset")
 
     def timer_start(self):
         self.check(self._l.hx_timer_start(self.handle))

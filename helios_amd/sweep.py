@@ -104,6 +104,7 @@ def _radiation_loop(computer, quants, rt):
             if it < r < nxt:
                 nxt = int(r)
         rt.run(it, nxt - it)
+        computer.report_diagnostics(quants[0])
         it = nxt
         for c in np.nonzero(~done)[0]:
             if int(rt.get("done", c)[0]):
@@ -168,6 +169,7 @@ def _convection_loop(computer, quants, rt):
             rt.conv_run(it + 1, nxt - it - 1)
         else:
             rt.conv_run(it, nxt - it)
+        computer.report_diagnostics(quants[0])
         it = nxt
         for c in np.nonzero(running)[0]:
             if int(rt.get("done", c)[0]):

@@ -46,6 +46,20 @@ int hx_destroy(hx_context* ctx);
 int hx_sync(hx_context* ctx);
 const char* hx_last_error(hx_context* ctx);
 int hx_device_name(hx_context* ctx, char* buf, int buflen);
+/* Conditions the reference reports through device-side printf (kernels.cu:227 G_limiter, :1458 ff. negative fluxes,
+ * :3385 random-overlap re-binning, :455 energy-budget correction) are counted in a per-context device record
+ * instead.  The flux and G counters only run in calls that are given debug = 1 (the reference prints under the same
+ * flag); the re-binning counter and the correction factor are always kept.  hx_diag_read blocks. */
+typedef struct hx_diag {
+    uint64_t negative_down_flux; /* entries < 0 in F_down_wg / Fc_down_wg after a flux solve */
+    uint64_t negative_up_flux;   /* entries < 0 in F_up_wg / Fc_up_wg */
+    uint64_t g_limited;          /* G+ / G- values clipped to +-1e8 */
+    uint64_t ro_rebin_skipped;   /* Gauss points that met an already used interval in add_to_mixed_opac */
+    double energy_correction;    /* factor applied by the last hx_corr_inc_energy (0 = none yet) */
+    uint64_t reserved[3];
+} hx_diag;
+int hx_diag_read(hx_context* ctx, hx_diag* out);
+int hx_diag_reset(hx_context* ctx);
 int hx_abi_version(void);
 /* raw hipStream_t of the context (for interop with another runtime's stream guards) */
 void* hx_stream(hx_context* ctx);

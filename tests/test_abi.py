@@ -32,7 +32,9 @@ def test_header_covers_every_hot_path_kernel():
 
 def test_struct_layouts_match():
     from helios_amd import rt
+    from helios_amd.device import HxDiag
     rt._check_struct_sizes(_lib.lib())
+    assert ctypes.sizeof(HxDiag) == 64          # 8 slots of 8 bytes (static_assert in context.hip)
 
 
 def test_no_gpu_means_loud_failure():

@@ -66,6 +66,26 @@ def test_run_helios_fused_equals_stagewise(tmp_path):
         assert os.path.getsize(os.path.join(str(tmp_path), "drv", "drv" + suffix)) > 100
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_run_helios_with_debugging_feedback(tmp_path, capfd, fused):
+    """`debugging_feedback = yes`: the run is the same as without it (the counters of hx_diag are read and reported
+    between iterations instead of device-side printf), and the energy-budget message appears as in the reference"""
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
+            "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "dbg",
+            "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-3",
+            "-convective_adjustment", "no", "-direct_irradiation_beam", "yes"]
+    a = _run_driver(argv, fused)
+    capfd.readouterr()
+    b = _run_driver(argv + ["-debugging_feedback", "yes"], fused)
+    out = capfd.readouterr().out
+    assert "Energy budget corrected" in out
+    assert int(a.iter_value) == int(b.iter_value)
+    np.testing.assert_array_equal(a.T_lay, b.T_lay)
+    np.testing.assert_array_equal(a.F_up_band, b.F_up_band)
+    # a healthy run has nothing to report
+    assert "negative flux" not in out and "malfunctioning" not in out
+
+
 def test_run_helios_with_convection(tmp_path):
     """hot interior -> super-adiabatic deep layers -> the convection loop engages and ends stable"""
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",

@@ -196,6 +196,72 @@ def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
         np.testing.assert_array_equal(got[k], z[k], err_msg=k)
 
 
+def test_diagnostics_record(hip, port):
+    """what the reference's kernels report through device printf is counted in the context's hx_diag record:
+    energy-budget factor (kernels.cu:455), negative fluxes and limited G functions under debug = 1 (:1458, :227),
+    skipped Gauss points of the random-overlap re-binning (:3385)"""
+    from helios_amd import phys_const as pc
+    from helios_amd import synthetic as syn
+    raw, ctx = hip.r, hip.r.ctx
+    rng = np.random.default_rng(4)
+    ctx.diag_reset()
+    assert ctx.diag() == dict(negative_down_flux=0, negative_up_flux=0, g_limited=0, ro_rebin_skipped=0,
+                              energy_correction=0.0)
+    # energy correction
+    nbin = 64
+    star, dl = rng.uniform(1e5, 1e6, nbin), rng.uniform(1e-6, 1e-5, nbin)
+    want = 5.6703669999999995e-5 * 5000.0 ** 4 / np.sum(dl * star)        # the kernels' own constant (kernels.cu:40)
+    scaled = star.copy()
+    raw.corr_inc_energy(np.zeros(nbin), scaled, dl, 1, nbin, 5000.0, 0)
+    np.testing.assert_allclose(ctx.diag()["energy_correction"], want, rtol=1e-13)
+    np.testing.assert_allclose(scaled, star * want, rtol=1e-13)
+    # negative fluxes: bins with a negative source function
+    ny, nb, ni = 4, 8, 6
+    n = ny * nb * ni
+    B = np.repeat(np.where(np.arange(nb) % 2 == 0, 1.0, -1.0), ni + 1) * rng.uniform(1.0, 2.0, nb * (ni + 1))
+    Fd, Fu = np.zeros(n), np.zeros(n)
+    args = [Fd, Fu, np.zeros(n), B, np.zeros(n), np.ones(n), np.zeros(n), np.full(n, 0.5), np.zeros(n), np.zeros(n),
+            np.zeros(nb), np.zeros(nb * ni), 0.0, 0, pc.R_SUN, 0.05 * pc.AU, ni, nb, 0.25, -0.5, ny, 0.5, 0, 0, 0]
+    raw.fband_iso(*(args + [0, 0.1]))
+    d = ctx.diag()
+    assert d["negative_down_flux"] == 0 and d["negative_up_flux"] == 0       # debug = 0: not counted
+    raw.fband_iso(*(args + [1, 0.1]))
+    d = ctx.diag()
+    assert d["negative_down_flux"] == int(np.sum(Fd < 0)) > 0
+    assert d["negative_up_flux"] == int(np.sum(Fu < 0)) > 0
+    # limited G functions: w0 = 0.5 and mu_star = -1/sqrt(2) put the denominator of G+- at rounding level
+    ny, nb, nl = 4, 8, 5
+    n = ny * nb * nl
+    ray = rng.uniform(1e-27, 1e-26, nb * nl)
+    kap = np.repeat(ray.reshape(nl, nb), ny, axis=1).reshape(nl, nb * ny).copy()
+    kap[:, ny * (nb // 2):] *= 10.0                                          # second half of the bins: harmless w0
+    outs = [np.zeros(n) for _ in range(7)]
+    dtc, w0 = np.zeros(nb * nl), np.zeros(n)
+    raw.calc_trans_iso(*outs, rng.uniform(1.0, 2.0, nl), kap.reshape(-1), np.ones(nl), ray, np.zeros(nb * nl),
+                       np.zeros(nb * nl), dtc, w0, np.zeros(nb * nl), np.zeros(ny * nb, np.int32), 0.0, 0.5, 0.5,
+                       -1.0 / np.sqrt(2.0), 1.0 - 1e-10, 1e-3, 1, nb, ny, nl, 0, 0, 1, 0.1)
+    Gp, Gm = outs[5], outs[6]
+    nlim = int(np.sum(np.abs(Gp) >= 1e8) + np.sum(np.abs(Gm) >= 1e8))
+    assert nlim > 0 and ctx.diag()["g_limited"] == nlim
+    # random overlap: one quadrature weight holds 90 % of the measure -> several Gauss points per interval
+    ny, nb, nlev = 20, 16, 3
+    gy, _ = syn.gauss_points(ny)
+    gw = np.full(ny, 0.2 / (ny - 1))
+    gw[-1] = 1.8
+    mix0 = np.sort(10.0 ** rng.uniform(-3, 0, (nlev, nb, ny)), axis=2)
+    spec = np.sort(10.0 ** rng.uniform(-3, 0, (nlev, nb, ny)), axis=2) / (1e-3 * 18.0 / 2.3)
+    res = []
+    for impl in (hip, port):
+        mix = mix0.reshape(-1).copy()
+        impl.add_to_mixed_opac(np.full(nlev, 1e-3), spec.reshape(-1).copy(), mix, np.full(nlev, 2.3 * pc.AMU), gw, gy,
+                               18.0 * pc.AMU, 1, 1, ny, nb, nlev)
+        res.append(mix)
+    np.testing.assert_allclose(res[0], res[1], rtol=1e-12)
+    assert ctx.diag()["ro_rebin_skipped"] > 0
+    ctx.diag_reset()
+    assert ctx.diag()["ro_rebin_skipped"] == 0 and ctx.diag()["energy_correction"] == 0.0
+
+
 def test_integration_stub_from_the_docs_runs():
     """the PyCUDA-replacement stub printed in INTEGRATION.md section 1, executed as written (library path aside): a
     reference-style launch `f(args..., block=..., grid=...)` of temp_inter and planck_interpol_interface"""
