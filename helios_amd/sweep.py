@@ -278,6 +278,18 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
     if rank == 0:
         print("\nSweep timing [s]: batch set-up %.2f, iteration loops %.2f, diagnostics + output files %.2f"
               % (timing["batch"], timing["loops"], timing["finish"]))
+    if world > 1:
+        # columns converge after different numbers of iterations: how unevenly the ranks were loaded
+        mine = dict(rank=rank, columns=hi - lo, loops=timing["loops"],
+                    iterations=int(sum(int(q.iter_value or 0) for q, _ in columns)))
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if rank == 0:
+            loops = np.array([e["loops"] for e in every])
+            print("Load over %d ranks: loop time min %.2f / mean %.2f / max %.2f s (imbalance max/mean = %.2f); "
+                  "iterations per rank %s" % (world, loops.min(), loops.mean(), loops.max(),
+                                              loops.max() / max(loops.mean(), 1e-30),
+                                              [e["iterations"] for e in every]))
     X = int(columns[0][0].nbin) if columns else 0
     local = np.array([np.asarray(q.F_up_band)[-X:] for q, _ in columns]).reshape(len(columns), X)
     spectra = gather_spectra(local, dist, coll_device)

@@ -389,6 +389,7 @@ def test_sweep_with_convection_and_two_ranks(tmp_path):
                        ["-output_directory", str(tmp_path) + "/two/"], cwd=root, env=env, capture_output=True, text=True,
                        timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
+    assert "Load over 2 ranks" in p.stdout          # columns need different iteration counts: the imbalance is reported
     z = np.load(os.path.join(str(tmp_path), "two", "cvs_sweep_spectra.npz"))
     np.testing.assert_allclose(z["F_up_TOA"], spectra, rtol=1e-12)
     for k in range(3):
