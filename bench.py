@@ -291,6 +291,8 @@ def main():
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get(args.workload, {}).get("rt_flux_hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic *= ncol                 # measured with one column per launch; a launch covers all columns
             roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
                             frac=achieved / 8000.0, traffic=traffic,
                             algorithmic_bytes_per_launch=tm["step_algorithmic"],

@@ -26,7 +26,7 @@ FUSED_CONFIGS = {
     "clouds_g0": dict(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2),
     "thin_top": dict(thin_top=True, nlayer=12),
     "ny1": dict(ny=1, nbin=17),
-    "L100": dict(nbin=24, nlayer=100),          # k=16, LPL=7: the BASELINE shape
+    "L100": dict(nbin=24, nlayer=100),          # k=16, 13 rows per lane: the BASELINE shape
     "L105": dict(nbin=12, nlayer=105),          # the reference's default layer count
     "L50": dict(nbin=21, nlayer=50, clouds=1),  # k=8, two bins per workgroup
     "L200": dict(nbin=7, nlayer=200, dir_beam=1),  # k=32, two Gauss-point partials per bin

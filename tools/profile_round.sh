@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof -o run -- python3 bench.py --steps 5
 python3 tools/rocpd_summary.py $(find $O/prof -name "*.db" | head -1) > $O/c2_kernel_stats.txt 2>&1
 rm -rf $O/prof
 python3 bench.py --columns-per-gpu 4 --steps 50 --no-cpu-baseline > $O/c2_bench_4columns.json 2>> $O/c2_bench.err
+python3 bench.py --columns-per-gpu 64 --steps 20 --warmup 10 --no-cpu-baseline > $O/c4_bench_64columns.json 2>> $O/c2_bench.err
 python3 bench.py --workload c1 --steps 500 --no-cpu-baseline > $O/c1_bench.json 2>> $O/c2_bench.err
 python3 bench.py --workload c3 --steps 20 --warmup 10 --no-cpu-baseline > $O/c3_bench.json 2>> $O/c2_bench.err
 rocprofv3 --kernel-trace --stats -d $O/prof3 -o run -- python3 bench.py --workload c3 --steps 20 --warmup 10 --no-cpu-baseline --profile-steps 0 > $O/prof3.log 2>&1
