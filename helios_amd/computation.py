@@ -409,7 +409,7 @@ class Compute(object):
 
     def _fused_supported(self, quant):
         return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
-                and quant.flux_calc_method == "iteration")
+                and quant.flux_calc_method == "iteration" and _i(quant.nlayer) <= 512)
 
     @staticmethod
     def _rt_flags(q):

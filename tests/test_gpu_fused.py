@@ -33,6 +33,8 @@ FUSED_CONFIGS = {
     "L33_ny16": dict(nbin=9, nlayer=33, ny=16),
     "L400": dict(nbin=5, nlayer=400, clouds=1, g_0=0.1),   # k=64: one spectral point per wavefront, >64 KiB LDS in k_rt_coef
     "L200_i2s": dict(nbin=6, nlayer=200, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),  # config-5 flags: 4 planes + clouds
+    "L512": dict(nbin=3, nlayer=512, dir_beam=1),   # the fused path's largest column: k=64, 16 rows per lane
+    "smallest": dict(nbin=2, nlayer=4),             # two bins, four layers (the height integration needs a layer below 10 bar)
 }
 
 
@@ -132,3 +134,20 @@ def test_fused_full_size_vs_stage_kernels(ctx):
     from helios_amd import phys_const as pc
     toa = c0.f_factor * (c0.R_star / c0.a) ** 2 * 5.6703669999999995e-5 * c0.T_star ** 4
     np.testing.assert_allclose(f["F_down_tot"][-1], toa, rtol=1e-10)
+
+
+def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kernels(ctx):
+    """the register-resident sweeps hold at most 16 half-layers per lane x 64 lanes: beyond that hx_rt_create reports
+    HX_E_UNSUPPORTED and Compute runs the per-stage kernels instead (still on the GPU -- there is no CPU path)"""
+    from helios_amd._lib import HeliosHipError
+    from helios_amd.computation import Compute
+    c = cases.make_case(nbin=2, nlayer=513)
+    with pytest.raises(HeliosHipError, match="512"):
+        fh.run_fused(ctx, c, 1)
+
+    class Q(object):
+        iso, singlewalk, flux_calc_method, nlayer = 0, 0, "iteration", 513
+    comp = Compute(ctx)
+    assert not comp._fused_supported(Q())
+    Q.nlayer = 512
+    assert comp._fused_supported(Q())
