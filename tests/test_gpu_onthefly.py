@@ -86,6 +86,18 @@ def test_run_helios_with_debugging_feedback(tmp_path, capfd, fused):
     assert "negative flux" not in out and "malfunctioning" not in out
 
 
+def test_run_helios_with_more_layers_than_the_fused_path_holds(tmp_path):
+    """520 layers: hx_rt_* would refuse (limit 512), the driver runs the per-stage kernels and converges"""
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "20 6 5 7",
+            "-number_of_layers", "520", "-maximum_number_of_iterations", "2000", "-name", "big",
+            "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-2",
+            "-convective_adjustment", "no"]
+    q = _run_driver(argv, True)
+    assert q.rt is None and 3 < int(q.iter_value) < 2000
+    from helios_amd import host_functions as hs
+    assert abs(hs.global_energy_imbalance(q)) < 2e-2
+
+
 def test_run_helios_with_convection(tmp_path):
     """hot interior -> super-adiabatic deep layers -> the convection loop engages and ends stable"""
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",
