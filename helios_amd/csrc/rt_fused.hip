@@ -337,7 +337,7 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
         return hx_fail(ctx, HX_E_UNSUPPORTED,
                        "fused path supports nlayer <= 512; use the per-stage API");
     }
-    rt->nchunk = std::max(1, std::min(512, (rt->X + 31) / 32));
+    rt->nchunk = std::max(1, std::min(512, (rt->X + 47) / 48));  // balances k_rt_totals_a (more chunks) against _b (fewer)
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
