@@ -337,7 +337,9 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
         return hx_fail(ctx, HX_E_UNSUPPORTED,
                        "fused path supports nlayer <= 512; use the per-stage API");
     }
-    rt->nchunk = std::max(1, std::min(512, (rt->X + 47) / 48));  // balances k_rt_totals_a (more chunks) against _b (fewer)
+    // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
+    // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
+    rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
