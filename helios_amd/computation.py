@@ -472,6 +472,18 @@ class Compute(object):
             rt.keep_down_fluxes(True)     # so that the negative-flux count covers the downward fluxes too
         return rt
 
+    @staticmethod
+    def _runtime_limit_iteration(quant):
+        """number of completed iterations after which the reference's condition3 ends a time-stepped run: the smallest
+        n with n * physical_tstep >= runtime_limit (computation.py:942 tests (iter + 1) * tstep < limit every iteration)"""
+        ts, lim = float(quant.physical_tstep), float(quant.runtime_limit)
+        n = max(1, int(np.ceil(lim / ts)))
+        while n > 1 and (n - 1) * ts >= lim:
+            n -= 1
+        while n * ts < lim:
+            n += 1
+        return n
+
     def _push_vmr(self, quant):
         """hand the current per-species VMR profiles to the fused state (host step of the refresh)"""
         hsfunc.calculate_vmr_for_all_species(quant)
@@ -502,6 +514,11 @@ class Compute(object):
             for r in quant.crit_relaxation_numbers:
                 if it < r < nxt:
                     nxt = int(r)
+            # the reference looks at the surface temperature inside every iteration whose index is a multiple of 100
+            # (computation.py:946-952), i.e. after 1, 101, 201, ... completed iterations: end a chunk there
+            nxt = min(nxt, it + 1 + (100 - it % 100) % 100)
+            if quant.physical_tstep != 0:                        # computation.py:941-943, tested every iteration
+                nxt = min(nxt, max(it + 1, self._runtime_limit_iteration(quant)))
             nxt = self._stop_for_coupling_output(quant, it, nxt)
             rt.run(it, nxt - it)
             self.report_diagnostics(quant)
@@ -516,7 +533,7 @@ class Compute(object):
                 condition1 = False
             if quant.physical_tstep != 0:
                 condition3 = it * quant.physical_tstep < quant.runtime_limit
-            if (it_prev // 100) != (it // 100) or it_prev % 100 == 0:
+            if (it - 1) % 100 == 0:
                 T_surf = rt.get("T_lay")[L]                      # computation.py:946-952
                 condition2 = T_surf < quant.plancktable_dim * quant.plancktable_step - 2
                 if not condition2:

@@ -1230,6 +1230,15 @@ int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t
         rt->keep_down = v != 0;
         return 0;
     }
+    if (n == "planck_grid") {  // a table built elsewhere (tests: the reference's own), shared by all columns
+        const size_t want = (size_t)(rt->d.plancktable_dim + 1) * rt->X * 8;
+        if (in_bytes != want) return hx_fail(rt->ctx, HX_E_ARG, "wrong size for planck_grid");
+        int rc = h2d(rt, rt->planck_grid, in, in_bytes);
+        for (int c = 0; c < rt->C && !rc; c++)  // its last row is the stellar spectrum the sweeps use
+            rc = hx_d2d(rt->ctx, rt->Bstar + (size_t)c * rt->X,
+                        rt->planck_grid + (size_t)rt->d.plancktable_dim * rt->X, (size_t)rt->X * 8);
+        return rc;
+    }
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     const size_t L = rt->L;

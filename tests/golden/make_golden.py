@@ -1,9 +1,17 @@
-"""Generates the golden vectors under tests/golden/ from the REFERENCE's own kernels
-(oracle/_ref/libhelios_ref.so = /root/reference/source/kernels.cu compiled for the host).
+"""Generates the golden vectors under tests/golden/ from the REFERENCE's own kernels.
 
-Run in the build container only (the reference tree is not present on the GPU box):
-
-    python tests/golden/make_golden.py
+    --backend gfx950  (the pin)  oracle/_ref/libhelios_ref_gfx950.so = /root/reference/source/kernels.cu
+                      compiled UNMODIFIED by hipcc for gfx950 (ROCm's own headers, no shim) and run
+                      on the MI355X as real GPU threads with the block/grid of source/computation.py.
+                      Run on the GPU box (the prebuilt library travels there, the reference tree
+                      does not):
+                          gpurun -- python tests/golden/make_golden.py --backend gfx950 --out gpurun_out/golden
+                      then copy gpurun_out/golden/*.npz to tests/golden/ and commit.
+    --backend host    oracle/_ref/libhelios_ref.so = the same file parsed by g++ through
+                      oracle/ref_shim.h (CPU only; kept as a cross-check of the shim, not a pin)
+    --compare DIR     compare the fixtures in DIR with those in tests/golden/ key by key and print
+                      the largest relative difference per file (how far two builds of the reference
+                      are from each other)
 
 A fixture is data: the seeded inputs of one small problem and the arrays the reference produces from
 them.  Host constants (astropy-unpinned in the reference) are recorded in `meta`.
@@ -48,10 +56,27 @@ STATE_KEYS = ["planckband_lay", "planckband_int", "opac_wg_lay", "opac_wg_int", 
               "F_up_tot", "F_net", "F_net_diff", "abort", "T_store", "deltat_prefactor"]
 
 
+BACKEND = "gfx950"
+OUT = HERE
+SOURCES = {
+    "gfx950": "oracle/_ref/libhelios_ref_gfx950.so: reference source/kernels.cu compiled unmodified by hipcc "
+              "(ROCm 7.2, -x hip --offload-arch=gfx950 -O2 -include hip/hip_runtime.h) and run on an MI355X",
+    "host": "oracle/_ref/libhelios_ref.so (reference source/kernels.cu compiled as host C++ through oracle/ref_shim.h)",
+}
+
+
+def reference():
+    import oracle
+    lib = oracle.refgpu if BACKEND == "gfx950" else oracle.ref
+    if lib is None:
+        raise SystemExit("the %s build of the reference is not available here" % BACKEND)
+    return RefImpl(lib)
+
+
 def meta():
     return json.dumps(dict(
-        generator="tests/golden/make_golden.py",
-        source="oracle/_ref/libhelios_ref.so (reference source/kernels.cu compiled as host C++)",
+        generator="tests/golden/make_golden.py --backend " + BACKEND,
+        source=SOURCES[BACKEND],
         host_constants={k: getattr(pc, k) for k in ("AU", "R_SUN", "R_JUP", "SIGMA_SB", "AMU", "R_UNIV")},
         numpy=np.__version__))
 
@@ -70,7 +95,7 @@ def chain_fixture(name, cfg):
     kw = dict(SIZE)
     kw.update(cfg)
     c0 = cases.make_case(**kw)
-    ref = RefImpl()
+    ref = reference()
     c = c0.copy()
     s = cases.alloc_state(c)
     cases.setup_planck(ref, c, s)
@@ -86,12 +111,12 @@ def chain_fixture(name, cfg):
     cases.radiation_iterations(ref, c, s, 11, start=1)
     for k, v in snapshot(c, s, STATE_KEYS).items():
         data["it12." + k] = v
-    np.savez_compressed(os.path.join(HERE, "chain_%s.npz" % name), **data)
+    np.savez_compressed(os.path.join(OUT, "chain_%s.npz" % name), **data)
 
 
 def mixing_fixture():
     """species interpolation + k-coefficient mixing: every branch of add_to_mixed_opac"""
-    ref = RefImpl()
+    ref = reference()
     rng = np.random.default_rng(20243)
     nbin, nlev, ny, ntemp, npress = 6, 8, 20, 5, 4
     gy, gw = syn.gauss_points(ny)
@@ -148,7 +173,7 @@ def mixing_fixture():
     tot = h2o * 0.3
     ref.add_to_mixed_scat(v2, h2o, tot, nbin, nlev)
     data.update({"sc.temp": t2, "sc.press": p2, "sc.vmr": v2, "sc.h2o": h2o, "sc.total": tot})
-    np.savez_compressed(os.path.join(HERE, "mixing.npz"), **data)
+    np.savez_compressed(os.path.join(OUT, "mixing.npz"), **data)
 
 
 MATRIX_NAMES = ["default", "dirbeam_albedo", "clouds_g0_i2s", "iso_clouds", "thin_top"]
@@ -158,7 +183,7 @@ def matrix_state(name):
     """inputs of the tridiagonal flux solve = the coefficient planes of chain_<name>.npz after iteration 1"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_checks as gc
-    c, z = gc.load_chain(name)
+    c, z = gc.load_chain(name, OUT)
     s = cases.alloc_state(c)
     for k in z.files:
         if k.startswith("it1.") and k[4:] in s and k[4:] not in ("F_down_wg", "F_up_wg", "Fc_down_wg", "Fc_up_wg"):
@@ -170,7 +195,7 @@ def matrix_state(name):
 
 
 def matrix_fixture():
-    ref = RefImpl()
+    ref = reference()
     data = {"meta": meta()}
     for name in MATRIX_NAMES:
         c, s = matrix_state(name)
@@ -179,16 +204,131 @@ def matrix_fixture():
             data["%s.%s" % (name, k)] = s[k].copy()
         for k, v in m.items():
             data["%s.%s" % (name, k)] = v.copy()
-    np.savez_compressed(os.path.join(HERE, "matrix.npz"), **data)
+    np.savez_compressed(os.path.join(OUT, "matrix.npz"), **data)
+
+
+# ---- columns large enough for the fused path's k = 16 / k = 32 tilings (64 bins x 100 / 200 layers) ------------
+BIG_CONFIGS = {
+    "default": dict(nbin=64, nlayer=100),
+    "clouds_beam": dict(nbin=64, nlayer=100, clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2),
+    "L200_beam": dict(nbin=32, nlayer=200, dir_beam=1, albedo=0.1),
+}
+BIG_SIZE = dict(ntemp=5, npress=4, plancktable_dim=300, plancktable_step=10)
+BIG_KEYS = ["F_up_band", "F_down_band", "F_dir_band", "F_up_tot", "F_down_tot", "F_net", "planckband_lay",
+            "planckband_int", "scat_cross_lay", "scat_cross_int", "meanmolmass_lay", "meanmolmass_int",
+            "delta_z_lay", "abort", "T_store", "deltat_prefactor"]
+BIG_WG_KEYS = ["F_up_wg", "F_down_wg", "Fc_up_wg", "Fc_down_wg", "F_dir_wg", "opac_wg_lay", "opac_wg_int"]
+
+
+def big_bins(nbin):
+    return np.array(sorted(set([0, 1, nbin // 3, nbin // 2, nbin - 2, nbin - 1])))
+
+
+def wg_sample(c, a):
+    """every Gauss point and level of a few bins of a [y + ny*x + ny*nbin*i] array"""
+    a = a.reshape(-1, c.nbin, c.ny)
+    return a[:, big_bins(c.nbin), :].copy()
+
+
+def big_fixture(name, cfg):
+    kw = dict(BIG_SIZE)
+    kw.update(cfg)
+    c0 = cases.make_case(**kw)
+    ref = reference()
+    c = c0.copy()
+    s = cases.alloc_state(c)
+    cases.setup_planck(ref, c, s)
+    data = {"meta": meta(), "config": json.dumps(kw), "planck_grid": s.planck_grid.copy(),
+            "sample_bins": big_bins(c.nbin)}
+    for k, v in c0.items():
+        data["in." + k] = np.asarray(v)
+
+    def snap(prefix):
+        for k in BIG_KEYS:
+            data[prefix + k] = s[k].copy()
+        for k in BIG_WG_KEYS:
+            data[prefix + k + ".sample"] = wg_sample(c, s[k])
+        data[prefix + "T_lay"], data[prefix + "T_int"], data[prefix + "z_lay"] = c.T_lay.copy(), c.T_int.copy(), c.z_lay.copy()
+
+    cases.radiation_iterations(ref, c, s, 1)
+    snap("it1.")
+    cases.radiation_iterations(ref, c, s, 11, start=1)
+    snap("it12.")
+    np.savez_compressed(os.path.join(OUT, "big_%s.npz" % name), **data)
+
+
+# ---- whole loops: SURVEY 8(c) "after N = 1, 10, 11, 50 iterations and at convergence" -------------------------------
+def loop_fixture(name):
+    import loop_driver as ld
+    c0, relax = ld.loop_case(name)
+    ref = reference()
+    c = c0.copy()
+    s = cases.alloc_state(c)
+    cases.setup_planck(ref, c, s)
+    data = {"meta": meta(), "planck_grid": s.planck_grid.copy(), "crit_relaxation_numbers": np.array(relax, np.int64)}
+    for k, v in c0.items():
+        data["in." + k] = np.asarray(v)
+    n, snaps, reason = ld.radiation_loop(ref, c, s, ld.SNAP_AT, crit_relaxation_numbers=relax)
+    data["iter_count"] = np.array(n)
+    data["reason"] = np.array(reason)
+    for at, sn in snaps.items():
+        for k, v in sn.items():
+            data["%s.%s" % (("it%d" % at) if at != "end" else "end", k)] = v
+    np.savez_compressed(os.path.join(OUT, "loop_%s.npz" % name), **data)
+    print("loop_%s: %d iterations (%s)" % (name, n, reason))
+
+
+def compare(other):
+    """largest relative difference per file between the fixtures in `other` and those next to this script"""
+    worst_all = 0.0
+    for f in sorted(os.listdir(other)):
+        if not f.endswith(".npz") or not os.path.exists(os.path.join(HERE, f)) or f == "host_functions.npz":
+            continue
+        a, b = np.load(os.path.join(other, f)), np.load(os.path.join(HERE, f))
+        worst, where = 0.0, ""
+        for k in a.files:
+            if k not in b.files or a[k].dtype.kind not in "fi" or k.startswith("in.") or a[k].shape != b[k].shape:
+                continue
+            x, y = a[k].astype(float), b[k].astype(float)
+            scale = np.abs(y).max()
+            if scale == 0:
+                continue
+            with np.errstate(invalid="ignore"):
+                d = np.nanmax(np.abs(x - y)) / scale       # relative to the array's largest entry
+            if d > worst:
+                worst, where = d, k
+        worst_all = max(worst_all, worst)
+        print("%-28s max |a-b| / max|b| = %.3e  (%s)" % (f, worst, where))
+    print("largest over all files: %.3e" % worst_all)
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["matrix"]:
-        matrix_fixture()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=["gfx950", "host"], default="gfx950")
+    ap.add_argument("--out", default=HERE)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--compare", default="")
+    a = ap.parse_args()
+    if a.compare:
+        compare(a.compare)
         sys.exit(0)
-    for name, cfg in CHAIN_CONFIGS.items():
-        chain_fixture(name, cfg)
-    mixing_fixture()
-    matrix_fixture()
-    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
-    print("wrote fixtures, %.1f KB total" % (tot / 1024.0))
+    BACKEND, OUT = a.backend, os.path.abspath(a.out)
+    os.makedirs(OUT, exist_ok=True)
+    only = set(a.only.split(",")) if a.only else None
+    if not only or "chain" in only:
+        for name, cfg in CHAIN_CONFIGS.items():
+            chain_fixture(name, cfg)
+    if not only or "mixing" in only:
+        mixing_fixture()
+    if not only or "matrix" in only:
+        matrix_fixture()
+    if not only or "big" in only:
+        for name, cfg in BIG_CONFIGS.items():
+            big_fixture(name, cfg)
+    if not only or "loop" in only:
+        import loop_driver as ld
+        for name in ld.LOOP_NAMES:
+            loop_fixture(name)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print("wrote fixtures to %s, %.1f KB total" % (OUT, tot / 1024.0))

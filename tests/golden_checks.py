@@ -17,8 +17,8 @@ def _close(a, b, rtol, atol=1e-300, name=""):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=name)
 
 
-def load_chain(name):
-    z = np.load(os.path.join(GOLDEN, "chain_%s.npz" % name))
+def load_chain(name, directory=None, prefix="chain_"):
+    z = np.load(os.path.join(directory or GOLDEN, "%s%s.npz" % (prefix, name)))
     c = cases.Case()
     for k in z.files:
         if k.startswith("in."):
@@ -31,7 +31,7 @@ def load_chain(name):
     return c, z
 
 
-def check_chain(impl, name, rtol1=1e-11, rtol12=1e-8, check_planck_table=True, planck_rtol=1e-11):
+def check_chain(impl, name, rtol1=1e-11, rtol12=1e-8, check_planck_table=True, planck_rtol=1e-9):
     """`rtol1`: tolerance after one iteration (every stage run once on identical inputs);
     `rtol12`: after 12 iterations, where last-bit differences have been fed back 12 times."""
     c, z = load_chain(name)
@@ -39,13 +39,36 @@ def check_chain(impl, name, rtol1=1e-11, rtol12=1e-8, check_planck_table=True, p
     if check_planck_table:
         cases.setup_planck(impl, c, s)
         # Phi_n(y_top) - Phi_n(y_bot) cancels in the Rayleigh-Jeans tail (kernels.cu:103-104): 1-ulp
-        # differences between libm exp() implementations are amplified to ~1e-10 there
+        # differences between libm exp() implementations are amplified to ~1e-10 there (1.2e-10 between
+        # the host libm and the reference's gfx950 build)
         _close(s.planck_grid, z["planck_grid"], rtol=planck_rtol, atol=1e-290, name="planck_grid")
     s.planck_grid[:] = z["planck_grid"]
     cases.radiation_iterations(impl, c, s, 1)
     _compare(c, s, z, "it1.", rtol1)
     cases.radiation_iterations(impl, c, s, 11, start=1)
     _compare(c, s, z, "it12.", rtol12)
+
+
+# Tolerances against the reference's own GPU build (tests/golden/*.npz, `meta.source`).  Two builds of
+# the SAME reference source -- g++ on the host without FMA contraction and hipcc for gfx950 with it,
+# each with its own libm -- differ from each other by the amounts below (measured with
+# `make_golden.py --compare`, recorded in DESIGN.md section 2); the restatement and the HIP library
+# round like the host build (-ffp-contract=off), so these are the floors of any comparison with the
+# GPU-run reference.  Every array gets an element-wise `rtol` plus an absolute floor `ATOL * max|want|`:
+#   * 1e-13 * max: differences of O(1) terms (N = zeta+ zeta- (1 - T^2), P - M + N, F_net[i] - F_net[i+1],
+#     the G-weighted beam terms) leave ~1e-15 * max of absolute noise on entries that are orders of
+#     magnitude smaller than the array's largest;
+#   * G+-: the denominator (kernels.cu:168) passes close to zero, 6e-11 * max observed -> 1e-9;
+#   * temperatures follow F_net_diff, 100 x the flux tolerance.
+ATOL_DEFAULT = 1e-13
+ATOL = {"G_plus": 1e-9, "G_minus": 1e-9}
+
+
+def _atol_scale(name):
+    for k, v in ATOL.items():
+        if name.startswith(k):
+            return v
+    return ATOL_DEFAULT
 
 
 def _compare(c, s, z, prefix, rtol):
@@ -60,23 +83,18 @@ def _compare(c, s, z, prefix, rtol):
         if want.dtype.kind == "i":
             assert np.array_equal(got, want), name
             continue
-        atol = 1e-300
         rt = rtol
         if name == "Fc_dir_wg":          # the TOA slab is never written by the reference
             got, want = got[:wgn], want[:wgn]
-        if name.startswith(("F_", "Fc_")):
-            # G-weighted direct-beam terms cancel down to the diffuse flux inside the reference's
-            # own formula: last-bit input noise re-appears as ~1e-15*max(F) absolute (see
-            # tests/test_oracle_vs_ref.py)
+        atol = 1e-300 + _atol_scale(name) * np.abs(want).max()
+        if name.startswith(("F_", "Fc_")) and name.endswith("_wg"):
             atol = 1e-90 + 1e-13 * fscale
         if name in ("F_net", "F_net_diff"):
             atol = 1e-12 * np.abs(z[prefix + "F_up_tot"]).max()
-        if name.startswith(("G_plus", "G_minus")):
-            atol = 1e-15   # both are differences of O(1) terms
-        if name.startswith("planckband"):
-            atol = 1e-13 * np.abs(want).max()   # Wien tail: d ln B / d ln T = hc/(lambda k T) >> 1
         if name in ("T_lay", "T_int", "T_store"):
-            rt = max(rtol * 100, 1e-10)
+            rt = max(rtol * 100, 1e-9)
+        if name.startswith("planckband"):
+            rt = rtol * 100   # Wien tail: d ln B / d ln T = hc / (lambda k T) >> 1 amplifies the temperature differences
         _close(got, want, rtol=rt, atol=atol, name=prefix + name)
 
 
@@ -110,6 +128,73 @@ def check_mixing(impl, rtol=1e-11):
 
 
 MATRIX_NAMES = ["default", "dirbeam_albedo", "clouds_g0_i2s", "iso_clouds", "thin_top"]
+BIG_NAMES = sorted(os.path.basename(f)[4:-4] for f in glob.glob(os.path.join(GOLDEN, "big_*.npz")))
+
+
+def check_loop(run, name, rtol_flux=1e-6, rtol_T=1e-6):
+    """`run(c, s, crit_relaxation_numbers) -> (iter_count, snaps)` against tests/golden/loop_<name>.npz.
+    The iteration count must be the reference's; fluxes and the T-P profile within the north-star tolerance
+    (1e-6 relative) at every recorded iteration and at the end."""
+    c, z = load_chain(name, prefix="loop_")
+    s = cases.alloc_state(c)
+    s.planck_grid[:] = z["planck_grid"]
+    n, snaps = run(c, s, tuple(int(r) for r in z["crit_relaxation_numbers"]))
+    assert n == int(z["iter_count"]), "iterations: %d, reference %d" % (n, int(z["iter_count"]))
+    for at in [k for k in snaps]:
+        tag = "end" if at == "end" else "it%d" % at
+        fscale = np.abs(z[tag + ".F_up_tot"]).max()
+        for k, got in snaps[at].items():
+            want = z["%s.%s" % (tag, k)]
+            if k == "abort":
+                assert np.array_equal(got, want), tag + ".abort"
+            elif k == "T_lay":
+                _close(got, want, rtol=rtol_T, name=tag + ".T_lay")
+            elif k == "deltat_prefactor":
+                _close(got, want, rtol=1e-9, name=tag + "." + k)     # a product of 1.1s and 1/1.5s: decisions, not noise
+            elif k == "F_net":
+                _close(got, want, rtol=rtol_flux, atol=1e-9 * fscale, name=tag + ".F_net")   # a difference of the totals
+            else:
+                _close(got, want, rtol=rtol_flux, atol=1e-13 * max(np.abs(want).max(), 1e-300), name=tag + "." + k)
+
+
+def check_big(run, name, rtol1=1e-10, rtol12=1e-8):
+    """`run(c, planck_grid, n_iter, state) -> (dict of arrays, state)` against tests/golden/big_<name>.npz: band
+    fluxes, totals, temperatures and -- for the sampled bins -- every Gauss point of the spectral fluxes"""
+    c, z = load_chain(name, prefix="big_")
+    bins = z["sample_bins"]
+    state = None
+    for n_iter, prefix, rtol in ((1, "it1.", rtol1), (12, "it12.", rtol12)):
+        out, state = run(c, z["planck_grid"], n_iter, state)
+        fscale = max(np.abs(z[prefix + k + ".sample"]).max() for k in ("F_down_wg", "F_up_wg", "F_dir_wg"))
+        for k in z.files:
+            if not k.startswith(prefix):
+                continue
+            nm = k[len(prefix):]
+            want = z[k]
+            if nm.endswith(".sample"):
+                nm = nm[:-7]
+                if nm not in out:
+                    continue
+                a = np.asarray(out[nm])
+                nlev = want.shape[0]
+                got = a[:nlev * c.nbin * c.ny].reshape(nlev, c.nbin, c.ny)[:, bins, :]
+                if nm.startswith("Fc_"):
+                    got, want = got[:c.nlayer], want[:c.nlayer]
+                atol = 1e-13 * (fscale if nm.startswith(("F_", "Fc_")) else np.abs(want).max())
+                _close(got, want, rtol=rtol, atol=atol, name=prefix + nm)
+                continue
+            if nm not in out:
+                continue
+            got = np.asarray(out[nm])
+            if want.dtype.kind == "i":
+                assert np.array_equal(got, want), nm
+                continue
+            rt, atol = rtol, 1e-13 * np.abs(want).max()
+            if nm in ("F_net",):
+                atol = 1e-12 * np.abs(z[prefix + "F_up_tot"]).max()
+            if nm in ("T_lay", "T_int", "T_store") or nm.startswith("planckband"):
+                rt = max(rtol * 100, 1e-9)
+            _close(got, want, rtol=rt, atol=atol, name=prefix + nm)
 
 
 def check_matrix(impl, name, rtol=1e-11):
@@ -124,8 +209,13 @@ def check_matrix(impl, name, rtol=1e-11):
     if name == "default":
         s.scat_trigger[::2] = 0
     m = cases.flux_matrix(impl, c, s)
+    # the source terms are differences of O(1) products (kernels.cu:2139-2198): 1e-15 * max of absolute noise
+    # between two builds of the reference, i.e. up to 5e-7 relative on their smallest entries; the
+    # back-substitution then carries ~1e-8 * max into the downward fluxes ("numerically fragile",
+    # docs/sections/parameters.rst:326)
     for k in ("alpha", "beta", "source_term_down", "source_term_up", "c_prime", "d_prime"):
-        _close(m[k], z["%s.%s" % (name, k)], rtol=rtol, name=k)
+        want = z["%s.%s" % (name, k)]
+        _close(m[k], want, rtol=rtol, atol=1e-13 * np.abs(want).max(), name=k)
     for k in ("F_down_wg", "F_up_wg") + (("Fc_down_wg", "Fc_up_wg") if c.iso == 0 else ()):
         want = z["%s.%s" % (name, k)]
-        _close(s[k], want, rtol=rtol, atol=1e-14 * np.abs(want).max(), name=k)
+        _close(s[k], want, rtol=rtol, atol=1e-7 * np.abs(want).max(), name=k)

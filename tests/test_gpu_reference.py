@@ -1,0 +1,239 @@
+"""The HIP library against THE REFERENCE ITSELF on the same GPU: oracle/_ref/libhelios_ref_gfx950.so is
+the reference's source/kernels.cu compiled unmodified by hipcc for gfx950 (no shim) and launched with the
+block/grid of source/computation.py.  Here it runs side by side with libhelios_hip.so on seeded inputs
+that are NOT among the committed fixtures, and the fused path / the product's loop driver are held to the
+vectors that build produced (tests/golden/big_*.npz, loop_*.npz).
+
+Tolerances: the reference's GPU build contracts a*b+c into FMAs (hipcc's default, as nvcc's), the HIP
+library rounds every operation (-ffp-contract=off); tests/golden_checks.py lists what that does to
+cancelling terms.  Fluxes, spectra and temperatures are far inside the north-star's 1e-6."""
+import numpy as np
+import pytest
+
+import cases
+import fused_helpers as fh
+import golden_checks as gc
+import loop_driver as ld
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from helios_amd.device import Context
+    return Context(0)
+
+
+@pytest.fixture(scope="module")
+def refgpu():
+    import oracle
+    from impls import RefImpl
+    lib = oracle.refgpu
+    if lib is None:
+        pytest.skip("oracle/_ref/libhelios_ref_gfx950.so not present (it is built where /root/reference exists)")
+    return RefImpl(lib)
+
+
+@pytest.fixture(scope="module")
+def hip(ctx):
+    from impls import hip_impl
+    return hip_impl(ctx)
+
+
+LIVE_CONFIGS = {
+    "scat": dict(nbin=37, nlayer=23),
+    "clouds_beam_i2s": dict(nbin=70, nlayer=50, clouds=1, g_0=0.2, scat_corr=1, dir_beam=1, albedo=0.15),
+    "zenith": dict(nbin=19, nlayer=31, dir_beam=1, geom_zenith_corr=1, zenith_deg=75.0),
+    "iso": dict(nbin=23, nlayer=17, iso=1, clouds=1),
+    "L100": dict(nbin=48, nlayer=100),
+}
+
+
+def _chain(impl, c0, n_iter):
+    c = c0.copy()
+    s = cases.alloc_state(c)
+    cases.setup_planck(impl, c, s)
+    grid = s.planck_grid.copy()
+    cases.radiation_iterations(impl, c, s, n_iter)
+    return c, s, grid
+
+
+@pytest.mark.parametrize("name", sorted(LIVE_CONFIGS))
+def test_stage_kernels_vs_reference_on_the_gpu(hip, refgpu, name):
+    """every per-stage entry point (hx_<kernel>) against the reference kernel of the same name, both on this GPU,
+    chained through one refresh + 3 iterations"""
+    c0 = cases.make_case(**LIVE_CONFIGS[name])
+    cr, sr, grid_r = _chain(refgpu, c0, 3)
+    ch, sh, grid_h = _chain(hip, c0, 3)
+    np.testing.assert_allclose(grid_h, grid_r, rtol=1e-9, atol=1e-290, err_msg="planck_grid")
+    # same table for the comparison of everything downstream (the Rayleigh-Jeans tail noise is the table's own)
+    c = c0.copy()
+    s = cases.alloc_state(c)
+    s.planck_grid[:] = grid_r
+    cases.radiation_iterations(hip, c, s, 3)
+    c2 = c0.copy()
+    s2 = cases.alloc_state(c2)
+    s2.planck_grid[:] = grid_r
+    cases.radiation_iterations(refgpu, c2, s2, 3)
+    fscale = max(np.abs(s2[k]).max() for k in ("F_down_wg", "F_up_wg", "F_dir_wg"))
+    wgn = c.ny * c.nbin * c.nlayer
+    for k in sorted(s2):
+        want, got = s2[k], s[k]
+        if k in ("planck_grid", "trans_band", "delta_tau_band", "trans_weight_band", "contr_func_band", "opac_band_lay",
+                 "F_dir_tot"):
+            continue
+        if want.dtype.kind == "i":
+            assert np.array_equal(got, want), k
+            continue
+        if k == "Fc_dir_wg":
+            got, want = got[:wgn], want[:wgn]
+        atol = 1e-300 + gc._atol_scale(k) * np.abs(want).max()
+        if k.startswith(("F_", "Fc_")) and k.endswith("_wg"):
+            atol = 1e-90 + 1e-13 * fscale
+        if k in ("F_net", "F_net_diff"):
+            atol = 1e-12 * np.abs(s2["F_up_tot"]).max()
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=atol, err_msg=k)
+    np.testing.assert_allclose(c.T_lay, c2.T_lay, rtol=1e-9)
+    np.testing.assert_allclose(c.z_lay, c2.z_lay, rtol=1e-10)
+
+
+def test_random_overlap_vs_reference_on_the_gpu(hip, refgpu):
+    """add_to_mixed_opac: the reference's adjacent-swap sort run by real GPU threads (9.6 KB of scratch each) against
+    the HIP kernel, on generic, dominated, tie-heavy, constant and unsorted inputs"""
+    from test_gpu_stages import _ro_run
+    got = _ro_run(hip)
+    want = _ro_run(refgpu)
+    for k in want:
+        assert np.all(np.isfinite(got[k])), k
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-12, err_msg=k)
+
+
+def test_species_loop_vs_reference_on_the_gpu(hip, refgpu):
+    """one on-the-fly refresh (4 absorbers + H2O + H2 scattering) and the iteration that follows"""
+    c0 = cases.add_species(cases.make_case(nbin=21, nlayer=12), nspecies=4)
+    res = []
+    for impl in (hip, refgpu):
+        c = c0.copy()
+        s = cases.alloc_state(c)
+        cases.setup_planck(refgpu, c, s)
+        cases.radiation_iterations(impl, c, s, 1, refresh=cases.refresh_onthefly)
+        res.append((c, s))
+    (c, s), (c2, s2) = res
+    for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int", "F_up_band", "F_down_band", "F_net"):
+        np.testing.assert_allclose(s[k], s2[k], rtol=1e-10, atol=1e-13 * np.abs(s2[k]).max(), err_msg=k)
+    np.testing.assert_allclose(c.T_lay, c2.T_lay, rtol=1e-9)
+
+
+def _fused_run(ctx, c, planck_grid, n_iter, state):
+    """tests/golden_checks.check_big runner for the fused path (restarted from iteration 0 each time)"""
+    from helios_amd.rt import batch_from_case
+    rt = batch_from_case(ctx, c)
+    try:
+        rt.keep_down_fluxes(True)
+        rt.build_planck_table(1 if c.T_star > 10 else 0)
+        rt.set_state(-1, "planck_grid", planck_grid)      # downstream of the same table as the reference run
+        rt.run(0, n_iter)
+        keys = ["T_lay", "T_int", "F_up_band", "F_down_band", "F_dir_band", "F_up_tot", "F_down_tot", "F_net",
+                "planckband_lay", "planckband_int", "scat_cross_lay", "scat_cross_int", "meanmolmass_lay",
+                "meanmolmass_int", "delta_z_lay", "z_lay", "F_up_wg", "Fc_up_wg", "F_down_wg", "Fc_down_wg", "abort",
+                "opac_wg_lay", "opac_wg_int"]
+        out = {k: rt.get(k) for k in keys}
+        out["deltat_prefactor"] = rt.get("delta_t_prefactor")
+        out["T_store"] = rt.get("T_store")
+        return out, None
+    finally:
+        rt.close()
+
+
+@pytest.mark.parametrize("name", gc.BIG_NAMES)
+def test_fused_big_golden(ctx, name):
+    """64 bins x 100 layers (k = 16 tiles, 13 rows per lane: the BASELINE shape), with clouds + beam + I2S (4+2
+    coefficient planes) and 32 x 200 (k = 32): the fused path against vectors the reference produced on the GPU"""
+    gc.check_big(lambda c, grid, n, st: _fused_run(ctx, c, grid, n, st), name, rtol1=1e-9, rtol12=1e-7)
+
+
+@pytest.mark.parametrize("name", ld.LOOP_NAMES)
+def test_fused_loop_golden(ctx, name):
+    """hx_rt_run to convergence (device-side `done` latch) against the reference-kernel loop: same iteration count,
+    T_lay / F_net / emission spectrum within 1e-6 after 1, 10, 11, 50 iterations and at the end"""
+    from helios_amd.rt import batch_from_case
+
+    def run(c, s, relax):
+        rt = batch_from_case(ctx, c)
+        try:
+            rt.build_planck_table(1 if c.T_star > 10 else 0)
+            snaps = {}
+            it = 0
+            stops = sorted(set(ld.SNAP_AT) | set(relax))
+            limit = c.rad_convergence_limit
+            while True:
+                nxt = min([p for p in stops if p > it] + [it + 10 - it % 10])
+                rt.run(it, nxt - it)
+                done = int(rt.get("done")[0])
+                it = int(rt.get("iters_done")[0]) if done else nxt
+                if it in ld.SNAP_AT or done:
+                    X, I = c.nbin, c.ninterface
+                    sn = dict(F_net=rt.get("F_net"), F_up_tot=rt.get("F_up_tot"), F_down_tot=rt.get("F_down_tot"),
+                              T_lay=rt.get("T_lay"), F_up_band_TOA=rt.get("F_up_band")[X * (I - 1):],
+                              F_down_band_BOA=rt.get("F_down_band")[:X], F_dir_band_BOA=rt.get("F_dir_band")[:X],
+                              abort=rt.get("abort"), deltat_prefactor=rt.get("delta_t_prefactor"))
+                    if it in ld.SNAP_AT:
+                        snaps[it] = sn
+                    if done:
+                        snaps["end"] = sn
+                        return it, snaps
+                if it in relax:
+                    limit *= 10.0
+                    rt.set_convergence_limit(0, limit)
+                assert it < 20000
+        finally:
+            rt.close()
+    gc.check_loop(run, name)
+
+
+@pytest.mark.parametrize("name", ld.LOOP_NAMES)
+def test_compute_radiation_loop_golden(ctx, name, capsys):
+    """the product's driver, Compute.radiation_loop on a Store, against the reference-kernel loop: iteration
+    count, T-P profile, net flux and TOA emission spectrum"""
+    from helios_amd.computation import Compute
+    from store_helpers import store_from_case
+    c, z = gc.load_chain(name, prefix="loop_")
+    relax = tuple(int(r) for r in z["crit_relaxation_numbers"])
+    q = store_from_case(ctx, c, relax)
+    comp = Compute(ctx)
+    comp.radiation_loop(q)
+    assert int(q.iter_value) == int(z["iter_count"])
+    X, I = c.nbin, c.ninterface
+    np.testing.assert_allclose(q.dev_T_lay.get(), z["end.T_lay"], rtol=1e-6)
+    fs = np.abs(z["end.F_up_tot"]).max()
+    np.testing.assert_allclose(q.dev_F_net.get(), z["end.F_net"], rtol=1e-6, atol=1e-9 * fs)
+    np.testing.assert_allclose(q.dev_F_up_band.get()[X * (I - 1):], z["end.F_up_band_TOA"], rtol=1e-6,
+                               atol=1e-13 * z["end.F_up_band_TOA"].max())
+    np.testing.assert_allclose(q.dev_F_down_band.get()[:X], z["end.F_down_band_BOA"], rtol=1e-6,
+                               atol=1e-13 * max(z["end.F_down_band_BOA"].max(), 1e-300))
+
+
+def test_conv_temp_iter_vs_reference_on_the_gpu(hip, refgpu, port):
+    """conv_temp_iter (kernels.cu:2768-2884): hx_conv_temp_iter against the reference kernel on this GPU and against
+    the CPU restatement, below and above the hard-coded iteration 6000 (:2844-2846), with and without marked layers"""
+    rng = np.random.default_rng(5)
+    L = 37
+    for itervalue in (0, 19, 20, 5999, 6000, 6019, 12345):
+        for variant in range(3):
+            base = dict(F_net=rng.uniform(-1e5, 1e5, L + 1), F_net_diff=np.zeros(L),
+                        T_lay=rng.uniform(300, 2500, L + 1), p_lay=np.sort(10 ** rng.uniform(0, 9, L))[::-1].copy(),
+                        p_int=np.sort(10 ** rng.uniform(0, 9.2, L + 1))[::-1].copy(),
+                        T_store=rng.uniform(300, 2500, L + 1), pref=10 ** rng.uniform(-3, 1, L + 1),
+                        marked=(rng.uniform(size=L + 1) < (0.0, 0.3, 1.0)[variant]).astype(np.int32),
+                        F_add=rng.uniform(0, 10, L) * (variant == 1), F_smooth=np.zeros(L), F_smooth_sum=np.zeros(L))
+            outs = []
+            for impl in (refgpu, hip, port):
+                d = {k: v.copy() for k, v in base.items()}
+                impl.conv_temp_iter(d["F_net"], d["F_net_diff"], d["T_lay"], d["p_lay"], d["p_int"], d["T_store"],
+                                    d["pref"], d["marked"], d["F_add"], d["F_smooth"], d["F_smooth_sum"], L, itervalue,
+                                    20, 0, 5.67e-5 * 150.0 ** 4)
+                outs.append(d)
+            for other in outs[1:]:
+                for k in ("T_lay", "T_store", "pref", "F_net_diff"):
+                    np.testing.assert_allclose(other[k], outs[0][k], rtol=1e-12, atol=1e-300,
+                                               err_msg="%s it=%d variant=%d" % (k, itervalue, variant))
