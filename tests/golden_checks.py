@@ -58,10 +58,12 @@ def check_chain(impl, name, rtol1=1e-11, rtol12=1e-8, check_planck_table=True, p
 #   * 1e-13 * max: differences of O(1) terms (N = zeta+ zeta- (1 - T^2), P - M + N, F_net[i] - F_net[i+1],
 #     the G-weighted beam terms) leave ~1e-15 * max of absolute noise on entries that are orders of
 #     magnitude smaller than the array's largest;
-#   * G+-: the denominator (kernels.cu:168) passes close to zero, 6e-11 * max observed -> 1e-9;
+#   * G+-: the denominator E/eps^2 (E - w0)(1 - w0 g0) - 1/mu*^2 (kernels.cu:168) is ~ -4 w0 (1 + g0) with the default
+#     eps = 0.5, mu* = -0.5: a difference of two numbers near 4, relative error ~1e-16 / w0 on a G of O(1) --
+#     3e-9 observed between the HIP kernels and the reference on the same GPU -> 1e-8 * max(1, max|G|);
 #   * temperatures follow F_net_diff, 100 x the flux tolerance.
 ATOL_DEFAULT = 1e-13
-ATOL = {"G_plus": 1e-9, "G_minus": 1e-9}
+ATOL = {"G_plus": 1e-8, "G_minus": 1e-8}
 
 
 def _atol_scale(name):
@@ -69,6 +71,14 @@ def _atol_scale(name):
         if name.startswith(k):
             return v
     return ATOL_DEFAULT
+
+
+def atol_for(name, want):
+    """absolute floor of the comparison of array `name` with the reference's `want`"""
+    m = np.abs(want).max() if want.size else 0.0
+    if name.startswith(("G_plus", "G_minus")):
+        m = max(m, 1.0)
+    return 1e-300 + _atol_scale(name) * m
 
 
 def _compare(c, s, z, prefix, rtol):
@@ -86,7 +96,7 @@ def _compare(c, s, z, prefix, rtol):
         rt = rtol
         if name == "Fc_dir_wg":          # the TOA slab is never written by the reference
             got, want = got[:wgn], want[:wgn]
-        atol = 1e-300 + _atol_scale(name) * np.abs(want).max()
+        atol = atol_for(name, want)
         if name.startswith(("F_", "Fc_")) and name.endswith("_wg"):
             atol = 1e-90 + 1e-13 * fscale
         if name in ("F_net", "F_net_diff"):
@@ -176,10 +186,11 @@ def check_big(run, name, rtol1=1e-10, rtol12=1e-8):
                 if nm not in out:
                     continue
                 a = np.asarray(out[nm])
-                nlev = want.shape[0]
+                nlev = min(want.shape[0], a.size // (c.nbin * c.ny))      # layer arrays: nlayer or ninterface slabs (Q2)
+                if nm.startswith("Fc_") or nm == "opac_wg_lay":
+                    nlev = c.nlayer
                 got = a[:nlev * c.nbin * c.ny].reshape(nlev, c.nbin, c.ny)[:, bins, :]
-                if nm.startswith("Fc_"):
-                    got, want = got[:c.nlayer], want[:c.nlayer]
+                want = want[:nlev]
                 atol = 1e-13 * (fscale if nm.startswith(("F_", "Fc_")) else np.abs(want).max())
                 _close(got, want, rtol=rtol, atol=atol, name=prefix + nm)
                 continue
