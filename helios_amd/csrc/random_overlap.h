@@ -1,0 +1,378 @@
+// Random-overlap mixing of one more absorber into the running k-distribution of a (bin, level) point --
+// add_to_mixed_opac, kernels.cu:3263-3399 -- as a device function for ONE wavefront, shared by the
+// per-stage entry point (stage_mixing.hip) and the species loop of the fused refresh (rt_fused.hip).
+//
+// The reference forms the 400 pair sums K = mix[y1] + add[y2] with weights (w[y1]/2)(w[y2]/2) in a crossing-dependent
+// fill order, sorts them with repeated adjacent swaps (a stable sort), accumulates mid-point abscissae and reads the
+// 20 new Gauss points off by linear interpolation.  Here:
+//
+//  * 512 slots = 64 lanes x 8; slot r of lane l starts with fill position e = 64 r + l, so the per-position LDS images of
+//    the sums and weights are written with unit stride (no bank conflicts).
+//  * If the sums are already ascending in fill order -- the reference fills the stronger curve on the outer loop for
+//    that reason, and a quarter of the problems of a 20-species mix are -- nothing is sorted at all.
+//  * Otherwise a bitonic network sorts ONE 32-bit key per slot,
+//        key = q(K) << 9 | e,     q(K) = (bits(K) - (hi32(Kmin) << 32)) >> sh     (23 bits, monotone in K)
+//    with `sh` chosen per problem so that the 23 bits span exactly [Kmin, Kmax] (18 mantissa bits for sums that cover
+//    eight decades).  A compare-exchange is v_min_u32 / v_max_u32 inside a lane and one DPP move + v_med3_u32 per slot
+//    across lanes (med3(own, partner, 0) = min for the lower lane, med3(own, partner, ~0) = max for the upper one):
+//    about 530 vector instructions for the 45 steps, against 1.4 k for a network that moves fp64 sums with a payload.
+//    Keys with equal q are ordered by fill position, which is the reference's stable order for equal sums.
+//  * What the quantisation can get wrong -- two sums of different rows closer than 2^-18 relative, in the wrong fill
+//    order -- is repaired on the exact fp64 values: the sorted keys fetch (K, weight) from LDS, a wave-uniform test looks
+//    for an inversion, and only then odd-even transposition passes (strict '>', hence stable) run until none is left.
+//    The permutation is therefore exactly the reference's; the fp64 network and the all-pairs ranking kept in
+//    stage_mixing.hip give bit-identical results (tests/test_gpu_stages.py::test_random_overlap_orderings_vs_oracle).
+//  * Sorted sums and abscissae go back to LDS at index w + w/8 (stride 9 doubles between lanes: conflict-free), the 20
+//    Gauss points find their interval by binary search.
+#pragma once
+#include "hx_common.h"
+
+namespace ro {
+
+constexpr int NY = 20;
+constexpr int N = NY * NY;   // 400 pair sums
+constexpr int SLOTS = 8;     // per lane: 512 slots
+constexpr int LDS_N = 512;   // by fill position (<= 511) or by padded rank (399 + 49)
+
+struct Shared {
+    double outer[NY], inner[NY], hw[NY], gy[NY];  // outer: the curve that is stronger at y = 0 (outer fill loop)
+    double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded rank: sorted sum / abscissa
+};
+
+struct Lane {
+    unsigned c[6];         // c[t] = 0 where lane bit t is clear (lower partner of an exchange over that bit), else ~0
+    unsigned pk20[SLOTS];  // fill position e = 64 r + lane as LDS byte offsets 8 (e / 20) | 8 (e % 20) << 16
+};
+
+struct Counters {
+    unsigned skipped = 0, passes = 0;
+};
+
+__device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const double* gauss_weight, const double* gauss_y) {
+    if (lane < NY) {
+        sh.hw[lane] = 0.5 * gauss_weight[lane];
+        sh.gy[lane] = gauss_y[lane];
+    }
+#pragma unroll
+    for (int t = 0; t < 6; t++) ln.c[t] = (lane >> t) & 1 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const unsigned e = 64 * r + lane, q = e / 20;
+        ln.pk20[r] = 8 * q | (8 * (e - 20 * q)) << 16;
+    }
+}
+
+__device__ __forceinline__ void flush(const Counters& c, int lane, unsigned long long* diag) {
+    if (lane == 0) {
+        if (c.skipped) atomicAdd(diag + HX_DIAG_RO_REBIN, (unsigned long long)c.skipped);
+        if (c.passes) atomicAdd(diag + HX_DIAG_RO_FIXUP, (unsigned long long)c.passes);
+    }
+}
+
+__device__ __forceinline__ unsigned med3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// the value lane^M holds: DPP moves where one or two of them express the permutation, the LDS crossbar for M = 16, 31, 63
+template <int M>
+__device__ __forceinline__ unsigned xor_lane(int addr, unsigned x) {
+    const int v = (int)x;
+    if constexpr (M == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return __builtin_amdgcn_mov_dpp(v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (M == 15) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); // row_mirror
+    else if constexpr (M == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    else if constexpr (M == 4)                                                              // 7 ^ 3
+        return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+    else return __builtin_amdgcn_ds_bpermute(addr, v);
+}
+
+struct Keys {
+    unsigned k[SLOTS];
+};
+
+template <int J>
+__device__ __forceinline__ void lane_step(Keys& v) {  // slot s against s^J
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++)
+        if ((s & J) == 0) {
+            const unsigned a = v.k[s], b = v.k[s | J];
+            v.k[s] = min(a, b);
+            v.k[s | J] = max(a, b);
+        }
+}
+
+template <int W>
+__device__ __forceinline__ void lane_mirror(Keys& v) {  // slot s against s^(W-1) inside blocks of W
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++)
+        if ((s & (W - 1)) < W / 2) {
+            const unsigned a = v.k[s], b = v.k[s ^ (W - 1)];
+            v.k[s] = min(a, b);
+            v.k[s ^ (W - 1)] = max(a, b);
+        }
+}
+
+// exchange with lane^M: slot s meets the partner's slot s (plain step) or 7-s (MIRROR, first step of a phase)
+template <int M, bool MIRROR>
+__device__ __forceinline__ void cross_step(Keys& v, int lane, const Lane& ln) {
+    constexpr int TOP = MIRROR ? (M + 1) / 2 : M;
+    constexpr int T = TOP == 1 ? 0 : TOP == 2 ? 1 : TOP == 4 ? 2 : TOP == 8 ? 3 : TOP == 16 ? 4 : 5;
+    const int addr = (lane ^ M) << 2;
+    Keys n;
+#pragma unroll
+    for (int s = 0; s < SLOTS; s++) {
+        const int ps = MIRROR ? SLOTS - 1 - s : s;
+        n.k[s] = med3(v.k[s], xor_lane<M>(addr, v.k[ps]), ln.c[T]);
+    }
+    v = n;
+}
+
+// position p = 8 lane + slot, ascending
+__device__ __forceinline__ void sort512(Keys& v, int lane, const Lane& ln) {
+    lane_step<1>(v);
+    lane_mirror<4>(v); lane_step<1>(v);
+    lane_mirror<8>(v); lane_step<2>(v); lane_step<1>(v);
+#define RO_LANE_TAIL lane_step<4>(v); lane_step<2>(v); lane_step<1>(v);
+    cross_step<1, true>(v, lane, ln); RO_LANE_TAIL
+    cross_step<3, true>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
+    cross_step<7, true>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
+    RO_LANE_TAIL
+    cross_step<15, true>(v, lane, ln); cross_step<4, false>(v, lane, ln); cross_step<2, false>(v, lane, ln);
+    cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
+    cross_step<31, true>(v, lane, ln); cross_step<8, false>(v, lane, ln); cross_step<4, false>(v, lane, ln);
+    cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
+    cross_step<63, true>(v, lane, ln); cross_step<16, false>(v, lane, ln); cross_step<8, false>(v, lane, ln);
+    cross_step<4, false>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
+    RO_LANE_TAIL
+#undef RO_LANE_TAIL
+}
+
+__device__ __forceinline__ double shfl(int addr, double x) {  // the value of lane addr / 4
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int padded(int w) { return w + (w >> 3); }
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double x) {  // the DPP-selected lane's value, 0.0 where there is none
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then the row
+// totals across (row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3).  All variants of the mixing kernel
+// add in this order.
+__device__ __forceinline__ double wave_inclusive_sum(double x) {
+    x += dpp_or_zero<0x111, 0xF>(x);
+    x += dpp_or_zero<0x112, 0xF>(x);
+    x += dpp_or_zero<0x114, 0xF>(x);
+    x += dpp_or_zero<0x118, 0xF>(x);
+    x += dpp_or_zero<0x142, 0xA>(x);
+    x += dpp_or_zero<0x143, 0xC>(x);
+    return x;
+}
+
+// Orders this wavefront's LDS traffic.  One wavefront works on one problem and the LDS unit serves a wavefront's
+// instructions in issue order, so a fence at wavefront scope (no s_barrier, no wait for acknowledgements) is all that
+// is needed between a write by one lane and a read by another; workgroups may therefore hold several wavefronts.
+__device__ __forceinline__ void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One problem.  Lanes 0..19 pass the running mix and the new absorber's (already scaled) k-coefficients at their Gauss
+// point and receive the mixed value (kernels.cu:3293-3396, ro_method == 1, s > 0, ny == 20).  All 64 lanes must call.
+template <bool MONOTONE, bool CROSSING>
+__device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys& v, int yx, int hmin, int sh_bits) {
+    const int nfirst = NY * yx;
+    const int inv_yx = (1048576 + yx - 1) / yx;
+    const char* outer = (const char*)sh.outer;
+    const char* inner = (const char*)sh.inner;
+    const char* hw = (const char*)sh.hw;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const int e = 64 * r + lane;
+        double K = __builtin_inf(), g = 0.0;
+        unsigned key = 0xFFFFFE00u | (unsigned)e;
+        if (r < 6 || (r == 6 && lane < N - 6 * 64)) {  // e < 400: every lane for r < 6, 16 lanes for r = 6, none for r = 7
+            int aq = ln.pk20[r] & 0xFFFF, ar = ln.pk20[r] >> 16;  // byte offsets of outer[e / 20], inner[e % 20]
+            if (CROSSING) {  // the curves cross: two fill regions (:3332-3365)
+                const bool first = e < nfirst;
+                // e / yx and e / 20 for e < 512 as multiply-shift (exact: e * d < 2^20 / d for d <= 20)
+                const int q = (int)(__umul24(e, first ? inv_yx : 52429) >> 20);
+                const int rem = e - __umul24(q, first ? yx : NY);
+                // second part: the curves have changed places, the other one is on the outer loop
+                aq = 8 * (first ? q : rem);
+                ar = 8 * (first ? rem : q);
+            }
+            K = *(const double*)(outer + aq) + *(const double*)(inner + ar);
+            g = *(const double*)(hw + aq) * *(const double*)(hw + ar);
+            int dh = __double2hiint(K) - hmin;
+            if (!MONOTONE) dh = max(dh, 0);
+            unsigned q23 = sh_bits >= 32 ? (unsigned)dh >> (sh_bits - 32)
+                                         : __builtin_amdgcn_alignbit((unsigned)dh, (unsigned)__double2loint(K), sh_bits);
+            if (!MONOTONE) q23 = min(q23, 0x7FFFFFu);
+            key = q23 << 9 | (unsigned)e;
+        }
+        sh.A[e] = K;
+        sh.B[e] = g;
+        v.k[r] = key;
+    }
+}
+
+__device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, double my_mix, double my_add, Counters& cnt) {
+    // corners of the tableau, wave-uniform
+    const double m0 = __shfl(my_mix, 0), a0 = __shfl(my_add, 0), m19 = __shfl(my_mix, NY - 1), a19 = __shfl(my_add, NY - 1);
+    // less than 1 % of the other everywhere: correlated-k (:3297-3310)
+    if ((0.01 * m0 > a19) || (0.01 * a0 > m19)) return my_mix + my_add;
+    const bool mix_first = m0 > a0;
+    sync();  // the previous problem's readers are done with sh
+    if (lane < NY) {
+        sh.outer[lane] = mix_first ? my_mix : my_add;
+        sh.inner[lane] = mix_first ? my_add : my_mix;
+    }
+    sync();
+    // last crossing of the two curves (:3321-3329); are both k-distributions (ascending)?
+    bool cross = false, down = false;
+    if (lane >= 1 && lane < NY) {
+        const double po = sh.outer[lane - 1], pi = sh.inner[lane - 1];
+        const double pm = mix_first ? po : pi, pa = mix_first ? pi : po;
+        cross = (my_mix > my_add) != (pm > pa);
+        down = my_mix < pm || my_add < pa;
+    }
+    const unsigned long long cmask = __ballot(cross);
+    const int yx = cmask ? 63 - __clzll((long long)cmask) : NY;
+    const bool monotone = __ballot(down) == 0;
+    double kmin = m0 + a0, kmax = m19 + a19;
+    if (!monotone) {  // the extreme sums are not at the corners of the tableau
+        double mn1 = sh.outer[0], mx1 = mn1, mn2 = sh.inner[0], mx2 = mn2;
+#pragma unroll 1
+        for (int j = 1; j < NY; j++) {
+            mn1 = fmin(mn1, sh.outer[j]); mx1 = fmax(mx1, sh.outer[j]);
+            mn2 = fmin(mn2, sh.inner[j]); mx2 = fmax(mx2, sh.inner[j]);
+        }
+        kmin = mn1 + mn2;
+        kmax = mx1 + mx2;
+    }
+    // key scale (wave-uniform): (bits(K) - (hi32(Kmin) << 32)) >> sh fits 23 bits for every K <= Kmax
+    const int hmin = __builtin_amdgcn_readfirstlane(__double2hiint(kmin));
+    const unsigned long long dmax =
+        ((unsigned long long)(unsigned)(__builtin_amdgcn_readfirstlane(__double2hiint(kmax)) - hmin) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(kmax));
+    const int bl = dmax ? 64 - __clzll((long long)dmax) : 0;
+    const int sh_bits = bl > 23 ? bl - 23 : 0;
+    Keys v;
+    if (yx == NY) {
+        if (monotone) fill<true, false>(sh, ln, lane, v, yx, hmin, sh_bits);
+        else fill<false, false>(sh, ln, lane, v, yx, hmin, sh_bits);
+    } else {
+        if (monotone) fill<true, true>(sh, ln, lane, v, yx, hmin, sh_bits);
+        else fill<false, true>(sh, ln, lane, v, yx, hmin, sh_bits);
+    }
+    sync();
+    // already ascending in fill order?
+    bool unsorted = false;
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const int e = 64 * r + lane;
+        if (r < 6 || lane < N - 1 - 6 * 64) unsorted = unsorted || sh.A[e] > sh.A[e + 1];
+    }
+    int src[SLOTS];  // byte offset of the fill position of the element at rank 8 lane + r
+    if (__ballot(unsorted) == 0) {
+#pragma unroll
+        for (int r = 0; r < SLOTS; r++) src[r] = 8 * (SLOTS * lane + r);
+    } else {
+        sort512(v, lane, ln);
+#pragma unroll
+        for (int r = 0; r < SLOTS; r++) src[r] = (v.k[r] & 511) << 3;
+    }
+    double K[SLOTS], g[SLOTS];
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        K[r] = *(const double*)((const char*)sh.A + src[r]);
+        g[r] = *(const double*)((const char*)sh.B + src[r]);
+    }
+    // exact finish: any inversion left by the quantisation?
+    const int next = (lane < 63 ? lane + 1 : lane) << 2, prev = (lane > 0 ? lane - 1 : lane) << 2;
+    int passes = 0;
+    for (;;) {
+        bool inv = false;
+#pragma unroll
+        for (int r = 0; r + 1 < SLOTS; r++) inv = inv || K[r] > K[r + 1];
+        const double kn = shfl(next, K[0]);
+        inv = inv || (lane < 63 && K[SLOTS - 1] > kn);
+        if (__ballot(inv) == 0 || passes >= 2 * LDS_N) break;
+        passes++;
+        auto ce = [&](int a, int b) {
+            const bool sw = K[a] > K[b];
+            const double ka = K[a], kb = K[b], ga = g[a], gb = g[b];
+            K[a] = sw ? kb : ka; K[b] = sw ? ka : kb;
+            g[a] = sw ? gb : ga; g[b] = sw ? ga : gb;
+        };
+        ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7);
+        ce(1, 2); ce(3, 4); ce(5, 6);
+        const double kn0 = shfl(next, K[0]), gn0 = shfl(next, g[0]);
+        const double kp7 = shfl(prev, K[SLOTS - 1]), gp7 = shfl(prev, g[SLOTS - 1]);
+        const bool sw_hi = lane < 63 && K[SLOTS - 1] > kn0, sw_lo = lane > 0 && kp7 > K[0];
+        if (sw_hi) { K[SLOTS - 1] = kn0; g[SLOTS - 1] = gn0; }
+        if (sw_lo) { K[0] = kp7; g[0] = gp7; }
+    }
+    cnt.passes += passes;
+    // cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376): 8 per lane + wave exclusive scan
+    double csum = 0.0;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) csum += g[r];
+    double run = wave_inclusive_sum(csum) - csum;
+    sync();  // every lane has fetched its (K, g): A and B change meaning
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const int w = SLOTS * lane + r;
+        if (w < N) {
+            sh.A[9 * lane + r] = K[r];  // = padded(w)
+            sh.B[9 * lane + r] = run + 0.5 * g[r];
+        }
+        run += g[r];
+    }
+    sync();
+    // re-binning (:3379-3396): first w >= 1 with Y_w > y_q, at most one Gauss point per w
+    int w = N + lane;  // beyond the Gauss points: ascending, so that no skip is seen there
+    double yq = 0.0;
+    if (lane < NY) {
+        yq = sh.gy[lane];
+        int lo = 1, hi = N;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sh.B[padded(mid)] > yq) hi = mid; else lo = mid + 1;
+        }
+        w = lo;
+    }
+    // a Gauss point that falls into the interval of its predecessor takes the next one (the reference's walk advances w
+    // before it looks at the next point, and reports a malfunction, :3383-3387): w'_q = max over j <= q of (w_j + q - j)
+    int wq = w;
+    const int wprev = __shfl_up(w, 1);
+    if (__ballot(lane >= 1 && lane < NY && w <= wprev) != 0) {  // never seen with Gauss-Legendre points and weights
+        int t = lane < NY ? w - lane : -(1 << 20);
+        for (int d = 1; d < 32; d <<= 1) {
+            const int up = __shfl_up(t, d);
+            if (lane >= d) t = max(t, up);
+        }
+        wq = t + lane;
+        cnt.skipped += __popcll(__ballot(lane < NY && wq != w));
+    }
+    double out = my_mix;  // w = 400: the walk ran out of sums, the reference leaves the entry as it was
+    if (lane < NY && wq < N) {
+        const int i0 = padded(wq - 1), i1 = padded(wq);
+        out = (sh.A[i0] * (sh.B[i1] - yq) + sh.A[i1] * (yq - sh.B[i0])) / (sh.B[i1] - sh.B[i0]);
+    }
+    return out;
+}
+
+}  // namespace ro

@@ -1,6 +1,7 @@
 // Per-stage entry points, part 4: on-the-fly opacity mixing (correlated-k and random overlap),
 // H2O Rayleigh scattering, scattering-cross-section accumulation, total asymmetry parameter.
 #include "two_stream.h"
+#include "random_overlap.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -302,22 +303,18 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
         }
         __syncthreads();
         // cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376): lane-contiguous
-        // chunks of 7 + wave exclusive scan
-        double g[RO_PER_LANE], csum = 0.0;
-        for (int r = 0; r < RO_PER_LANE; r++) {
-            const int w = lane * RO_PER_LANE + r;
+        // chunks of 8 (the slots of a lane in the sorting networks, so that all three variants add in the same
+        // order and agree bit for bit) + wave exclusive scan
+        double g[BT_PER_LANE], csum = 0.0;
+        for (int r = 0; r < BT_PER_LANE; r++) {
+            const int w = lane * BT_PER_LANE + r;
             g[r] = w < RO_N ? s_Y[w] : 0.0;
             csum += g[r];
         }
-        double incl = csum;
-        for (int d = 1; d < 64; d <<= 1) {
-            const double up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        double run = incl - csum;
+        double run = ro::wave_inclusive_sum(csum) - csum;
         __syncthreads();
-        for (int r = 0; r < RO_PER_LANE; r++) {
-            const int w = lane * RO_PER_LANE + r;
+        for (int r = 0; r < BT_PER_LANE; r++) {
+            const int w = lane * BT_PER_LANE + r;
             if (w < RO_N) s_Y[w] = run + 0.5 * g[r];
             run += g[r];
         }
@@ -354,6 +351,53 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
             }
         }
     }
+}
+
+// ---- random overlap, default kernel: 32-bit quantised keys + exact finish (random_overlap.h) ---------------------
+__global__ void __launch_bounds__(64)
+k_add_to_mixed_opac_q32(const double* __restrict__ vmr, const double* __restrict__ opac_spec,
+                        double* __restrict__ opac_wg, const double* __restrict__ meanmolmass,
+                        const double* __restrict__ gauss_weight, const double* __restrict__ gauss_y,
+                        double mass_spec, int nbin, int nlev, unsigned long long* __restrict__ diag) {
+    __shared__ ro::Shared sh;
+    const int lane = threadIdx.x;
+    ro::Lane ln;
+    ro::init(sh, ln, lane, gauss_weight, gauss_y);
+    // a contiguous run of (bin, level) problems per wavefront: the level -- and with it the factor
+    // vmr * mass / mu, a division -- changes once or twice per run
+    const long long npair = (long long)nbin * nlev;
+    const long long chunk = (npair + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * chunk, p1 = min(npair, p0 + chunk);
+    int i_cur = -1;
+    double fac = 0.0;
+    ro::Counters cnt;
+    for (long long pair = p0; pair < p1; pair++) {
+        const int i = (int)(pair / nbin);
+        if (i != i_cur) {
+            i_cur = i;
+            fac = vmr[i] * mass_spec / meanmolmass[i];  // (vmr * mass) / mu, then times kappa (:3293)
+        }
+        const size_t base = (size_t)RO_NY * pair;  // = ny*x + ny*nbin*i
+        double my_mix = 0.0, my_add = 0.0;
+        if (lane < RO_NY) {
+            my_mix = opac_wg[base + lane];
+            my_add = fac * opac_spec[base + lane];
+        }
+        const double out = ro::mix(sh, ln, lane, my_mix, my_add, cnt);
+        if (lane < RO_NY) opac_wg[base + lane] = out;
+    }
+    ro::flush(cnt, lane, diag);
+}
+
+__global__ void __launch_bounds__(256)
+k_add_correlated_k(const double* __restrict__ vmr, const double* __restrict__ opac_spec, double* __restrict__ opac_wg,
+                   const double* __restrict__ meanmolmass, double mass_spec, int ny, int nbin, int nlev) {
+    // kernels.cu:3302-3310 for any ny: opac += (vmr * mass / mu) * kappa
+    const size_t per_level = (size_t)ny * nbin;
+    const int i = blockIdx.y;
+    const double fac = vmr[i] * mass_spec / meanmolmass[i];
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < per_level; k += (size_t)gridDim.x * blockDim.x)
+        opac_wg[per_level * i + k] += fac * opac_spec[per_level * i + k];
 }
 
 // calc_index_h2o / calc_h2o_scat (kernels.cu:3174-3205, :3404-3440)
@@ -422,18 +466,26 @@ int hx_add_to_mixed_opac(hx_context* ctx, const double* vmr, const double* opac_
         return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 (got %d)", ny);
     const long long npair = (long long)nbin * nlay_or_nint;
     const int grid = (int)min(npair, (long long)256 * 12 * 16);
-    static const bool rank_sort = [] {  // cross-check / A-B knob, read once
+    static const int sort_kind = [] {  // cross-check / A-B knob, read once: q32 (default), bitonic (fp64 network), rank
         const char* e = getenv("HELIOS_RO_SORT");
-        return e != nullptr && strcmp(e, "rank") == 0;
+        if (e != nullptr && strcmp(e, "rank") == 0) return 2;
+        if (e != nullptr && strcmp(e, "bitonic") == 0) return 1;
+        return 0;
     }();
-    if (rank_sort)
+    if (sort_kind == 2)
         k_add_to_mixed_opac<false><<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
                                                                 gauss_y, mass_spec, s, ro_method, ny, nbin,
                                                                 nlay_or_nint, ctx->diag + HX_DIAG_RO_REBIN);
-    else
+    else if (sort_kind == 1)
         k_add_to_mixed_opac<true><<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
                                                                gauss_y, mass_spec, s, ro_method, ny, nbin,
                                                                nlay_or_nint, ctx->diag + HX_DIAG_RO_REBIN);
+    else if (!ro_possible)
+        k_add_correlated_k<<<dim3(hx_cdiv((long long)ny * nbin, 1024), nlay_or_nint), 256, 0, ctx->stream>>>(
+            vmr, opac_spec, opac_wg, meanmolmass, mass_spec, ny, nbin, nlay_or_nint);
+    else
+        k_add_to_mixed_opac_q32<<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
+                                                             gauss_y, mass_spec, nbin, nlay_or_nint, ctx->diag);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -56,7 +56,9 @@ typedef struct hx_diag {
     uint64_t g_limited;          /* G+ / G- values clipped to +-1e8 */
     uint64_t ro_rebin_skipped;   /* Gauss points that met an already used interval in add_to_mixed_opac */
     double energy_correction;    /* factor applied by the last hx_corr_inc_energy (0 = none yet) */
-    uint64_t reserved[3];
+    uint64_t ro_fixup_passes;    /* exact odd-even passes add_to_mixed_opac ran after its quantised-key sort (a cost
+                                    figure: how often two pair sums of different rows agree to 2^-18) */
+    uint64_t reserved[2];
 } hx_diag;
 int hx_diag_read(hx_context* ctx, hx_diag* out);
 int hx_diag_reset(hx_context* ctx);

@@ -107,7 +107,7 @@ def test_random_overlap_vs_reference_on_the_gpu(hip, refgpu):
     want = _ro_run(refgpu)
     for k in want:
         assert np.all(np.isfinite(got[k])), k
-        np.testing.assert_allclose(got[k], want[k], rtol=1e-12, err_msg=k)
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-11 if k == "wide" else 5e-12, err_msg=k)   # see test_gpu_stages
 
 
 def test_species_loop_vs_reference_on_the_gpu(hip, refgpu):

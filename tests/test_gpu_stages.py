@@ -156,6 +156,16 @@ def _ro_cases():
     out["flat_mix"] = (np.full(shape, 0.25), out["generic"][1])
     out["flat_both"] = (np.full(shape, 0.25), np.full(shape, 0.5) / fac)
     out["unsorted"] = (10.0 ** rng.uniform(-2, 0, shape), 10.0 ** rng.uniform(-2, 0, shape) / fac)
+    # the quantised keys' hard cases: two curves of the same shape (every anti-diagonal of the tableau ties to the last
+    # bits), a narrow range (all sums within 1e-5: the key shift goes below 32), a wide one with a tiny minimum
+    # (denormal-sized sums next to O(1e6)), and an absorber just above the 1 % negligibility threshold
+    shape_curve = np.sort(10.0 ** rng.uniform(-3, 1, shape), axis=2)
+    out["same_shape"] = (shape_curve, shape_curve * (1.0 + 1e-9 * rng.uniform(-1, 1, shape)) / fac)
+    out["narrow"] = (1.0 + 1e-5 * np.sort(rng.uniform(0, 1, shape), axis=2),
+                     (1.0 + 1e-5 * np.sort(rng.uniform(0, 1, shape), axis=2)) / fac)
+    out["tiny_min"] = (np.sort(10.0 ** rng.uniform(-300, 6, shape), axis=2),
+                       np.sort(10.0 ** rng.uniform(-300, 6, shape), axis=2) / fac)
+    out["dominated"] = (generic, np.sort(generic[..., ::-1] * 0.03, axis=2) / fac)
     return (ny, nbin, nlev), out
 
 
@@ -174,9 +184,10 @@ def _ro_run(impl):
 
 
 def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
-    """the bitonic network (default) against the oracle's adjacent-swap sort, incl. problems full of equal sums, and
-    against the all-pairs ranking kernel (HELIOS_RO_SORT=rank, read once per process -> child process): the two
-    device variants must agree bit for bit"""
+    """the quantised-key network with exact finish (default) against the oracle's adjacent-swap sort, incl. problems full
+    of equal sums, and against the two other device variants -- the fp64 bitonic network (HELIOS_RO_SORT=bitonic) and the
+    all-pairs ranking (HELIOS_RO_SORT=rank); the knob is read once per process -> child processes.  All three must
+    agree bit for bit."""
     import os
     import subprocess
     import sys
@@ -184,16 +195,21 @@ def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
     want = _ro_run(port)
     for k in want:
         assert np.all(np.isfinite(got[k])), k
-        np.testing.assert_allclose(got[k], want[k], rtol=1e-12, err_msg=k)
-    out = tmp_path / "rank.npz"
+        # the interpolation weight (y - Y[w-1]) / (Y[w] - Y[w-1]) carries the rounding of the cumulative weights Y ~ 1 (a
+        # parallel scan here, 399 sequential additions in the reference) over an interval that can be as short as the
+        # smallest weight product, (0.0176 / 2)^2 = 7.7e-5: 2.2e-16 / 7.7e-5 = 3e-12.  'wide': neighbouring sums up to 18
+        # decades apart multiply that by K[w] / K[w-1]
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-11 if k == "wide" else 5e-12, err_msg=k)
     here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys, numpy as np; sys.path.insert(0, %r); import test_gpu_stages as t; from impls import hip_impl; "
-            "np.savez(%r, **t._ro_run(hip_impl()))" % (here, str(out)))
-    env = dict(os.environ, HELIOS_RO_SORT="rank")
-    subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=os.path.dirname(here), timeout=600)
-    z = np.load(out)
-    for k in want:
-        np.testing.assert_array_equal(got[k], z[k], err_msg=k)
+    for kind in ("rank", "bitonic"):
+        out = tmp_path / (kind + ".npz")
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import test_gpu_stages as t; from impls import hip_impl; "
+                "np.savez(%r, **t._ro_run(hip_impl()))" % (here, str(out)))
+        env = dict(os.environ, HELIOS_RO_SORT=kind)
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, cwd=os.path.dirname(here), timeout=600)
+        z = np.load(out)
+        for k in want:
+            np.testing.assert_array_equal(got[k], z[k], err_msg="%s vs %s" % (k, kind))
 
 
 def test_diagnostics_record(hip, port):
