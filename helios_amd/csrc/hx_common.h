@@ -70,3 +70,8 @@ extern "C" int hx_internal_fdir_noniso(hx_context* ctx, double* F_dir_wg, double
                                        double mu_star, double R_planet, double R_star, double a,
                                        int dir_beam, int geom_zenith_corr, int ninterface, int nbin,
                                        int ny);
+extern "C" int hx_internal_fdir_noniso_batch(hx_context* ctx, double* F_dir_wg, double* Fc_dir_wg, const double* star,
+                                             const double* delta_tau_wg_upper, const double* delta_tau_wg_lower,
+                                             const double* z_lay, const hx_rt_column* colpar, const int* done,
+                                             int ncol, int dir_beam, int geom_zenith_corr, int ninterface, int nbin,
+                                             int ny);

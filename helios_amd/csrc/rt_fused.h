@@ -64,6 +64,11 @@ struct hx_rt {
     double *opac_k = nullptr, *opac_scat_cross = nullptr, *opac_meanmass = nullptr;
     double* planck_grid = nullptr;  // [(dim+1) * X]; row dim = stellar row of column 0
     std::vector<hx::Species> species;
+    void* species_dev = nullptr;   // SpeciesDev [nspecies]: what the batched mixing kernels read (rt_species.h)
+    int* abs_list = nullptr;       // indices of the absorbing species
+    int nabs = 0;
+    bool species_dev_stale = true;
+    double *fac_lay = nullptr, *fac_int = nullptr;        // vmr * mass / mu per (column, level, species)
     double *spec_lay = nullptr, *spec_int = nullptr;      // one species interpolated, [Y*X*I]
     double *sc_spec_lay = nullptr, *sc_spec_int = nullptr;  // one species' scattering cross-sections
 

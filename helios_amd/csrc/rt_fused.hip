@@ -5,6 +5,7 @@
 //   refresh  = :860-879  (opacities, mean molecular mass, [species mixing], transmission, dz, beam)
 //   step     = :856-857 + :880-888 + :926-932 (T_int, Planck, 3*scat+1 sweeps, integrate, T step)
 #include "rt_kernels.h"
+#include "rt_species.h"
 
 #include <algorithm>
 #include <cmath>
@@ -264,30 +265,6 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
         default: fn<16>(rt, a); break;            \
     }
 
-// mean molecular mass of column c from its mixing ratios (layers, and interfaces if asked)
-int meanmolmass_from_vmr(hx_rt* rt, int c, bool interfaces) {
-    hx_context* ctx = rt->ctx;
-    const int S = rt->d.nspecies, I = rt->I;
-    const double* vl = rt->vmr_lay + (size_t)c * S * I;
-    const double* vi = rt->vmr_int + (size_t)c * S * I;
-    std::vector<double> w(S);
-    std::vector<int> inmu(S);
-    for (int s = 0; s < S; s++) { w[s] = rt->species[s].weight; inmu[s] = rt->species[s].in_mu; }
-    double* dw = nullptr; int* dm = nullptr;
-    HX_HIP(ctx, hipMalloc((void**)&dw, S * 8));
-    HX_HIP(ctx, hipMalloc((void**)&dm, S * 4));
-    h2d(rt, dw, w.data(), S * 8);
-    h2d(rt, dm, inmu.data(), S * 4);
-    k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vl, dw, dm, rt->mmm_lay + (size_t)c * I, S, I);
-    if (interfaces)
-        k_rt_meanmolmass<<<hx_cdiv(I, 64), 64, 0, ctx->stream>>>(vi, dw, dm, rt->mmm_int + (size_t)c * I, S, I);
-    HX_LAUNCH_CHECK(ctx);
-    HX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(dw);
-    (void)hipFree(dm);
-    return 0;
-}
-
 int set_flux_shmem_limits(hx_rt* rt) {
     const size_t shmem = flux_shmem_bytes(rt);
     if (shmem > 160 * 1024) return rt_fail(rt, HX_E_UNSUPPORTED, "workgroup LDS demand exceeds 160 KiB");
@@ -314,6 +291,9 @@ int hx_rt_struct_sizes(int* dims_size, int* flags_size, int* column_size) {
     return 0;
 }
 
+static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* flags,
+                          const hx_rt_column* columns);
+
 int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* flags,
                  const hx_rt_column* columns, hx_rt** out_rt) {
     if (!ctx || !dims || !flags || !columns || !out_rt) return HX_E_ARG;
@@ -324,6 +304,17 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
                "bad Planck-table dimensions");
     HX_HIP(ctx, hipSetDevice(ctx->device));
     hx_rt* rt = new hx_rt();
+    const int rc_create = rt_create_into(rt, ctx, dims, flags, columns);
+    if (rc_create) {  // frees every device allocation made so far (a failed 100 GB batch must not leak them)
+        hx_rt_destroy(rt);
+        return rc_create;
+    }
+    *out_rt = rt;
+    return 0;
+}
+
+static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* flags,
+                          const hx_rt_column* columns) {
     rt->ctx = ctx;
     rt->d = *dims;
     rt->f = *flags;
@@ -332,11 +323,8 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     rt->C = dims->ncol;
     rt->nsweep = 3 * (flags->scat ? 1 : 0) + 1;  // computation.py:531-537 (iterative run type)
     if (const char* e = getenv("HELIOS_RT_DEBUG_NSWEEP")) rt->nsweep = atoi(e);  // profiling experiments only
-    if (!choose_geometry(rt->L, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g)) {
-        delete rt;
-        return hx_fail(ctx, HX_E_UNSUPPORTED,
-                       "fused path supports nlayer <= 512; use the per-stage API");
-    }
+    if (!choose_geometry(rt->L, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g))
+        return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512; use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
     rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
@@ -344,7 +332,7 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
     int rc = set_flux_shmem_limits(rt);
-    if (rc) { delete rt; return rc; }
+    if (rc) return rc;
 
     const size_t X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, C = rt->C, nc = X * Y;
     RT_ALLOC(rt->interwave, X + 1); RT_ALLOC(rt->deltawave, X); RT_ALLOC(rt->wave, X);
@@ -396,15 +384,19 @@ int hx_rt_create(hx_context* ctx, const hx_rt_dims* dims, const hx_rt_flags* fla
         rt->tp_lay = t1; rt->tp_int = t2;
     }
     RT_ALLOC(rt->T_lay_ref, C * (L + 1)); RT_ALLOC(rt->T_int_ref, C * I);
-    rc = h2d(rt, rt->colpar, rt->cols.data(), C * sizeof(hx_rt_column));
-    if (rc) return rc;
-    *out_rt = rt;
-    return 0;
+    if (dims->nspecies > 0) {
+        SpeciesDev* sd = nullptr;
+        RT_ALLOC(sd, (size_t)dims->nspecies);
+        rt->species_dev = sd;
+        RT_ALLOC(rt->abs_list, (size_t)dims->nspecies);
+        RT_ALLOC(rt->fac_lay, C * I * dims->nspecies); RT_ALLOC(rt->fac_int, C * I * dims->nspecies);
+    }
+    return h2d(rt, rt->colpar, rt->cols.data(), C * sizeof(hx_rt_column));
 }
 
 int hx_rt_destroy(hx_rt* rt) {
     if (!rt) return 0;
-    (void)hipStreamSynchronize(rt->ctx->stream);
+    if (rt->ctx) (void)hipStreamSynchronize(rt->ctx->stream);
     ProfScope::flush(rt);
     for (void* p : rt->allocs) (void)hipFree(p);
     delete rt;
@@ -463,6 +455,7 @@ int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const doub
     }
     if (is_h2o == 2) sp.scattering = true;  // H2O with computed Rayleigh cross-section
     rt->have_tables = true;
+    rt->species_dev_stale = true;
     return 0;
 }
 
@@ -599,175 +592,135 @@ int hx_rt_build_planck_table(hx_rt* rt, int energy_correction) {
     return 0;
 }
 
-static int read_done(hx_rt* rt, std::vector<int>& done) {
-    done.resize(rt->C);
-    return hx_d2h(rt->ctx, done.data(), rt->done, rt->C * sizeof(int));
+// device image of the species list for the batched mixing kernels (rt_species.h)
+static int upload_species_table(hx_rt* rt) {
+    if (!rt->species_dev_stale) return 0;
+    const int S = rt->d.nspecies;
+    std::vector<SpeciesDev> sd(S);
+    std::vector<int> abs;
+    for (int s = 0; s < S; s++) {
+        const Species& sp = rt->species[s];
+        sd[s] = SpeciesDev{sp.pretab, sp.scat_cross, sp.weight, sp.absorbing ? 1 : 0, sp.scattering ? 1 : 0,
+                           sp.is_h2o ? 1 : 0, (rt->f.kcoeff_mixing_ro && !sp.is_cia) ? 1 : 0,  // computation.py:1343
+                           sp.in_mu, 0};
+        if (sp.absorbing) abs.push_back(s);
+    }
+    int rc = h2d(rt, rt->species_dev, sd.data(), S * sizeof(SpeciesDev));
+    if (!rc && !abs.empty()) rc = h2d(rt, rt->abs_list, abs.data(), abs.size() * sizeof(int));
+    rt->nabs = (int)abs.size();
+    rt->species_dev_stale = rc != 0;
+    return rc;
+}
+
+// on-the-fly mixing of every column, level and bin of the batch (computation.py:865-869, :1454-1501)
+static int refresh_species(hx_rt* rt) {
+    hx_context* ctx = rt->ctx;
+    int rc = upload_species_table(rt);
+    if (rc) return rc;
+    MixArgs m;
+    m.X = rt->X; m.Y = rt->Y; m.L = rt->L; m.I = rt->I; m.C = rt->C; m.S = rt->d.nspecies;
+    m.ntemp = rt->d.ntemp; m.npress = rt->d.npress; m.nabs = rt->nabs;
+    m.sp = (const SpeciesDev*)rt->species_dev; m.abs_list = rt->abs_list;
+    m.T_lay = rt->T_lay; m.T_int = rt->T_int; m.p_lay = rt->p_lay; m.p_int = rt->p_int;
+    m.vmr_lay = rt->vmr_lay; m.vmr_int = rt->vmr_int;
+    m.ktemp = rt->ktemp; m.kpress = rt->kpress; m.gauss_w = rt->gauss_w; m.gauss_y = rt->gauss_y; m.wave = rt->wave;
+    m.mmm_lay = rt->mmm_lay; m.mmm_int = rt->mmm_int;
+    m.tp_lay = (TPIndex*)rt->tp_lay; m.tp_int = (TPIndex*)rt->tp_int;
+    m.fac_lay = rt->fac_lay; m.fac_int = rt->fac_int;
+    m.opac_wg_lay = rt->opac_wg_lay; m.opac_wg_int = rt->opac_wg_int;
+    m.scat_lay = rt->scat_cross_lay; m.scat_int = rt->scat_cross_int;
+    m.done = rt->done; m.diag = ctx->diag;
+    k_rt_species_prep<<<dim3(hx_cdiv(rt->I, 64), rt->C), 64, 0, ctx->stream>>>(m);
+    HX_LAUNCH_CHECK(ctx);
+    {
+        ProfScope ps(rt, "add_to_mixed_opac");
+        const long long npair = (long long)rt->C * (rt->L + rt->I) * rt->X;
+        // short runs (about ten points, each folding in every absorber): a wavefront lives for a fraction of a
+        // millisecond, so the last round of workgroups does not leave the chip half empty
+        static const int waves = [] { const char* e = getenv("HELIOS_RT_MIX_WAVES"); return e ? atoi(e) : 256 * 16 * 48; }();
+        const int grid = (int)std::min(npair, (long long)waves);
+        k_rt_mix_species<<<grid, 64, 0, ctx->stream>>>(m);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    {
+        ProfScope ps(rt, "mixed_scat");
+        k_rt_scat_species<<<dim3(hx_cdiv(rt->X, 256), rt->L + rt->I, rt->C), 256, 0, ctx->stream>>>(m);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    return 0;
 }
 
 int hx_rt_refresh(hx_rt* rt) {
     hx_context* ctx = rt->ctx;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables && rt->have_planck, HX_E_STATE,
                "set grid, tables and build the Planck table first");
-    const int X = rt->X, Y = rt->Y, L = rt->L, I = rt->I;
-    const size_t nc = (size_t)X * Y, wgI = nc * I, bandI = (size_t)X * I;
-    std::vector<int> done;
-    int rc = read_done(rt, done);
-    if (rc) return rc;
+    const int X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, C = rt->C;
+    const size_t nc = (size_t)X * Y;
+    int rc = 0;
+    if (rt->d.nspecies > 0) {  // computation.py:1343: random overlap is written for 20 Gauss points
+        bool any_ro = false;
+        for (const Species& sp : rt->species) any_ro = any_ro || (sp.absorbing && rt->f.kcoeff_mixing_ro && !sp.is_cia);
+        if (Y != ro::NY && any_ro) return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 (got %d)", Y);
+        HX_REQUIRE(ctx, Y <= ro::NY, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 20 Gauss points");
+    }
     KArgs a = make_args(rt);
     {   // interface temperatures (and node Planck values) of the CURRENT layer temperatures
         ProfScope ps(rt, "rt_nodes");
-        dim3 grid(hx_cdiv(X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
+        dim3 grid(hx_cdiv(X, 32), hx_cdiv(rt->H + 3, 32), C);
         k_rt_nodes<<<grid, 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
     }
     ProfScope ps_all(rt, "refresh_total");
+    // Every launch below covers all columns; a column whose loop has ended (done[c], set on the device) is skipped
+    // inside the kernels and keeps the state of its last real refresh.  No host round trip.
     // premixed table without the beam: the k-table look-up is fused into k_rt_coef (the beam needs the
     // materialised opacities for its optical depths); HELIOS_RT_FUSED_LOOKUP=0 switches it off
     bool fused_lookup = rt->d.nspecies == 0 && !rt->f.dir_beam;
     if (const char* e = getenv("HELIOS_RT_FUSED_LOOKUP")) fused_lookup = fused_lookup && atoi(e) != 0;
-    if (fused_lookup) {
-        k_rt_tp_index<<<dim3(hx_cdiv(I, 64), rt->C), 64, 0, ctx->stream>>>(a, (TPIndex*)rt->tp_lay, (TPIndex*)rt->tp_int);
-        k_rt_scat_interp<<<dim3(hx_cdiv(X, 256), I, rt->C), 256, 0, ctx->stream>>>(a, rt->scat_cross_lay, rt->scat_cross_int);
-        HX_LAUNCH_CHECK(ctx);
-        // remember the temperatures this refresh used, so that the arrays can be rebuilt on demand
-        for (int c = 0; c < rt->C; c++) {
-            if (done[c]) continue;  // a finished column keeps the state of its last real refresh
-            hx_d2d(ctx, rt->T_lay_ref + (size_t)c * (L + 1), rt->T_lay + (size_t)c * (L + 1), (size_t)(L + 1) * 8);
-            hx_d2d(ctx, rt->T_int_ref + (size_t)c * I, rt->T_int + (size_t)c * I, (size_t)I * 8);
-        }
-    }
     rt->opac_stale = fused_lookup;
-    for (int c = 0; c < rt->C; c++) {
-        if (done[c]) continue;
-        const double* T_lay = rt->T_lay + (size_t)c * (L + 1);
-        const double* T_int = rt->T_int + (size_t)c * I;
-        const double* p_lay = rt->p_lay + (size_t)c * L;
-        const double* p_int = rt->p_int + (size_t)c * I;
-        double* opl = rt->opac_wg_lay + c * wgI;
-        double* opi = rt->opac_wg_int + c * wgI;
-        double* scl = rt->scat_cross_lay + c * bandI;
-        double* sci = rt->scat_cross_int + c * bandI;
-        double* mml = rt->mmm_lay + (size_t)c * I;
-        double* mmi = rt->mmm_int + (size_t)c * I;
-        if (rt->d.nspecies == 0 && fused_lookup) {
-            // opacities are interpolated inside k_rt_coef; only the mean molecular mass here
-            rc = hx_meanmolmass_interpol(ctx, T_lay, rt->ktemp, mml, rt->opac_meanmass, p_lay, rt->kpress,
-                                         rt->d.npress, rt->d.ntemp, L);
-            if (rc) return rc;
-            rc = hx_meanmolmass_interpol(ctx, T_int, rt->ktemp, mmi, rt->opac_meanmass, p_int, rt->kpress,
-                                         rt->d.npress, rt->d.ntemp, I);
-            if (rc) return rc;
-        } else if (rt->d.nspecies == 0) {
-            ProfScope ps(rt, "opac_interpol");
-            rc = hx_opac_interpol(ctx, T_lay, rt->ktemp, p_lay, rt->kpress, rt->opac_k, opl,
-                                  rt->opac_scat_cross, scl, rt->d.npress, rt->d.ntemp, Y, X, L);
-            if (rc) return rc;
-            rc = hx_opac_interpol(ctx, T_int, rt->ktemp, p_int, rt->kpress, rt->opac_k, opi,
-                                  rt->opac_scat_cross, sci, rt->d.npress, rt->d.ntemp, Y, X, I);
-            if (rc) return rc;
-            rc = hx_meanmolmass_interpol(ctx, T_lay, rt->ktemp, mml, rt->opac_meanmass, p_lay, rt->kpress,
-                                         rt->d.npress, rt->d.ntemp, L);
-            if (rc) return rc;
-            rc = hx_meanmolmass_interpol(ctx, T_int, rt->ktemp, mmi, rt->opac_meanmass, p_int, rt->kpress,
-                                         rt->d.npress, rt->d.ntemp, I);
-            if (rc) return rc;
+    if (rt->d.nspecies == 0) {
+        k_rt_tp_index<<<dim3(hx_cdiv(I, 64), C), 64, 0, ctx->stream>>>(a, (TPIndex*)rt->tp_lay, (TPIndex*)rt->tp_int);
+        k_rt_scat_interp<<<dim3(hx_cdiv(X, 256), I, C), 256, 0, ctx->stream>>>(a, rt->scat_cross_lay, rt->scat_cross_int);
+        k_rt_mmm_table<<<dim3(hx_cdiv(I, 64), C), 64, 0, ctx->stream>>>(a, rt->opac_meanmass, rt->mmm_lay, rt->mmm_int);
+        HX_LAUNCH_CHECK(ctx);
+        if (fused_lookup) {
+            // opacities are interpolated inside k_rt_coef; remember the temperatures this refresh used, so that
+            // the arrays can be rebuilt on demand
+            k_rt_keep_ref_T<<<dim3(hx_cdiv(I + 1, 64), C), 64, 0, ctx->stream>>>(a, rt->T_lay_ref, rt->T_int_ref);
         } else {
-            // on-the-fly mixing, computation.py:1454-1501 (tables stay resident on the device; the
-            // reference re-uploads every species table on every refresh)
-            const int S = rt->d.nspecies;
-            const double* vl = rt->vmr_lay + (size_t)c * S * I;
-            const double* vi = rt->vmr_int + (size_t)c * S * I;
-            rc = meanmolmass_from_vmr(rt, c, true);   // host_functions.py:913-959
-            if (rc) return rc;
-            hx_memset0(ctx, opl, wgI * 8);
-            hx_memset0(ctx, opi, wgI * 8);
-            hx_memset0(ctx, scl, bandI * 8);
-            hx_memset0(ctx, sci, bandI * 8);
-            for (int s = 0; s < S; s++) {
-                const Species& sp = rt->species[s];
-                if (sp.absorbing) {
-                    {
-                        ProfScope ps(rt, "opac_species_interpol");
-                        rc = hx_opac_species_interpol(ctx, T_lay, rt->ktemp, p_lay, rt->kpress, sp.pretab,
-                                                      rt->spec_lay, rt->d.npress, rt->d.ntemp, Y, X, L);
-                        if (rc) return rc;
-                        rc = hx_opac_species_interpol(ctx, T_int, rt->ktemp, p_int, rt->kpress, sp.pretab,
-                                                      rt->spec_int, rt->d.npress, rt->d.ntemp, Y, X, I);
-                        if (rc) return rc;
-                    }
-                    ProfScope ps(rt, "add_to_mixed_opac");
-                    const int ro = (rt->f.kcoeff_mixing_ro && !sp.is_cia) ? 1 : 0;  // computation.py:1343
-                    const double mass = sp.weight * HX_AMU;
-                    rc = hx_add_to_mixed_opac(ctx, vl + (size_t)s * I, rt->spec_lay, opl, mml, rt->gauss_w,
-                                              rt->gauss_y, mass, s, ro, Y, X, L);
-                    if (rc) return rc;
-                    rc = hx_add_to_mixed_opac(ctx, vi + (size_t)s * I, rt->spec_int, opi, mmi, rt->gauss_w,
-                                              rt->gauss_y, mass, s, ro, Y, X, I);
-                    if (rc) return rc;
-                }
-                if (sp.scattering) {
-                    ProfScope ps(rt, "mixed_scat");
-                    if (sp.is_h2o) {
-                        const double mass = sp.weight * HX_AMU;
-                        rc = hx_calc_h2o_scat(ctx, T_lay, p_lay, rt->wave, rt->sc_spec_lay, vl + (size_t)s * I,
-                                              mass, X, L);
-                        if (rc) return rc;
-                        rc = hx_calc_h2o_scat(ctx, T_int, p_int, rt->wave, rt->sc_spec_int, vi + (size_t)s * I,
-                                              mass, X, I);
-                        if (rc) return rc;
-                    } else {
-                        // the reference tiles the [nbin] cross-section over the levels on the host
-                        // (read.py:1642-1645) and uploads it; here the broadcast happens on the device
-                        k_rt_tile_rows<<<dim3(hx_cdiv(X, 256), L), 256, 0, ctx->stream>>>(sp.scat_cross,
-                                                                                         rt->sc_spec_lay, X, L);
-                        k_rt_tile_rows<<<dim3(hx_cdiv(X, 256), I), 256, 0, ctx->stream>>>(sp.scat_cross,
-                                                                                         rt->sc_spec_int, X, I);
-                        HX_LAUNCH_CHECK(ctx);
-                    }
-                    rc = hx_add_to_mixed_scat(ctx, vl + (size_t)s * I, rt->sc_spec_lay, scl, X, L);
-                    if (rc) return rc;
-                    rc = hx_add_to_mixed_scat(ctx, vi + (size_t)s * I, rt->sc_spec_int, sci, X, I);
-                    if (rc) return rc;
-                }
-            }
+            ProfScope ps(rt, "opac_interpol");
+            const int chunks = (int)std::min<long long>(hx_cdiv((long long)nc, 256), 1024);
+            k_rt_opac_table<<<dim3(chunks, I, C), 256, 0, ctx->stream>>>(a, rt->opac_wg_lay, rt->opac_wg_int);
         }
-        if (rt->f.clouds) {
-            rc = hx_calc_total_g_0_of_gas_and_clouds(ctx, scl, rt->cl_g0_lay + c * bandI,
-                                                     rt->cl_sc_lay + c * bandI, rt->g0_tot_lay + c * bandI,
-                                                     rt->f.g_0, X, L);
-            if (rc) return rc;
-            rc = hx_calc_total_g_0_of_gas_and_clouds(ctx, sci, rt->cl_g0_int + c * bandI,
-                                                     rt->cl_sc_int + c * bandI, rt->g0_tot_int + c * bandI,
-                                                     rt->f.g_0, X, I);
-            if (rc) return rc;
-        }
-        rc = hx_calc_delta_z(ctx, T_lay, p_int, p_lay, mml, rt->delta_z + (size_t)c * L, rt->cols[c].g, L);
+        HX_LAUNCH_CHECK(ctx);
+    } else {
+        rc = refresh_species(rt);
         if (rc) return rc;
     }
-    k_rt_height<<<rt->C, 64, 0, ctx->stream>>>(rt->p_lay, rt->delta_z, rt->z_lay, L, rt->f.planet_type_gas, (size_t)L);
+    if (rt->f.clouds) {
+        k_rt_total_g0<<<dim3(hx_cdiv(X, 256), I, C), 256, 0, ctx->stream>>>(a, rt->cl_g0_lay, rt->cl_g0_int,
+                                                                          rt->g0_tot_lay, rt->g0_tot_int);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    k_rt_delta_z<<<dim3(hx_cdiv(L, 64), C), 64, 0, ctx->stream>>>(a, rt->delta_z);
+    k_rt_height<<<C, 64, 0, ctx->stream>>>(rt->p_lay, rt->delta_z, rt->z_lay, L, rt->f.planet_type_gas, (size_t)L, rt->done);
     HX_LAUNCH_CHECK(ctx);
     if (rt->has_heating) {   // computation.py:913-918: refreshed with the layer heights, every 10th iteration
-        k_rt_heating<<<rt->C, 64, 0, ctx->stream>>>(rt->add_heat_dens, rt->delta_z, rt->F_add_heat_lay,
-                                                    rt->F_add_heat_sum, L, rt->done);
+        k_rt_heating<<<C, 64, 0, ctx->stream>>>(rt->add_heat_dens, rt->delta_z, rt->F_add_heat_lay,
+                                                rt->F_add_heat_sum, L, rt->done);
         HX_LAUNCH_CHECK(ctx);
     }
     if (rt->f.dir_beam) {
         ProfScope ps(rt, "direct_beam");
-        k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, rt->C), 256, 0, ctx->stream>>>(a);
+        k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
-        for (int c = 0; c < rt->C; c++) {
-            if (done[c]) continue;
-            const hx_rt_column& cp = rt->cols[c];
-            rc = hx_internal_fdir_noniso(ctx, rt->F_dir_wg + c * wgI, rt->Fc_dir_wg + c * wgI,
-                                         rt->Bstar + (size_t)c * X, 1, rt->dtau_u + c * nc * L,
-                                         rt->dtau_l + c * nc * L, rt->z_lay + (size_t)c * L, cp.mu_star,
-                                         cp.R_planet, cp.R_star, cp.a, rt->f.dir_beam,
-                                         rt->f.geom_zenith_corr, I, X, Y);
-            if (rc) return rc;
-            k_rt_fdir_band<<<dim3(hx_cdiv(X, 256), I), 256, 0, ctx->stream>>>(
-                rt->F_dir_wg + c * wgI, rt->F_dir_band_n + c * bandI, rt->gauss_w, X, Y, I);
-            HX_LAUNCH_CHECK(ctx);
-        }
+        rc = hx_internal_fdir_noniso_batch(ctx, rt->F_dir_wg, rt->Fc_dir_wg, rt->Bstar, rt->dtau_u, rt->dtau_l,
+                                           rt->z_lay, rt->colpar, rt->done, C, rt->f.dir_beam,
+                                           rt->f.geom_zenith_corr, I, X, Y);
+        if (rc) return rc;
+        k_rt_fdir_band<<<dim3(hx_cdiv(X, 256), I, C), 256, 0, ctx->stream>>>(rt->F_dir_wg, rt->F_dir_band_n,
+                                                                           rt->gauss_w, X, Y, I, rt->done);
+        HX_LAUNCH_CHECK(ctx);
     }
     {
         ProfScope ps(rt, "rt_coef");
@@ -932,14 +885,20 @@ int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
     hx_context* ctx = rt->ctx;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables, HX_E_STATE, "hx_rt_conv_adjust before the tables are set");
     if (itervalue % 10 == 0) {   // computation.py:1030-1036: mu of the profile BEFORE the adjustment
-        for (int c = 0; c < rt->C; c++) {
-            int rc = rt->d.nspecies == 0
-                         ? hx_meanmolmass_interpol(ctx, rt->T_lay + (size_t)c * (rt->L + 1), rt->ktemp,
-                                                   rt->mmm_lay + (size_t)c * rt->I, rt->opac_meanmass,
-                                                   rt->p_lay + (size_t)c * rt->L, rt->kpress, rt->d.npress,
-                                                   rt->d.ntemp, rt->L)
-                         : meanmolmass_from_vmr(rt, c, false);
+        if (rt->d.nspecies == 0) {
+            for (int c = 0; c < rt->C; c++) {
+                int rc = hx_meanmolmass_interpol(ctx, rt->T_lay + (size_t)c * (rt->L + 1), rt->ktemp,
+                                                 rt->mmm_lay + (size_t)c * rt->I, rt->opac_meanmass,
+                                                 rt->p_lay + (size_t)c * rt->L, rt->kpress, rt->d.npress,
+                                                 rt->d.ntemp, rt->L);
+                if (rc) return rc;
+            }
+        } else {
+            int rc = upload_species_table(rt);
             if (rc) return rc;
+            k_rt_mmm_from_vmr<<<dim3(hx_cdiv(rt->L, 64), rt->C), 64, 0, ctx->stream>>>(
+                (const SpeciesDev*)rt->species_dev, rt->d.nspecies, rt->vmr_lay, rt->mmm_lay, rt->L, rt->I);
+            HX_LAUNCH_CHECK(ctx);
         }
     }
     if (rt->entr_kappa) {   // computation.py:1037: kappa and c_p of the profile before the adjustment

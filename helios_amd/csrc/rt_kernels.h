@@ -873,10 +873,10 @@ __global__ void k_rt_heating(const double* __restrict__ dens, const double* __re
 
 // altitude of the layer centres from the layer thicknesses (host_functions.py:673-698), one thread
 __global__ void k_rt_height(const double* __restrict__ p_lay, const double* __restrict__ dz,
-                            double* __restrict__ z, int L, int gas, size_t stride) {
+                            double* __restrict__ z, int L, int gas, size_t stride, const int* __restrict__ done) {
     const int col = blockIdx.x;
     p_lay += col * stride; dz += col * stride; z += col * stride;
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0 || done[col]) return;
     if (gas) {
         int i0 = 0;
         for (int i = 0; i < L; i++) if (p_lay[i] >= 1e7) i0 = i;
@@ -904,13 +904,15 @@ __global__ void k_rt_meanmolmass(const double* __restrict__ vmr, const double* _
     out[i] = num / tot * HX_AMU;
 }
 
-// F_dir_band_n[x][i] = sum_y w_y/2 F_dir_wg[y + Y x + Y X i]
+// F_dir_band_n[x][i] = sum_y w_y/2 F_dir_wg[y + Y x + Y X i]; grid (chunks of x, I, C)
 __global__ void __launch_bounds__(256) k_rt_fdir_band(const double* __restrict__ F_dir_wg,
                                                       double* __restrict__ out,
                                                       const double* __restrict__ gauss_w, int X, int Y,
-                                                      int I) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
-    if (x >= X) return;
+                                                      int I, const int* __restrict__ done) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, col = blockIdx.z;
+    if (x >= X || done[col]) return;
+    F_dir_wg += (size_t)col * Y * X * I;
+    out += (size_t)col * X * I;
     double s = 0.0;
     for (int y = 0; y < Y; y++) s += 0.5 * gauss_w[y] * F_dir_wg[(size_t)y + (size_t)Y * x + (size_t)Y * X * i];
     out[(size_t)x * I + i] = s;
@@ -942,6 +944,69 @@ __global__ void __launch_bounds__(256) k_rt_scat_interp(KArgs a, double* scat_la
         (pass == 0 ? scat_lay : scat_int)[col * bandI + x + (size_t)a.X * lev] =
             blend_tp(t0[cp * k.pdown], t0[cp * k.pup], t1[cp * k.pdown], t1[cp * k.pup], k, false);
     }
+}
+
+// ---- per refresh, all columns at once (a column whose loop has ended is skipped on the device) -------------------
+// mean molecular mass of a premixed table at every level (meanmolmass_interpol, kernels.cu:649-699) from the table
+// indices k_rt_tp_index left behind
+__global__ void k_rt_mmm_table(KArgs a, const double* __restrict__ table, double* mmm_lay, double* mmm_int) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.I || a.done[col]) return;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 0 && i >= a.L) continue;
+        const TPIndex k = (pass == 0 ? a.tp_lay : a.tp_int)[(size_t)col * a.I + i];
+        (pass == 0 ? mmm_lay : mmm_int)[(size_t)col * a.I + i] =
+            blend_tp(table[k.pdown + a.npress * k.tdown], table[k.pup + a.npress * k.tdown],
+                     table[k.pdown + a.npress * k.tup], table[k.pup + a.npress * k.tup], k, false);
+    }
+}
+
+// premixed k-table look-up into opac_wg_lay / opac_wg_int (opac_interpol, kernels.cu:524-610); grid (chunks, I, C)
+__global__ void __launch_bounds__(256) k_rt_opac_table(KArgs a, double* opac_lay, double* opac_int) {
+    const int col = blockIdx.z, lev = blockIdx.y;
+    if (a.done[col]) return;
+    const size_t nc = (size_t)a.Y * a.X, sp = nc, st = nc * a.npress, wgI = nc * a.I;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 0 && lev >= a.L) continue;
+        const TPIndex k = (pass == 0 ? a.tp_lay : a.tp_int)[(size_t)col * a.I + lev];
+        double* out = (pass == 0 ? opac_lay : opac_int) + col * wgI + nc * lev;
+        for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < nc; c += (size_t)gridDim.x * blockDim.x)
+            out[c] = blend_tp(a.ktable[c + sp * k.pdown + st * k.tdown], a.ktable[c + sp * k.pup + st * k.tdown],
+                              a.ktable[c + sp * k.pdown + st * k.tup], a.ktable[c + sp * k.pup + st * k.tup], k, false);
+    }
+}
+
+// layer heights (calc_delta_z, kernels.cu:1247-1261)
+__global__ void k_rt_delta_z(KArgs a, double* __restrict__ dz) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.L || a.done[col]) return;
+    const double* pint = a.p_int + (size_t)col * a.I;
+    dz[(size_t)col * a.L + i] = HX_KBOLTZMANN * a.T_lay[(size_t)col * (a.L + 1) + i] /
+                                (a.mmm_lay[(size_t)col * a.I + i] * a.colpar[col].g) * log(pint[i] / pint[i + 1]);
+}
+
+// asymmetry parameter of gas + clouds at the layer centres and interfaces (calc_total_g_0_of_gas_and_clouds, :472-492)
+__global__ void __launch_bounds__(256) k_rt_total_g0(KArgs a, const double* __restrict__ g_cl_lay,
+                                                     const double* __restrict__ g_cl_int, double* g_tot_lay,
+                                                     double* g_tot_int) {
+    const int col = blockIdx.z, lev = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.X || a.done[col]) return;
+    const size_t k = (size_t)col * a.X * a.I + x + (size_t)a.X * lev;
+    if (lev < a.L) {
+        const double num = a.g_0 * a.scat_cross_lay[k] + g_cl_lay[k] * a.cl_sc_lay[k];
+        g_tot_lay[k] = num / (a.scat_cross_lay[k] + a.cl_sc_lay[k]);
+    }
+    const double num = a.g_0 * a.scat_cross_int[k] + g_cl_int[k] * a.cl_sc_int[k];
+    g_tot_int[k] = num / (a.scat_cross_int[k] + a.cl_sc_int[k]);
+}
+
+// remember the temperatures a refresh used (opacities are rebuilt from them on demand)
+__global__ void k_rt_keep_ref_T(KArgs a, double* T_lay_ref, double* T_int_ref) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a.done[col]) return;  // a finished column keeps the state of its last real refresh
+    if (i <= a.L) T_lay_ref[(size_t)col * (a.L + 1) + i] = a.T_lay[(size_t)col * (a.L + 1) + i];
+    if (i < a.I) T_int_ref[(size_t)col * a.I + i] = a.T_int[(size_t)col * a.I + i];
 }
 
 // broadcast a scalar-per-bin cross-section to all levels: out[x + X*i] = src[x]

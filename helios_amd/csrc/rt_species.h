@@ -1,0 +1,173 @@
+// On-the-fly opacity mixing of the fused refresh: the species loop of
+// calculate_total_opacity_and_scat_cross_sections_from_species (computation.py:1454-1501) and the host steps around it
+// (host_functions.py:874-959, :1050-1056) as THREE launches for all columns, levels and species of a batch.
+//
+//   k_rt_species_prep   per (column, level): mean molecular mass from the mixing ratios, fractional (T, log10 P)
+//                       table indices with the species clamp [0, n-1] (kernels.cu:3233, :3238), and the factor
+//                       vmr * mass / mu of every absorber (:3293)
+//   k_rt_mix_species    per (column, level, bin) -- one wavefront at a time: the running k-distribution stays in 20 lanes'
+//                       registers while the absorbers are folded in one after the other (correlated-k for the first
+//                       species and for CIA pairs, random overlap via ro::mix otherwise).  Each absorber's 20 coefficients
+//                       are interpolated from the four table corners as they are needed (opac_species_interpol, :3209-3259:
+//                       the reference writes them to a 161 MB array per species and reads them back); the next absorber's
+//                       corners are in flight while the present one is mixed.  opac_wg_lay / opac_wg_int are written once.
+//   k_rt_scat_species   per (column, level, bin): sum of vmr * sigma over the scattering species (add_to_mixed_scat,
+//                       :3444-3459; water vapour through calc_h2o_scat, :3404-3440)
+//
+// Columns whose loop has ended (done[c]) are skipped on the device: no host round trip inside a refresh.
+#pragma once
+#include "random_overlap.h"
+#include "two_stream.h"
+
+namespace hx {
+
+struct SpeciesDev {
+    const double* pretab;      // [t][p][x][y] flat (reference order) or null
+    const double* scat_cross;  // [x] or null
+    double weight;             // molar weight
+    int absorbing, scattering, is_h2o, ro, in_mu, pad;
+};
+
+struct MixArgs {
+    int X, Y, L, I, C, S, ntemp, npress, nabs;
+    const SpeciesDev* sp;  // [S]
+    const int* abs_list;   // [nabs] indices of the absorbing species, ascending
+    const double *T_lay, *T_int, *p_lay, *p_int;  // column strides L+1, I, L, I
+    const double *vmr_lay, *vmr_int;              // [C][S][I]
+    const double *ktemp, *kpress, *gauss_w, *gauss_y, *wave;
+    double *mmm_lay, *mmm_int;          // [C][I]
+    TPIndex *tp_lay, *tp_int;           // [C][I]
+    double *fac_lay, *fac_int;          // [C][I][S]
+    double *opac_wg_lay, *opac_wg_int;  // [C][Y X I]
+    double *scat_lay, *scat_int;        // [C][X I]
+    const int* done;
+    unsigned long long* diag;
+};
+
+__global__ void k_rt_species_prep(MixArgs a) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.I || a.done[col]) return;
+    for (int pass = 0; pass < 2; pass++) {
+        const bool lay = pass == 0;
+        if (lay && i >= a.L) continue;
+        const double* vmr = (lay ? a.vmr_lay : a.vmr_int) + (size_t)col * a.S * a.I;
+        double num = 0.0, tot = 0.0;  // host_functions.py:927-959
+        for (int s = 0; s < a.S; s++)
+            if (a.sp[s].in_mu) {
+                num += vmr[(size_t)s * a.I + i] * a.sp[s].weight;
+                tot += vmr[(size_t)s * a.I + i];
+            }
+        const double mmm = num / tot * HX_AMU;
+        (lay ? a.mmm_lay : a.mmm_int)[(size_t)col * a.I + i] = mmm;
+        const double T = lay ? a.T_lay[(size_t)col * (a.L + 1) + i] : a.T_int[(size_t)col * a.I + i];
+        const double P = lay ? a.p_lay[(size_t)col * a.L + i] : a.p_int[(size_t)col * a.I + i];
+        (lay ? a.tp_lay : a.tp_int)[(size_t)col * a.I + i] = locate_tp(T, P, a.ktemp, a.ntemp, a.kpress, a.npress, false, false);
+        double* fac = (lay ? a.fac_lay : a.fac_int) + ((size_t)col * a.I + i) * a.S;
+        for (int s = 0; s < a.S; s++) {
+            const double mass = a.sp[s].weight * HX_AMU;
+            fac[s] = vmr[(size_t)s * a.I + i] * mass / mmm;  // (vmr * mass) / mu, then times kappa (:3293)
+        }
+    }
+}
+
+// mean molecular mass of the layers only (the convection loop refreshes it ahead of the adjustment, computation.py:1030-1036)
+__global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, const double* __restrict__ vmr_lay,
+                                  double* __restrict__ mmm_lay, int L, int I) {
+    const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const double* vmr = vmr_lay + (size_t)col * S * I;
+    double num = 0.0, tot = 0.0;
+    for (int s = 0; s < S; s++)
+        if (sp[s].in_mu) {
+            num += vmr[(size_t)s * I + i] * sp[s].weight;
+            tot += vmr[(size_t)s * I + i];
+        }
+    mmm_lay[(size_t)col * I + i] = num / tot * HX_AMU;
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_rt_mix_species(MixArgs a) {
+    __shared__ ro::Shared sh;
+    const int lane = threadIdx.x;
+    ro::Lane ln;
+    ro::init(sh, ln, lane, a.gauss_w, a.gauss_y);
+    ro::Counters cnt;
+    const long long nlev = a.L + a.I, per_col = nlev * a.X, npair = per_col * a.C;
+    const long long chunk = (npair + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * chunk, p1 = min(npair, p0 + chunk);
+    const size_t nc = (size_t)a.Y * a.X, st_p = nc, st_t = nc * a.npress;
+    long long lev_cur = -1;
+    TPIndex tp = {};
+    const double* fac = nullptr;
+    double* out_level = nullptr;
+    size_t pl_dd = 0, pl_ud = 0, pl_du = 0, pl_uu = 0;  // table planes of the level's four (T, P) corners: wave-uniform
+    bool skip = false;
+    for (long long pair = p0; pair < p1; pair++) {
+        const long long cl = pair / a.X;  // column * nlev + level
+        const int x = (int)(pair - cl * a.X);
+        if (cl != lev_cur) {  // wave-uniform: a new level (or column)
+            lev_cur = cl;
+            const int col = (int)(cl / nlev), lev = (int)(cl - (long long)col * nlev);
+            const bool lay = lev < a.L;
+            const int i = lay ? lev : lev - a.L;
+            skip = a.done[col] != 0;
+            tp = (lay ? a.tp_lay : a.tp_int)[(size_t)col * a.I + i];
+            fac = (lay ? a.fac_lay : a.fac_int) + ((size_t)col * a.I + i) * a.S;
+            out_level = (lay ? a.opac_wg_lay : a.opac_wg_int) + (size_t)col * nc * a.I + nc * i;
+            pl_dd = st_p * tp.pdown + st_t * tp.tdown;
+            pl_ud = st_p * tp.pup + st_t * tp.tdown;
+            pl_du = st_p * tp.pdown + st_t * tp.tup;
+            pl_uu = st_p * tp.pup + st_t * tp.tup;
+        }
+        if (skip) continue;
+        // Three groups of 20 lanes fetch three absorbers at a time: lane 20 g + y holds Gauss point y of absorber
+        // kb + g.  The next triple's table corners are requested before the present triple is mixed, so that even a run
+        // of negligible absorbers (a few dozen instructions each) does not wait for memory.
+        const int grp = lane / ro::NY, y = lane - grp * ro::NY;
+        const bool loader = grp < 3 && y < a.Y;
+        const unsigned off = (unsigned)(a.Y * x + y);  // inside a table plane: the same for all corners of all species
+        double c_dd = 0.0, c_ud = 0.0, c_du = 0.0, c_uu = 0.0;
+        if (loader && grp < a.nabs) {
+            const double* tab = a.sp[a.abs_list[grp]].pretab;
+            c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];
+        }
+        double mixv = 0.0;  // nullify_opac_scat_arrays (host_functions.py:1050-1056)
+        for (int kb = 0; kb < a.nabs; kb += 3) {
+            const double raw_mine = blend_tp(c_dd, c_ud, c_du, c_uu, tp, true);
+            if (loader && kb + 3 + grp < a.nabs) {
+                const double* tab = a.sp[a.abs_list[kb + 3 + grp]].pretab;
+                c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];
+            }
+            for (int j = 0; j < 3 && kb + j < a.nabs; j++) {
+                const int s = a.abs_list[kb + j];
+                const double raw = ro::shfl((ro::NY * j + y) << 2, raw_mine);  // lanes 0..19: from group j
+                const double add = fac[s] * raw;
+                if (s == 0 || a.sp[s].ro == 0) mixv += add;  // correlated-k (:3302-3310)
+                else mixv = ro::mix(sh, ln, lane, mixv, add, cnt);
+            }
+        }
+        if (lane < a.Y) out_level[off] = mixv;
+    }
+    ro::flush(cnt, lane, a.diag);
+}
+
+__global__ void __launch_bounds__(256) k_rt_scat_species(MixArgs a) {
+    const int col = blockIdx.z, lev = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.X || a.done[col]) return;
+    const bool lay = lev < a.L;
+    const int i = lay ? lev : lev - a.L;
+    const double* vmr = (lay ? a.vmr_lay : a.vmr_int) + (size_t)col * a.S * a.I;
+    const double T = lay ? a.T_lay[(size_t)col * (a.L + 1) + i] : a.T_int[(size_t)col * a.I + i];
+    const double P = lay ? a.p_lay[(size_t)col * a.L + i] : a.p_int[(size_t)col * a.I + i];
+    double sum = 0.0;
+    for (int s = 0; s < a.S; s++) {
+        if (!a.sp[s].scattering) continue;
+        const double f = vmr[(size_t)s * a.I + i];
+        const double sigma = a.sp[s].is_h2o ? h2o_rayleigh_cross(T, P, f, a.wave[x], a.sp[s].weight * HX_AMU)
+                                            : a.sp[s].scat_cross[x];
+        sum += f * sigma;
+    }
+    (lay ? a.scat_lay : a.scat_int)[(size_t)col * a.X * a.I + x + (size_t)a.X * i] = sum;
+}
+
+}  // namespace hx

@@ -123,6 +123,13 @@ __global__ void k_calc_delta_z(const double* __restrict__ tlay, const double* __
     if (i < nlayer) dz[i] = HX_KBOLTZMANN * tlay[i] / (mmm[i] * g) * log(pint[i] / pint[i + 1]);
 }
 
+// a batch of columns in one launch (the fused refresh): column blockIdx.z, per-column scalars from colpar, columns whose
+// loop has ended skipped; colpar == nullptr: the single column of the per-stage entry points
+struct BeamBatch {
+    const hx_rt_column* colpar;
+    const int* done;
+};
+
 __device__ __forceinline__ double slant_mu(double mu_star, double R_planet, const double* z_lay,
                                            int i, int j) {
     const double q = (R_planet + z_lay[i]) / (R_planet + z_lay[j]);
@@ -138,10 +145,18 @@ __global__ void __launch_bounds__(256)
 k_fdir_plane(double* __restrict__ F_dir, double* __restrict__ Fc_dir,
              const double* __restrict__ star, int star_stride, const double* __restrict__ dtau_u,
              const double* __restrict__ dtau_l, double mu_star, double R_star, double a, int dir_beam,
-             int ninterface, int nbin, int ny) {
+             int ninterface, int nbin, int ny, BeamBatch bb) {
     const size_t nc = (size_t)ny * nbin;
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nc) return;
+    if (bb.colpar) {  // column blockIdx.z of a batch: its own star, orbit and arrays
+        const int col = blockIdx.z;
+        if (bb.done[col]) return;
+        mu_star = bb.colpar[col].mu_star; R_star = bb.colpar[col].R_star; a = bb.colpar[col].a;
+        F_dir += col * nc * ninterface; Fc_dir += col * nc * ninterface;
+        dtau_u += col * nc * (ninterface - 1); dtau_l += col * nc * (ninterface - 1);
+        star += (size_t)col * nbin * star_stride;
+    }
     const int x = (int)(c / ny);
     const double I_dir = ((R_star / a) * (R_star / a)) * HX_PI * star[(size_t)x * star_stride];
     double F = -dir_beam * mu_star * I_dir;
@@ -164,11 +179,22 @@ __global__ void __launch_bounds__(256)
 k_fdir_sphere(double* __restrict__ F_dir, double* __restrict__ Fc_dir,
               const double* __restrict__ star, int star_stride, const double* __restrict__ dtau_u,
               const double* __restrict__ dtau_l, const double* __restrict__ z_lay, double mu_star,
-              double R_planet, double R_star, double a, int dir_beam, int ninterface, int nbin, int ny) {
+              double R_planet, double R_star, double a, int dir_beam, int ninterface, int nbin, int ny,
+              BeamBatch bb) {
     const size_t nc = (size_t)ny * nbin;
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (c >= nc) return;
+    if (bb.colpar) {
+        const int col = blockIdx.z;
+        if (bb.done[col]) return;
+        mu_star = bb.colpar[col].mu_star; R_star = bb.colpar[col].R_star; a = bb.colpar[col].a;
+        R_planet = bb.colpar[col].R_planet;
+        F_dir += col * nc * ninterface; Fc_dir += col * nc * ninterface;
+        dtau_u += col * nc * (ninterface - 1); dtau_l += col * nc * (ninterface - 1);
+        star += (size_t)col * nbin * star_stride;
+        z_lay += (size_t)col * (ninterface - 1);
+    }
     const int x = (int)(c / ny);
     const double I_dir = ((R_star / a) * (R_star / a)) * HX_PI * star[(size_t)x * star_stride];
     double F = -dir_beam * mu_star * I_dir;
@@ -271,11 +297,11 @@ int hx_fdir_iso(hx_context* ctx, double* F_dir_wg, const double* planckband_lay,
     if (geom_zenith_corr == 1)
         k_fdir_sphere<false><<<dim3(nb, ninterface), 256, 0, ctx->stream>>>(
             F_dir_wg, nullptr, star, ninterface + 1, delta_tau_wg, nullptr, z_lay, mu_star, R_planet,
-            R_star, a, dir_beam, ninterface, nbin, ny);
+            R_star, a, dir_beam, ninterface, nbin, ny, BeamBatch{nullptr, nullptr});
     else
         k_fdir_plane<false><<<nb, 256, 0, ctx->stream>>>(F_dir_wg, nullptr, star, ninterface + 1,
                                                         delta_tau_wg, nullptr, mu_star, R_star, a,
-                                                        dir_beam, ninterface, nbin, ny);
+                                                        dir_beam, ninterface, nbin, ny, BeamBatch{nullptr, nullptr});
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -290,12 +316,33 @@ int hx_internal_fdir_noniso(hx_context* ctx, double* F_dir_wg, double* Fc_dir_wg
     if (geom_zenith_corr == 1)
         k_fdir_sphere<true><<<dim3(nb, ninterface), 256, 0, ctx->stream>>>(
             F_dir_wg, Fc_dir_wg, star, star_stride, delta_tau_wg_upper, delta_tau_wg_lower, z_lay,
-            mu_star, R_planet, R_star, a, dir_beam, ninterface, nbin, ny);
+            mu_star, R_planet, R_star, a, dir_beam, ninterface, nbin, ny, BeamBatch{nullptr, nullptr});
     else
         k_fdir_plane<true><<<nb, 256, 0, ctx->stream>>>(F_dir_wg, Fc_dir_wg, star, star_stride,
                                                        delta_tau_wg_upper, delta_tau_wg_lower,
                                                        mu_star, R_star, a, dir_beam, ninterface,
-                                                       nbin, ny);
+                                                       nbin, ny, BeamBatch{nullptr, nullptr});
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// internal: every column of a fused batch in one launch.  Arrays are column-major with the strides of hx_rt
+// (F_dir / Fc_dir: ny*nbin*ninterface, dtau: ny*nbin*nlayer, star: nbin, z_lay: nlayer); mu_star, R_planet, R_star
+// and a come from colpar[col]; columns with done[col] != 0 are skipped.
+int hx_internal_fdir_noniso_batch(hx_context* ctx, double* F_dir_wg, double* Fc_dir_wg, const double* star,
+                                  const double* delta_tau_wg_upper, const double* delta_tau_wg_lower,
+                                  const double* z_lay, const hx_rt_column* colpar, const int* done, int ncol,
+                                  int dir_beam, int geom_zenith_corr, int ninterface, int nbin, int ny) {
+    const int nb = hx_cdiv((long long)ny * nbin, 256);
+    const BeamBatch bb{colpar, done};
+    if (geom_zenith_corr == 1)
+        k_fdir_sphere<true><<<dim3(nb, ninterface, ncol), 256, 0, ctx->stream>>>(
+            F_dir_wg, Fc_dir_wg, star, 1, delta_tau_wg_upper, delta_tau_wg_lower, z_lay, 0.0, 0.0, 0.0, 0.0,
+            dir_beam, ninterface, nbin, ny, bb);
+    else
+        k_fdir_plane<true><<<dim3(nb, 1, ncol), 256, 0, ctx->stream>>>(
+            F_dir_wg, Fc_dir_wg, star, 1, delta_tau_wg_upper, delta_tau_wg_lower, 0.0, 0.0, 0.0, dir_beam,
+            ninterface, nbin, ny, bb);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

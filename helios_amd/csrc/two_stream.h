@@ -123,4 +123,33 @@ __device__ __forceinline__ double planck_lookup(const double* planck_grid, doubl
     return planck_grid[x + (size_t)tdown * nbin];
 }
 
+
+// Rayleigh scattering cross-section of water vapour per molecule (calc_index_h2o + calc_h2o_scat,
+// kernels.cu:3174-3205, :3404-3440): refractive index of water at the vapour's density, Lorentz-Lorenz
+// factor and King correction; zero beyond 2.5 micron.
+__device__ __forceinline__ double h2o_rayleigh_cross(double T, double P, double f, double lam_cm, double mass_h2o) {
+    const double dens = f * P * mass_h2o / (HX_KBOLTZMANN * T);
+    const double lamda = lam_cm / 0.589e-4;
+    const double delta = dmin(1.0, dens) / 1.0;
+    const double theta = T / 273.15;
+    const double lamda_UV = 0.229202, lamda_IR = 5.432937;
+    const double a0 = 0.244257733, a1 = 0.974634476e-2, a2 = -0.373234996e-2, a3 = 0.268678472e-3,
+                 a4 = 0.158920570e-2, a5 = 0.245934259e-2, a6 = 0.900704920, a7 = -0.166626219e-1;
+    const double l2 = lamda * lamda;
+    const double A = delta * (a0 + a1 * delta + a2 * theta + a3 * l2 * theta + a4 / l2 +
+                              a5 / (l2 - lamda_UV * lamda_UV) + a6 / (l2 - lamda_IR * lamda_IR) +
+                              a7 * (delta * delta));
+    const double index = sqrt((2.0 * A + 1.0) / (1.0 - A));
+    const double n_ref = f * P / (HX_KBOLTZMANN * T);
+    const double King = (6.0 + 3.0 * 3e-4) / (6.0 - 7.0 * 3e-4);
+    double sc = 0.0;
+    if (lam_cm < 2.5e-4) {
+        const double n2 = index * index;
+        const double lor = (n2 - 1.0) / (n2 + 2.0);
+        const double lam2 = lam_cm * lam_cm;
+        sc = 24.0 * (HX_PI * HX_PI * HX_PI) / ((n_ref * n_ref) * (lam2 * lam2)) * (lor * lor) * King;
+    }
+    return sc;
+}
+
 }  // namespace hx
