@@ -9,9 +9,14 @@ isotropic scattering, fp64), synthetic tables per SURVEY.md section 8(d).
 One "step" = one pass of the radiation_loop body (reference source/computation.py:851-984): interface
 temperatures, Planck interpolation, every-10th-iteration opacity/transmission refresh, 3*scat+1
 two-stream sweeps, flux integration, temperature step -- all through libhelios_hip.so (hx_rt_step).
-Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, columns sharded
-(weak scaling: one column per GPU), no collective on the iteration path; the output spectra are
-gathered over RCCL once after the timed region.
+Inputs are resident in HBM before the timed region.
+
+N = 1 (default): BASELINE config 2, the configuration the metric is quoted on.  N > 1 (default): BASELINE
+config 4 -- the 512-column parameter sweep (8 x 8 x 8 over gravity, orbital distance and internal temperature,
+SURVEY.md 8(d)) with on-the-fly mixing of 20 species -- as each GPU's share of the 8-GPU run: 64 columns per
+GPU in one batch (weak scaling: the per-GPU work is fixed; 512 columns at N = 8).  One process per GPU, columns
+sharded, no collective on the iteration path; the output spectra are gathered over RCCL once after the timed
+region.  `--workload` / `--columns-per-gpu` override the defaults.
 """
 import argparse
 import json
@@ -35,6 +40,11 @@ WORKLOADS = {
     "c5": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, clouds=2, albedo=0.1, scat_corr=1,
                desc="BASELINE config 5 shape, one column: 30 000 bins x 200 layers, non-iso scattering (I2S "
                     "correction), two cloud decks, surface albedo; premixed table (the mixing cost is config 3's)"),
+    "c4": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=64, sweep=True,
+               desc="BASELINE config 4, one GPU's share of the 512-column sweep at 8 GPUs: 64 columns per GPU (g x a x "
+                    "T_intern grid), on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
+    "c4small": dict(nbin=500, nlayer=40, ny=20, ntemp=8, npress=6, nspecies=5, columns_per_gpu=6, sweep=True,
+                    desc="config 4 shape at 500 bins x 40 layers x 5 species, 6 columns per GPU (quick check)"),
     "c3small": dict(nbin=1000, nlayer=100, ny=20, ntemp=12, npress=10, nspecies=20,
                     desc="config 3 shape at 1000 bins (quick check)"),
 }
@@ -100,10 +110,23 @@ def build_case(w, seed):
     return c
 
 
-def make_batch(ctx, c, ncol):
+def sweep_column(c, gi):
+    """column `gi` of the 8 x 8 x 8 sweep of SURVEY.md 8(d): g in logspace(2.5, 3.5), a in logspace(-2, -0.5) AU,
+    T_intern in linspace(50, 400); everything else as in the single-column case"""
+    from helios_amd import phys_const as pc
+    i, j, k = (gi // 64) % 8, (gi // 8) % 8, gi % 8
+    g = float(np.logspace(2.5, 3.5, 8)[i])
+    a = float(np.logspace(-2.0, -0.5, 8)[j]) * pc.AU
+    T_intern = float(np.linspace(50.0, 400.0, 8)[k])
+    T_eff = c.f_factor ** 0.25 * (c.R_star / a) ** 0.5 * c.T_star
+    return dict(g=g, a=a, F_intern=pc.SIGMA_SB * T_intern ** 4, T_start=max(T_eff, 500.0))
+
+
+def make_batch(ctx, c, ncol, first_column=0, sweep=False):
     from helios_amd.rt import batch_from_case
     sp = c.species
-    rt = batch_from_case(ctx, c, ncol=ncol, nspecies=len(sp) if sp else 0)
+    cols = [sweep_column(c, first_column + i) for i in range(ncol)] if sweep else None
+    rt = batch_from_case(ctx, c, ncol=ncol, nspecies=len(sp) if sp else 0, columns=cols)
     if sp:
         from helios_amd import synthetic as syn
         for k, s_ in enumerate(sp):
@@ -115,17 +138,40 @@ def make_batch(ctx, c, ncol):
         vl = np.array([np.full(c.nlayer, s_["vmr"]) for s_ in sp])
         vi = np.array([np.full(c.nlayer + 1, s_["vmr"]) for s_ in sp])
         rt.set_column_vmr(-1, vl, vi)
+    if cols:
+        for i, cp in enumerate(cols):      # pressure grid and start profile follow the column's gravity / orbit
+            rt.set_column_profile(i, c.p_lay, c.p_int, np.full(c.nlayer + 1, cp["T_start"]), c.surf_albedo, c.starflux)
     return rt
 
 
+def native_oracle():
+    """the CPU oracle compiled on THIS host with -O3 -march=native; the prebuilt -O2 library
+    (which travels from the build container, whose CPU differs) if no compiler is at hand"""
+    import subprocess
+    import tempfile
+    import oracle
+    src = os.path.join(ROOT, "oracle", "helios_oracle.c")
+    out = os.path.join(tempfile.gettempdir(), "libhelios_oracle_native_%d.so" % os.getuid())
+    try:
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+                        "-o", out, src, "-lm"], check=True, capture_output=True, timeout=120)
+        with open(os.path.join(ROOT, "oracle", "helios_oracle.h")) as f:
+            return oracle._CLib(out, f.read(), "orc_"), "-O3 -march=native"
+    except Exception:
+        return oracle.port, "-O2 (prebuilt)"
+
+
 def cpu_baseline(w, seed):
-    """the CPU oracle (oracle/helios_oracle.c, OpenMP over bins) on a bounded sample of the same
-    workload: the first `nb` bins, 20-60 iterations from iteration 0 (one opacity refresh per 10), sized
-    for roughly 10-30 s; the thread count is the fastest of a short probe."""
+    """the CPU oracle (oracle/helios_oracle.c, OpenMP over bins) on a bounded sample of the same workload, from
+    iteration 0 (one opacity refresh per 10 iterations).  Premixed: ALL bins, 30 iterations.  On-the-fly mixing
+    (the reference's bubble sort of 400 sums per point and species): 4000 of the bins, 20 iterations, i.e. two
+    refreshes.  Thread count fixed at min(usable cores, 64)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
-    import oracle
-    nb = min(w["nbin"], 5000)
+    lib, flags = native_oracle()
+    species = bool(w.get("nspecies"))
+    nb = min(w["nbin"], 4000 if species else w["nbin"])
+    n_it = 20 if species else 30
     ws = dict(w)
     ws["nbin"] = nb
     c = build_case(ws, seed)
@@ -134,56 +180,62 @@ def cpu_baseline(w, seed):
     cc.T_int = np.zeros(c.nlayer + 1)
     for k in ("F_add_heat_lay", "F_add_heat_sum", "F_smooth", "F_smooth_sum"):
         cc[k] = np.zeros(c.nlayer)
-    for nm, n in (("lay", c.nlayer), ("int", c.nlayer + 1)):
-        for p in ("abs_cross_all_clouds_", "scat_cross_all_clouds_", "g_0_all_clouds_"):
-            cc[p + nm] = np.zeros(n * nb)
+    if not c.clouds:
+        for nm, n in (("lay", c.nlayer), ("int", c.nlayer + 1)):
+            for p in ("abs_cross_all_clouds_", "scat_cross_all_clouds_", "g_0_all_clouds_"):
+                cc[p + nm] = np.zeros(n * nb)
     cc.delta_colmass = (c.p_int[:-1] - c.p_int[1:]) / c.g
     cc.delta_col_upper = (c.p_lay - c.p_int[1:]) / c.g
     cc.delta_col_lower = (c.p_int[:-1] - c.p_lay) / c.g
     # a coarse Planck table keeps the (untimed) set-up short; the timed part does not depend on it
     cc.plancktable_dim, cc.plancktable_step = 800, 20
-    s = cases.alloc_state(cc)
+    refresh = cases.refresh_premixed
+    if species:
+        from helios_amd import synthetic as syn
+        sp = []
+        for k, s_ in enumerate(c.species):
+            tab = s_["pretab"]
+            if isinstance(tab, str):
+                tab = syn.ktable(np.random.default_rng(s_["table_seed"]), nb, c.ny, c.ktemp, c.kpress, c.gauss_y)
+            sp.append(dict(name="S%02d" % k, absorbing=tab is not None, scattering=s_["scat"] is not None,
+                           is_h2o=False, is_cia=False, weight=s_["weight"], vmr=s_["vmr"], pretab=tab,
+                           scat=s_["scat"]))
+        cc.species = sp
+        refresh = cases.refresh_onthefly
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    oracle.port.set_num_threads(min(ncpu, 32))
-    cases.setup_planck(oracle.port, cc, s)
-    # the visible core count can exceed what the container may actually use (CPU quota): time one
-    # flux sweep at a few thread counts and keep the fastest
-    cases.interpolate_temperatures_and_planck(oracle.port, cc, s)
-    cases.refresh_premixed(oracle.port, cc, s)
-    best = (1e30, 1)
-    for th in sorted(set(t for t in (4, 8, 16, 32, 64, 128, ncpu) if t <= ncpu)):
-        oracle.port.set_num_threads(th)
-        cases.flux_sweeps(oracle.port, cc, s, 1)
-        t1 = time.perf_counter()
-        cases.flux_sweeps(oracle.port, cc, s, 2)
-        el = time.perf_counter() - t1
-        if el < best[0]:
-            best = (el, th)
-    threads = best[1]
-    oracle.port.set_num_threads(threads)
-    # size the timed run for roughly 10-30 s of CPU work: one flux sweep took best[0]/2 s on nb bins
-    per_iter = 2.2 * best[0]                         # 4 sweeps + refresh share + the rest
-    n_it = int(min(60, max(20, 10 * round(15.0 / max(per_iter, 1e-3) / 10))))
+    threads = max(1, min(ncpu, 64))
+    lib.set_num_threads(threads)
     s = cases.alloc_state(cc)
-    cc.T_lay = c.T_lay.copy()
-    cases.setup_planck(oracle.port, cc, s)
+    cases.setup_planck(lib, cc, s)
     t0 = time.perf_counter()
-    cases.radiation_iterations(oracle.port, cc, s, n_it)
+    cases.radiation_iterations(lib, cc, s, n_it, refresh=refresh)
     dt = time.perf_counter() - t0
     return dict(value=n_it / dt * nb * c.nlayer, unit="bin*layer*iterations/s", cores=threads, kind="port",
-                sample="%d of %d bins x %d layers x %d Gauss points, %d iterations from iteration 0 "
-                       "(one opacity refresh per 10), oracle/helios_oracle.c with OpenMP over bins (%d of %d visible "
-                       "cores: fastest of a thread-count probe), %.1f s"
-                       % (nb, w["nbin"], c.nlayer, c.ny, n_it, threads, ncpu, dt))
+                sample="%d of %d bins x %d layers x %d Gauss points%s, %d iterations from iteration 0 (one opacity "
+                       "refresh per 10), oracle/helios_oracle.c built %s with OpenMP over bins on %d threads (%d usable "
+                       "cores), %.1f s"
+                       % (nb, w["nbin"], c.nlayer, c.ny, ", %d species" % len(c.species) if species else "", n_it,
+                          flags, threads, ncpu, dt))
+
+
+def load_counters(workload):
+    """per-launch counter figures measured with rocprofv3 --pmc in separate passes and committed under profiles/
+    (the bench itself runs without the profiler): (dict, source file) or (None, None)"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as f:
+        d = json.load(f).get(workload)
+    return (d, "profiles/traffic.json") if d else (None, None)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--columns-per-gpu", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--columns-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--phase", default="radiative", choices=["radiative", "convection"],
@@ -196,6 +248,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    # N = 1: the configuration the metric is quoted on (config 2); N > 1: the sharded parameter sweep (config 4)
+    wname = args.workload or ("c2" if world == 1 else "c4")
+    w = WORKLOADS[wname]
+    heavy = bool(w.get("nspecies")) and w["nbin"] >= 5000
+    steps = args.steps if args.steps is not None else (20 if heavy else 200)
+    warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
+    ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
 
     import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
     dist = None
@@ -213,16 +272,14 @@ def main():
             dist.init_process_group(backend)
 
     from helios_amd.device import Context
-    from helios_amd.rt import batch_from_case
 
-    w = WORKLOADS[args.workload]
     seed = 20240 + 2
     c = build_case(w, seed)
     ctx = Context(device_index)
-    ncol = args.columns_per_gpu
-    rt = make_batch(ctx, c, ncol)
-    # every column of a sweep differs (here: internal temperature -> different T-P trajectories)
-    if ncol > 1 or world > 1:
+    sweep = bool(w.get("sweep"))
+    rt = make_batch(ctx, c, ncol, first_column=rank * ncol, sweep=sweep)
+    # every column of a batch differs: the sweep's own parameters, or a few per cent in the start profile
+    if not sweep and (ncol > 1 or world > 1):
         for i in range(ncol):
             gi = rank * ncol + i
             rt.set_temperatures(i, c.T_lay * (1.0 + 0.01 * gi))
@@ -250,54 +307,83 @@ def main():
             rt.set_state(-1, name, v)
         run = rt.conv_run
     # warm-up: W untimed steps starting at iteration 0 (includes the first refresh)
-    run(0, args.warmup)
+    run(0, warmup)
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    run(args.warmup, args.steps)
+    run(warmup, steps)
     ev_ms = ctx.timer_stop_ms()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    rank_ms = [dt_local / steps * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt_local], dtype=torch.float64, device=coll_device)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) / steps * 1e3 for x in allt]
+        dt = max(float(x.item()) for x in allt)
 
     done = [int(rt.get("done", i)[0]) for i in range(ncol)]
 
-    # per-kernel timing of the dominant kernel: a separate short pass with HIP events on the stream
+    # per-kernel timing with HIP events on the library's stream, in separate short passes after the timed region:
+    # E-only iterations (no refresh) and one refresh on its own
     roofline = None
-    rt_prof = {}
     tm = rt.traffic_model()
+    counters, counter_source = load_counters(wname)
     if args.profile_steps > 0:
-        it0 = args.warmup + args.steps
+        it0 = warmup + steps
         it0 += (-it0) % 10 + 1                      # start right after a refresh boundary
-        run(args.warmup + args.steps, it0 - (args.warmup + args.steps))
+        run(warmup + steps, it0 - (warmup + steps))
         ctx.synchronize()
+        ctx.timer_start()
+        run(it0, 9)                                 # nine iterations without a refresh
+        e_only_ms = ctx.timer_stop_ms() / 9.0
         rt.profile(True)
-        run(it0, min(args.profile_steps, 9))     # E-iterations only
+        run(it0 + 9, 1)                             # iteration index = 0 mod 10: refresh + iteration
+        run(it0 + 10, min(args.profile_steps, 9))   # E-iterations under the event profiler
         rt.profile(False)
         flux_ms, nflux = rt.profile_read("rt_flux")
-        if c.species:   # one refresh under the profiler: where the on-the-fly mixing time goes
-            rt.profile(True)
-            rt.refresh()
-            rt.profile(False)
-        rt_prof = {k: rt.profile_read(k)[0] for k in ("refresh_total", "add_to_mixed_opac",
-                                                      "opac_species_interpol", "mixed_scat", "rt_coef")}
-        if nflux:
-            achieved = tm["step_algorithmic"] / (flux_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get(args.workload, {}).get("rt_flux_hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic *= ncol                 # measured with one column per launch; a launch covers all columns
+        prof = {k: rt.profile_read(k)[0] for k in ("refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
+                                                   "opac_interpol", "direct_beam", "rt_nodes", "rt_totals_a",
+                                                   "rt_totals_b")}
+        t_only_ms = prof["refresh_total"]
+        B_E, B_T = tm["step_algorithmic"], tm["refresh_algorithmic"]      # bytes per launch, all columns
+        B = B_E + B_T / 10.0
+        mix_bound = bool(c.species) and prof["add_to_mixed_opac"] > 5.0 * flux_ms
+        if nflux and not mix_bound:
+            achieved = B_E / (flux_ms * 1e-3) / 1e9
+            traffic = counters.get("rt_flux_hbm_bytes_per_launch") if counters else None
+            if traffic is not None:
+                traffic *= ncol                     # measured with one column per launch
             roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
-                            frac=achieved / 8000.0, traffic=traffic,
-                            algorithmic_bytes_per_launch=tm["step_algorithmic"],
-                            actual_bytes_model_per_launch=tm["step_actual"], avg_launch_ms=flux_ms,
-                            launches_timed=nflux)
+                            frac=achieved / 8000.0, traffic=traffic, traffic_source=counter_source if traffic else None,
+                            algorithmic_bytes_per_launch=B_E, actual_bytes_model_per_launch=tm["step_actual"],
+                            avg_launch_ms=flux_ms, launches_timed=nflux)
+        elif mix_bound:
+            # on-the-fly mixing: the refresh's species kernel is where the time goes.  Against HBM: B_T per launch;
+            # against vector issue (what actually binds it): instructions per launch from the committed PMC run
+            mix_ms = prof["add_to_mixed_opac"]
+            achieved = B_T / (mix_ms * 1e-3) / 1e9
+            traffic = counters.get("rt_mix_hbm_bytes_per_launch") if counters else None
+            roofline = dict(bound="hbm", kernel="k_rt_mix_species", achieved=achieved, peak=8000.0, unit="GB/s",
+                            frac=achieved / 8000.0, traffic=traffic * ncol if traffic else None,
+                            traffic_source=counter_source if traffic else None,
+                            algorithmic_bytes_per_launch=B_T, avg_launch_ms=mix_ms, launches_timed=1)
+            valu = counters.get("rt_mix_valu_instructions_per_launch") if counters else None
+            if valu:
+                peak = 1024 * 2.4e9 / 4.0           # SIMDs x clock / 4 cycles per wave64 instruction
+                rate = valu * ncol / (mix_ms * 1e-3)
+                roofline["valu_issue"] = dict(achieved=rate / 1e9, peak=peak / 1e9, unit="G wavefront-instructions/s",
+                                              frac=rate / peak, instructions_per_launch=valu * ncol,
+                                              source=counter_source)
+        if roofline is not None:
+            whole = B / (dt / steps) / 1e9          # B * iterations/s over the whole step
+            roofline["whole_step"] = dict(achieved=whole, peak=8000.0, unit="GB/s", frac=whole / 8000.0,
+                                          algorithmic_bytes_per_iteration=B)
+            roofline["e_only_ms_per_iteration"] = e_only_ms
+            roofline["t_only_ms_per_refresh"] = t_only_ms
+            roofline["kernels_ms"] = {k: v for k, v in prof.items() if v}
 
     # the path's only exchange: gather the emission spectra of all columns once, after the run
     gather_ms = None
@@ -312,32 +398,33 @@ def main():
         spec = torch.cat(out).cpu().numpy()
 
     total_cols = ncol * world
-    value = args.steps / dt * c.nbin * c.nlayer * total_cols
+    value = steps / dt * c.nbin * c.nlayer * total_cols
     line = {
         "metric": "rad-conv iterations/sec x (lambda-bins x layers)",
-        "value": value, "unit": "bin*layer*iterations/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "value": value, "unit": "bin*layer*iterations/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["desc"], "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
+                   "species": len(c.species) if c.species else 0,
                    "opacity_table_TP_grid": [c.ntemp, c.npress], "columns_per_gpu": ncol,
                    "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 4, "loop": args.phase,
                    "parallelism": "columns sharded, %d per GPU" % ncol},
-        "iterations_per_s_per_column": args.steps / dt,
-        "stream_event_ms_per_step": ev_ms / args.steps,
+        "iterations_per_s_per_column": steps / dt,
+        "stream_event_ms_per_step": ev_ms / steps,
+        "per_rank_ms_per_step": rank_ms,
+        "rank_imbalance": (max(rank_ms) - min(rank_ms)) / max(rank_ms),
         "columns_converged_during_run": int(sum(done)),
         "spectra_gather_ms": gather_ms,
         "spectrum_checksum": float(np.sum(spec)),
         "roofline": roofline,
     }
-    if roofline is not None and c.species:
-        roofline["refresh_kernels_ms"] = {k: rt_prof[k] for k in rt_prof}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not c.species:
+    rt.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, seed)
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(line))
-    rt.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1274,7 +1274,9 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
 int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* refresh_alg,
                         double* refresh_act) {
     // algorithmic bytes per iteration and column
-    const double X = rt->X, Y = rt->Y, L = rt->L, S = rt->d.nspecies;
+    const double X = rt->X, Y = rt->Y, L = rt->L;
+    double S = 0;  // absorbers: the species that bring a k-table
+    for (const Species& sp : rt->species) S += sp.absorbing ? 1.0 : 0.0;
     const double cl = rt->f.clouds ? 3.0 * (2 * L + 1) : 0.0;
     const double BE = 8.0 * X * (3.0 * Y * (2 * L + 1) + (2 * L + 1) + 2.0 * (2 * L + 3) + 3.0 * (L + 1) + cl);
     const double BT = 8.0 * Y * X * (2 * L + 1) * (S > 0 ? 4.0 * S + 1.0 : 5.0);
@@ -1286,7 +1288,7 @@ int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* r
                           + 8.0 * X * 2.0 * (L + 1) * 2.0                          // band arrays w + r
                           + 8.0 * X * Y * 2.0;                                     // U0
     const double premixed = 8.0 * Y * X * (2 * L + 1) * 5.0;
-    const double species = 8.0 * Y * X * (2 * L + 1) * S * (4.0 + 1.0 + 1.0 + 2.0);  // corners + spec w/r + mix r/w
+    const double species = 8.0 * Y * X * (2 * L + 1) * (4.0 * S + 1.0);  // table corners of every absorber + one write
     const double coef_k = tiles * g.nplane + 8.0 * Y * X * (2 * L + 1);
     if (step_alg) *step_alg = BE * rt->C;
     if (step_act) *step_act = flux_k * rt->C;

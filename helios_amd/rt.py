@@ -234,9 +234,10 @@ class RTBatch(object):
             self.handle = None
 
 
-def batch_from_case(ctx, c, ncol=1, nspecies=0):
+def batch_from_case(ctx, c, ncol=1, nspecies=0, columns=None):
     """build an RTBatch from a dict-like problem description that uses the reference's Store attribute
-    names (tests/cases.py, helios_amd.quantities.Store): every column gets the same inputs."""
+    names (tests/cases.py, helios_amd.quantities.Store): every column gets the same inputs, except for the
+    per-column parameters given in `columns` (a list of ncol dicts overriding g, a, F_intern, ...)."""
     flags = dict(scat=int(c.scat), dir_beam=int(c.dir_beam), clouds=int(c.clouds),
                  scat_corr=int(c.scat_corr), geom_zenith_corr=int(c.geom_zenith_corr),
                  smooth=int(c.smooth), real_star=int(c.real_star), planet_type_gas=1,
@@ -248,8 +249,11 @@ def batch_from_case(ctx, c, ncol=1, nspecies=0):
                F_intern=float(c.F_intern), rad_convergence_limit=float(c.rad_convergence_limit),
                physical_tstep=float(c.physical_tstep), adapt_interval=int(c.adapt_interval),
                foreplay=int(c.foreplay), no_atmo=int(c.no_atmo))
+    cols = [col] * ncol
+    if columns is not None:
+        cols = [dict(col, **{k: v for k, v in cp.items() if k in col}) for cp in columns]
     rt = RTBatch(ctx, c.nbin, c.ny, c.nlayer, ncol, c.ntemp, c.npress, c.plancktable_dim,
-                 c.plancktable_step, flags, [col] * ncol, nspecies=nspecies)
+                 c.plancktable_step, flags, cols, nspecies=nspecies)
     rt.set_grid(c.opac_interwave, c.opac_deltawave, c.opac_wave, c.gauss_y, c.gauss_weight, c.ktemp, c.kpress)
     if nspecies == 0:
         rt.set_premixed_tables(c.opac_k, c.opac_scat_cross, c.opac_meanmass)

@@ -45,3 +45,34 @@ def test_bench_two_ranks_share_the_columns():
     line = _last_json(p.stdout)
     assert line["n_gpus"] == 2 and line["config"]["columns_total"] == 2 and line["value"] > 0
     assert line["cpu_baseline"] is None and line["spectra_gather_ms"] is not None
+
+
+def test_bench_species_workload_carries_roofline_and_cpu_baseline():
+    """on-the-fly mixing (config 3 shape, reduced): the line names the mixing kernel, prices it against HBM and has a
+    CPU baseline too"""
+    p = subprocess.run([sys.executable, "bench.py", "--workload", "c3small", "--steps", "20", "--warmup", "10"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    r = line["roofline"]
+    assert r["kernel"] == "k_rt_mix_species" and r["bound"] == "hbm" and r["whole_step"]["frac"] > 0
+    assert r["t_only_ms_per_refresh"] > r["e_only_ms_per_iteration"] > 0
+    assert line["config"]["species"] == 22
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and "species" in cb["sample"]
+
+
+def test_bench_multi_rank_default_is_the_sharded_sweep():
+    """N > 1 without --workload: config 4 (columns of the parameter sweep sharded over the ranks); here the reduced
+    shape, two ranks on one GPU through the gloo hook"""
+    env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29519", "bench.py", "--gpus", "2", "--steps",
+                        "10", "--warmup", "10", "--workload", "c4small"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["columns_total"] == 12 and line["config"]["species"] == 7
+    assert len(line["per_rank_ms_per_step"]) == 2 and 0 <= line["rank_imbalance"] < 1
+    import bench
+    assert bench.WORKLOADS["c4"]["columns_per_gpu"] * 8 == 512
