@@ -1,0 +1,225 @@
+"""BASELINE.json's configurations at FULL size on the GPU, held to the CPU oracle where the domain allows it: spectral
+bins are independent up to the sums over wavelength, so the oracle runs blocks of contiguous bins cut out of the
+full-size column (same tables, same Planck table, same profile) and the HIP results of exactly those bins are
+compared -- opacities of every Gauss point and level after the mixing, Rayleigh cross-sections, band fluxes of the
+first flux solve (before the temperature step, which needs all bins) -- plus invariants over all bins.
+
+  config 3   20 absorbers + H2/He, random overlap, 10 000 bins x 100 layers, one column
+  config 4   8 columns of the parameter sweep with on-the-fly mixing in ONE batch == 8 single-column runs
+  config 5   30 000 bins x 200 layers, two cloud decks, g0, I2S correction, surface albedo, direct beam, and the
+             convection loop on top (radiative quantities against the oracle, the loop through invariants)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from helios_amd.device import Context
+    return Context(0)
+
+
+def _blocks(nbin, nb=16):
+    return [0, (nbin // 3) // nb * nb, (2 * nbin // 3) // nb * nb, nbin - nb], nb
+
+
+def _slice_table(tab, c, x0, nb):
+    """[t][p][x][y] flat -> the same layout for bins x0 .. x0+nb"""
+    t = np.asarray(tab).reshape(c.ntemp, c.npress, c.nbin, c.ny)
+    return np.ascontiguousarray(t[:, :, x0:x0 + nb, :]).reshape(-1)
+
+
+def _block_case(c, x0, nb, species_slices=None):
+    """the sub-problem of bins [x0, x0 + nb) as a tests/cases.py Case"""
+    b = cases.Case(c)
+    b.nbin = nb
+    b.opac_interwave = np.ascontiguousarray(c.opac_interwave[x0:x0 + nb + 1])
+    for k in ("opac_wave", "opac_deltawave", "surf_albedo", "starflux"):
+        b[k] = np.ascontiguousarray(np.asarray(c[k])[x0:x0 + nb])
+    b.opac_k = _slice_table(c.opac_k, c, x0, nb)
+    b.opac_scat_cross = np.ascontiguousarray(
+        np.asarray(c.opac_scat_cross).reshape(c.ntemp, c.npress, c.nbin)[:, :, x0:x0 + nb]).reshape(-1)
+    for nm, n in (("lay", c.nlayer), ("int", c.nlayer + 1)):
+        for p in ("abs_cross_all_clouds_", "scat_cross_all_clouds_", "g_0_all_clouds_"):
+            if c.clouds:
+                b[p + nm] = np.ascontiguousarray(np.asarray(c[p + nm]).reshape(n, c.nbin)[:, x0:x0 + nb]).reshape(-1)
+            else:
+                b[p + nm] = np.zeros(n * nb)
+    b.z_lay = np.zeros(c.nlayer)
+    b.T_int = np.zeros(c.nlayer + 1)
+    b.T_lay = np.asarray(c.T_lay, float).copy()
+    for k in ("F_add_heat_lay", "F_add_heat_sum", "F_smooth", "F_smooth_sum"):
+        b[k] = np.zeros(c.nlayer)
+    b.delta_colmass = (c.p_int[:-1] - c.p_int[1:]) / c.g
+    b.delta_col_upper = (c.p_lay - c.p_int[1:]) / c.g
+    b.delta_col_lower = (c.p_int[:-1] - c.p_lay) / c.g
+    if species_slices is not None:
+        b.species = [dict(sp, pretab=sl[x0], scat=None if sp["scat"] is None else np.ascontiguousarray(sp["scat"][x0:x0 + nb]))
+                     for sp, sl in species_slices]
+    return b
+
+
+def _oracle_block(port, b, planck_grid_dev, c, x0, nb, refresh):
+    s = cases.alloc_state(b)
+    s.planck_grid[:] = np.asarray(planck_grid_dev).reshape(c.plancktable_dim + 1, c.nbin)[:, x0:x0 + nb].reshape(-1)
+    cases.radiation_iterations(port, b, s, 1, refresh=refresh)
+    return s
+
+
+def _compare_block(got, s, c, x0, nb, keys_wg, keys_band, rtol=1e-9):
+    """`got`: full-size arrays in the reference layouts"""
+    Y, X, L, I = c.ny, c.nbin, c.nlayer, c.nlayer + 1
+    for k in keys_wg:
+        nlev = L if k.endswith("_lay") or k.startswith("Fc_") else I
+        a = np.asarray(got[k])[:nlev * X * Y].reshape(nlev, X, Y)[:, x0:x0 + nb, :]
+        w = np.asarray(s[k])[:nlev * nb * Y].reshape(nlev, nb, Y)
+        # fluxes with the beam: G-weighted terms of O(G F_dir) cancel down to the diffuse flux inside the reference's
+        # formula (kernels.cu:1652-1656), leaving ~1e-15 max(F) of absolute noise per half-layer; 2.4e-13 max(F) seen
+        # after 400 half-layers
+        atol = (1e-12 if k.startswith(("F_", "Fc_")) else 1e-13) * np.abs(w).max()
+        np.testing.assert_allclose(a, w, rtol=rtol, atol=atol, err_msg="%s bins %d.." % (k, x0))
+    for k in keys_band:
+        nlev = L if k.endswith("_lay") else I
+        a = np.asarray(got[k])[:nlev * X].reshape(nlev, X)[:, x0:x0 + nb]
+        w = np.asarray(s[k])[:nlev * nb].reshape(nlev, nb)
+        atol = (1e-12 if k.startswith("F_") else 1e-13) * np.abs(w).max()
+        np.testing.assert_allclose(a, w, rtol=rtol, atol=atol, err_msg="%s bins %d.." % (k, x0))
+
+
+def _upload_species(rt, c, xs, nb):
+    """upload every species table, keep the sampled bins of each for the oracle"""
+    from helios_amd import synthetic as syn
+    slices = []
+    for k, sp in enumerate(c.species):
+        tab = sp["pretab"]
+        if isinstance(tab, str):
+            tab = syn.ktable(np.random.default_rng(sp["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+        rt.set_species(k, tab, sp["scat"], sp["weight"], is_h2o=0, is_cia=0, in_mu=1)
+        sl = {x0: (_slice_table(tab, c, x0, nb) if tab is not None else None) for x0 in xs}
+        slices.append((dict(name="S%02d" % k, absorbing=tab is not None, scattering=sp["scat"] is not None, is_h2o=False,
+                            is_cia=False, weight=sp["weight"], vmr=sp["vmr"], pretab=None, scat=sp["scat"]), sl))
+        del tab
+    vl = np.array([np.full(c.nlayer, sp["vmr"]) for sp in c.species])
+    vi = np.array([np.full(c.nlayer + 1, sp["vmr"]) for sp in c.species])
+    rt.set_column_vmr(-1, vl, vi)
+    return slices
+
+
+def test_config3_full_size_sampled_bins_vs_oracle(ctx, port):
+    """20 species at 10 000 x 100: mixed opacities, scattering and the first flux solve of 64 bins against the oracle;
+    k-distributions stay ascending and fluxes non-negative everywhere"""
+    import bench
+    from helios_amd.rt import batch_from_case
+    c = bench.build_case(bench.WORKLOADS["c3"], 20242)
+    c.T_lay = 900.0 + 600.0 * (np.log10(np.append(c.p_lay, c.p_lay[0])) + 1.0) / 10.0   # a profile with structure
+    xs, nb = _blocks(c.nbin)
+    rt = batch_from_case(ctx, c, ncol=1, nspecies=len(c.species))
+    try:
+        slices = _upload_species(rt, c, xs, nb)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        got = {k: rt.get(k) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int", "F_up_band",
+                                      "F_down_band", "F_up_wg")}
+        grid = rt.get("planck_grid")
+        dg = ctx.diag()
+    finally:
+        rt.close()
+    for x0 in xs:
+        b = _block_case(c, x0, nb, slices)
+        s = _oracle_block(port, b, grid, c, x0, nb, cases.refresh_onthefly)
+        _compare_block(got, s, c, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg"),
+                       ("scat_cross_lay", "scat_cross_int", "F_up_band", "F_down_band"))
+    Y, X, L = c.ny, c.nbin, c.nlayer
+    for k, nlev in (("opac_wg_lay", L), ("opac_wg_int", L + 1)):
+        a = got[k][:nlev * X * Y].reshape(nlev, X, Y)
+        assert np.all(np.isfinite(a)) and a.min() > 0
+        assert np.all(np.diff(a, axis=2) >= 0), "%s: a mixed k-distribution is not ascending" % k
+    assert got["F_up_band"].min() >= 0 and got["F_down_band"].min() >= 0
+    assert dg["ro_rebin_skipped"] == 0
+
+
+def test_config4_batch_of_sweep_columns_equals_single_runs(ctx):
+    """8 columns of the parameter sweep (different gravity, orbit, internal flux, start profile) with on-the-fly mixing
+    of 20 species in one batch against 8 single-column runs: 12 iterations, two refreshes"""
+    import bench
+    w = dict(bench.WORKLOADS["c4"], nbin=1000, ntemp=10, npress=8)
+    c = bench.build_case(w, 20242)
+    picks = [0, 7, 63, 64, 200, 321, 448, 511]          # corners and interior of the 8 x 8 x 8 grid
+
+    def run(columns):
+        from helios_amd.rt import batch_from_case
+        cols = [bench.sweep_column(c, gi) for gi in columns]
+        rt = batch_from_case(ctx, c, ncol=len(cols), nspecies=len(c.species), columns=cols)
+        try:
+            _upload_species(rt, c, [], 1)
+            for i, cp in enumerate(cols):
+                rt.set_column_profile(i, c.p_lay, c.p_int, np.full(c.nlayer + 1, cp["T_start"]), c.surf_albedo, c.starflux)
+            rt.build_planck_table(1)
+            rt.run(0, 12)
+            return [{k: rt.get(k, i) for k in ("T_lay", "F_up_band", "F_net", "opac_wg_int", "meanmolmass_lay")}
+                    for i in range(len(cols))]
+        finally:
+            rt.close()
+    batch = run(picks)
+    assert np.abs(batch[0]["T_lay"] - batch[-1]["T_lay"]).max() > 1.0        # the columns really differ
+    for i, gi in enumerate(picks):
+        single = run([gi])[0]
+        for k in single:
+            np.testing.assert_allclose(batch[i][k], single[k], rtol=1e-12, atol=0, err_msg="column %d: %s" % (gi, k))
+
+
+def test_config5_full_size_clouds_beam_i2s_albedo_and_convection(ctx, port):
+    """30 000 bins x 200 layers, two cloud decks, g0, I2S correction, surface albedo, direct beam: the first refresh and
+    flux solve of 64 bins against the oracle; then the convection loop (adjustment + sweeps + temperature step on the
+    device) runs on the same batch"""
+    import bench
+    from helios_amd import phys_const as pc
+    from helios_amd.rt import batch_from_case
+    c = bench.build_case(bench.WORKLOADS["c5"], 20245)
+    c.dir_beam = 1
+    c.T_lay = 700.0 + 900.0 * (np.log10(np.append(c.p_lay, c.p_lay[0])) + 1.0) / 10.0
+    xs, nb = _blocks(c.nbin)
+    rt = batch_from_case(ctx, c, ncol=1)
+    try:
+        rt.keep_down_fluxes(True)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        got = {k: rt.get(k) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "F_up_band", "F_down_band",
+                                      "F_dir_band", "F_up_wg", "F_down_wg", "g_0_tot_lay", "g_0_tot_int")}
+        grid = rt.get("planck_grid")
+        for x0 in xs:
+            b = _block_case(c, x0, nb)
+            s = _oracle_block(port, b, grid, c, x0, nb, cases.refresh_premixed)
+            _compare_block(got, s, c, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg", "F_down_wg"),
+                           ("scat_cross_lay", "g_0_tot_lay", "g_0_tot_int", "F_up_band", "F_down_band", "F_dir_band"))
+        assert got["F_up_band"].min() >= 0 and got["F_dir_band"].min() >= 0 and got["F_dir_band"].max() > 0
+        # the convection loop on this column: a super-adiabatic interior is adjusted, fluxes stay finite, and the run
+        # ends with every convective layer on the adiabat
+        L = c.nlayer
+        kap = 2.0 / 7.0
+        T = np.maximum(2500.0 * (np.asarray(c.p_lay) / c.p_lay[0]) ** 0.4, 600.0)
+        rt.set_temperatures(0, np.append(T, 2600.0))
+        for name, v in (("kappa_lay", np.full(L, kap)), ("kappa_int", np.full(L + 1, kap)),
+                        ("c_p_lay", np.full(L, pc.R_UNIV / kap)), ("conv_layer", np.zeros(L + 1, np.int32)),
+                        ("conv_unstable", np.zeros(L + 1, np.int32)), ("dampara", np.array([-1.0]))):
+            rt.set_state(-1, name, v)
+        rt.conv_run(0, 12)
+        assert np.all(np.isfinite(rt.get("T_lay"))) and np.all(np.isfinite(rt.get("F_up_band")))
+        rt.conv_adjust(12)                       # the adjustment half-step of the next iteration
+        T2, F = rt.get("T_lay"), rt.get("F_net")
+        conv = rt.get("conv_layer")
+        assert np.all(np.isfinite(T2)) and np.all(np.isfinite(F)) and conv.sum() > 5
+        lay = np.where(conv[:L - 1] * conv[1:L] == 1)[0]              # neighbouring convective layers: dry adiabat
+        grad = np.log(T2[lay + 1] / T2[lay]) / np.log(c.p_lay[lay + 1] / c.p_lay[lay])
+        np.testing.assert_allclose(grad, kap, rtol=2e-2)
+    finally:
+        rt.close()
