@@ -22,7 +22,7 @@ _SCALARS = {
 
 _PROTO = re.compile(
     r"(?:^|[;{}\n])\s*(?:extern\s+)?(?:HX_API\s+)?"
-    r"(void|int|int32_t|int64_t|uint64_t|double|const\s+char\s*\*)\s+"
+    r"(void\s*\*|const\s+char\s*\*|void|int|int32_t|int64_t|uint64_t|double)\s*"
     r"([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{}()]*)\)\s*[;{]",
     re.S,
 )
@@ -70,7 +70,12 @@ def parse_prototypes(text, prefix):
                 argtypes.append(_ctype_of(p))
                 argnames.append(re.split(r"[\s*]+", p.strip())[-1])
         ret = ret.replace(" ", "")
-        restype = ctypes.c_char_p if ret.startswith("constchar") else _SCALARS[ret]
+        if ret.startswith("constchar"):
+            restype = ctypes.c_char_p
+        elif ret == "void*":
+            restype = ctypes.c_void_p
+        else:
+            restype = _SCALARS[ret]
         out[name] = (restype, argtypes, argnames)
     return out
 

@@ -406,6 +406,7 @@ int hx_rt_destroy(hx_rt* rt) {
 int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_deltawave,
                    const double* opac_wave, const double* gauss_y, const double* gauss_weight,
                    const double* ktemp, const double* kpress) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int rc = 0;
     rc |= h2d(rt, rt->interwave, opac_interwave, (rt->X + 1) * 8);
     rc |= h2d(rt, rt->deltawave, opac_deltawave, rt->X * 8);
@@ -420,6 +421,7 @@ int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_d
 
 int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opac_scat_cross,
                               const double* opac_meanmass) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     HX_REQUIRE(rt->ctx, rt->d.nspecies == 0, HX_E_STATE, "object was created for on-the-fly mixing");
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
     if (!rt->opac_k) {
@@ -437,6 +439,7 @@ int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opa
 
 int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const double* scat_cross,
                       double weight, int is_h2o, int is_cia, int in_mu) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
     Species& sp = rt->species[s];
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
@@ -469,6 +472,7 @@ static int for_cols(hx_rt* rt, int col, int* c0, int* c1) {
 int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const double* p_int,
                              const double* T_lay, const double* surf_albedo,
                              const double* starflux) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     const size_t L = rt->L, I = rt->I, X = rt->X;
@@ -491,6 +495,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
 }
 
 int hx_rt_set_column_vmr(hx_rt* rt, int col, const double* vmr_lay, const double* vmr_int) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     HX_REQUIRE(rt->ctx, rt->d.nspecies > 0, HX_E_STATE, "no species in a premixed object");
@@ -509,6 +514,7 @@ int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
                             const double* abs_cross_int, const double* scat_cross_lay,
                             const double* scat_cross_int, const double* g_0_lay,
                             const double* g_0_int) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     HX_REQUIRE(rt->ctx, rt->f.clouds == 1, HX_E_STATE, "object was created with clouds = 0");
@@ -526,6 +532,7 @@ int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
 
 int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
                              const double* F_add_heat_sum) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) {
@@ -536,6 +543,7 @@ int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
 }
 
 int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) rc |= h2d(rt, rt->T_lay + (size_t)c * (rt->L + 1), T_lay, (rt->L + 1) * 8);
@@ -543,6 +551,7 @@ int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
 }
 
 int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) {
@@ -554,6 +563,7 @@ int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
 
 
 int hx_rt_build_planck_table(hx_rt* rt, int energy_correction) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     HX_REQUIRE(rt->ctx, rt->have_grid, HX_E_STATE, "hx_rt_set_grid first");
     hx_context* ctx = rt->ctx;
     const int X = rt->X, dim = rt->d.plancktable_dim, step = rt->d.plancktable_step;
@@ -651,6 +661,7 @@ static int refresh_species(hx_rt* rt) {
 }
 
 int hx_rt_refresh(hx_rt* rt) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     hx_context* ctx = rt->ctx;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables && rt->have_planck, HX_E_STATE,
                "set grid, tables and build the Planck table first");
@@ -803,6 +814,7 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
 }
 
 int hx_rt_step(hx_rt* rt, int itervalue, int step_temperature) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     bool nodes_done = false;
     if (itervalue % 10 == 0 || !rt->refreshed) {  // computation.py:860
         int rc = hx_rt_refresh(rt);                // (also evaluates the nodes for this iteration)
@@ -863,8 +875,17 @@ int kappa_cp_from_table(hx_rt* rt, bool refresh_T_int) {
 
 }  // namespace
 
+// kappa and c_p of every column at its current temperatures (what interpolate_kappa_and_cp does for one column,
+// computation.py:199-250); needs hx_rt_set_kappa_table
+int hx_rt_kappa_cp_refresh(hx_rt* rt) {
+    if (!rt) return HX_E_ARG;
+    HX_REQUIRE(rt->ctx, rt->entr_kappa != nullptr, HX_E_STATE, "no kappa / c_p table set");
+    return kappa_cp_from_table(rt, true);
+}
+
 int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, const double* entr_press,
                           int entr_npress, const double* entr_kappa, const double* entr_c_p) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     HX_REQUIRE(rt->ctx, entr_ntemp > 1 && entr_npress > 1 && entr_temp && entr_press && entr_kappa && entr_c_p,
                HX_E_ARG, "hx_rt_set_kappa_table: need a (T, P) grid of at least 2 x 2");
     const size_t n = (size_t)entr_ntemp * entr_npress;
@@ -882,6 +903,7 @@ int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, co
 // first half of one iteration: [every 10th: mean molecular mass at the current temperatures] and the convective
 // adjustment of the temperature profile (computation.py:1027-1047)
 int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     hx_context* ctx = rt->ctx;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables, HX_E_STATE, "hx_rt_conv_adjust before the tables are set");
     if (itervalue % 10 == 0) {   // computation.py:1030-1036: mu of the profile BEFORE the adjustment
@@ -921,6 +943,7 @@ int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
 // two-stream sweeps, totals, convective-layer marking, equilibrium test and -- unless that ends the loop -- the
 // temperature step (computation.py:1048-1145).  A column whose loop has ended is frozen (`done`, `iters_done`).
 int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     hx_context* ctx = rt->ctx;
     bool nodes_done = false;
     if (itervalue % 10 == 0 || !rt->refreshed) {
@@ -981,6 +1004,7 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
 }
 
 int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     for (int n = 0; n < nsteps; n++) {
         int rc = hx_rt_conv_adjust(rt, itervalue + n);
         if (rc) return rc;
@@ -991,6 +1015,7 @@ int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps) {
 }
 
 int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     for (int n = 0; n < nsteps; n++) {
         int rc = hx_rt_step(rt, itervalue + n, 1);
         if (rc) return rc;
@@ -999,6 +1024,7 @@ int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
 }
 
 int hx_rt_converged_layers(hx_rt* rt, int* out_counts) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     return hx_d2h(rt->ctx, out_counts, rt->conv_count, rt->C * sizeof(int));
 }
 
@@ -1087,6 +1113,7 @@ static int materialize_opac(hx_rt* rt) {
 }
 
 int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     HX_REQUIRE(rt->ctx, col >= 0 && col < rt->C, HX_E_ARG, "column index out of range");
     if (strncmp(name, "opac_wg_", 8) == 0) {
         int rc = materialize_opac(rt);
@@ -1181,6 +1208,7 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
 }
 
 int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     const std::string n(name);
     if (n == "keep_down") {
         if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "keep_down expects one int32");
@@ -1239,6 +1267,7 @@ int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t
 }
 
 int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     HX_REQUIRE(rt->ctx, col >= 0 && col < rt->C && out_dptr, HX_E_ARG, "bad arguments");
     const size_t X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, nc = X * Y, c = col;
     const std::string n(name);
@@ -1273,6 +1302,7 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
 
 int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* refresh_alg,
                         double* refresh_act) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     // algorithmic bytes per iteration and column
     const double X = rt->X, Y = rt->Y, L = rt->L;
     double S = 0;  // absorbers: the species that bring a k-table
@@ -1298,12 +1328,14 @@ int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* r
 }
 
 int hx_rt_profile(hx_rt* rt, int enable) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     if (!enable) ProfScope::flush(rt);
     rt->profiling = enable != 0;
     return 0;
 }
 
 int hx_rt_profile_read(hx_rt* rt, const char* kernel, double* out_avg_ms, int* out_count) {
+    if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     ProfScope::flush(rt);
     for (auto& acc : rt->prof_acc)
         if (acc.first == kernel) {

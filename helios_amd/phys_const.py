@@ -4,7 +4,7 @@ Host-side counterpart of the reference's source/phys_const.py:27-44, which takes
 whatever `astropy.constants` version is installed (unpinned -> "parity unpinned" for these eight
 numbers).  The values below are the CODATA-2018 / IAU-2015 figures astropy >= 4.0
 returns; they are recorded in the metadata of every golden fixture.  Device-side constants live in
-helios_amd/csrc/constants.h and follow source/kernels.cu:36-41.
+helios_amd/csrc/hx_common.h and follow source/kernels.cu:36-41.
 """
 
 C = 2.99792458e10                # speed of light, cm / s

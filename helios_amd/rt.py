@@ -157,6 +157,10 @@ class RTBatch(object):
         self._ck(self._l.hx_rt_set_kappa_table(self.handle, _dp(a[0]), len(a[0]), _dp(a[1]), len(a[1]), _dp(a[2]),
                                                _dp(a[3])), "hx_rt_set_kappa_table")
 
+    def kappa_cp_refresh(self):
+        """kappa and c_p of every column from the table at the current temperatures"""
+        self._ck(self._l.hx_rt_kappa_cp_refresh(self.handle), "hx_rt_kappa_cp_refresh")
+
     def conv_adjust(self, itervalue):
         self._ck(self._l.hx_rt_conv_adjust(self.handle, int(itervalue)), "hx_rt_conv_adjust")
 

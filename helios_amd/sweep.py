@@ -73,6 +73,8 @@ def _prepare_column(base_argv, overrides, shared):
     hsfunc.set_up_numerical_parameters(keeper)
     hsfunc.construct_grid(keeper)
     hsfunc.initial_temp(keeper, reader)
+    if keeper.approx_f == 1 and keeper.planet_type == "rocky":      # helios.py:70-71
+        hsfunc.approx_f_from_formula(keeper, reader)
     hsfunc.calc_F_intern(keeper)
     add_heat.load_heating_terms_or_not(keeper)
     reader.cloud.cloud_pre_processing(keeper)
@@ -103,6 +105,7 @@ def _radiation_loop(computer, quants, rt):
         for r in q0.crit_relaxation_numbers:
             if it < r < nxt:
                 nxt = int(r)
+        nxt = min(nxt, it + 1 + (100 - it % 100) % 100)      # the 100-iteration surface-temperature check
         rt.run(it, nxt - it)
         computer.report_diagnostics(quants[0])
         it = nxt
@@ -110,6 +113,14 @@ def _radiation_loop(computer, quants, rt):
             if int(rt.get("done", c)[0]):
                 done[c] = True
                 iters[c] = int(rt.get("iters_done", c)[0])
+        if (it - 1) % 100 == 0:     # computation.py:946-952: a surface hotter than the Planck table ends the radiative loop
+            for c in np.nonzero(~done)[0]:
+                q = quants[c]
+                if not rt.get("T_lay", c)[int(q.nlayer)] < q.plancktable_dim * q.plancktable_step - 2:
+                    q.convection = 1
+                    done[c] = True
+                    iters[c] = it
+                    rt.set_state(int(c), "done", np.ones(1, np.int32))
         if it in q0.crit_relaxation_numbers:
             for c in np.nonzero(~done)[0]:
                 hsfunc.relax_radiative_convergence_criterion(quants[c])
@@ -132,14 +143,21 @@ def _convection_loop(computer, quants, rt):
     ncol = len(quants)
     active = np.zeros(ncol, bool)
     iters = np.zeros(ncol, np.int64)
+    from_table = any(computer._kappa_from_table(q) for q in quants)
+    if from_table:    # kappa / c_p follow the profile the radiation loop left behind (computation.py:1037), as in a single run
+        rt.kappa_cp_refresh()
     for c, q in enumerate(quants):
         if not (q.singlewalk == 0 and q.convection == 1) or getattr(q, "aborted", False):
             continue
         for n in ("T_lay", "F_net", "F_up_tot", "F_down_tot"):
             setattr(q, n, rt.get(n, c))
+        if from_table:
+            for n in ("kappa_lay", "kappa_int", "c_p_lay"):
+                setattr(q, n, rt.get(n, c))
         q.p_lay, q.p_int = np.asarray(q.p_lay, float), np.asarray(q.p_int, float)
         hsfunc.conv_check(q)
         hsfunc.mark_convective_layers(q, stitching=0)
+        q.iter_value = np.int32(0)      # the convection loop counts from zero, also when it has nothing to do
         if sum(q.conv_unstable) > 0:
             active[c] = True
             for name, v, dt in (("kappa_lay", q.kappa_lay, np.float64), ("kappa_int", q.kappa_int, np.float64),
@@ -190,6 +208,8 @@ def _convection_loop(computer, quants, rt):
         q.iter_value = np.int32(iters[c])
         q.conv_layer, q.conv_unstable = rt.get("conv_layer", c), rt.get("conv_unstable", c)
         q.marked_red = rt.get("marked_red", c)
+        for n in ("kappa_lay", "kappa_int", "c_p_lay"):      # what the output files report, as in a single run
+            setattr(q, n, rt.get(n, c))
     return iters
 
 
@@ -234,6 +254,8 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
     from .parallel import gather_spectra, shard_columns
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world > len(overrides_list):
+        raise ValueError("%d ranks for %d columns: a sweep needs at least one column per rank" % (world, len(overrides_list)))
     lo, hi = shard_columns(len(overrides_list), rank, world)
     computer = comp.Compute()
     writer = write_mod.Write()

@@ -383,6 +383,9 @@ int hx_rt_run(hx_rt* rt, int itervalue, int nsteps);
  * them kappa_lay / kappa_int / c_p_lay follow the profile on the device (kappa_interpol, cp_interpol) */
 int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, const double* entr_press,
                           int entr_npress, const double* entr_kappa, const double* entr_c_p);
+/* kappa and c_p of every column at its current temperatures (one column: Compute.interpolate_kappa_and_cp,
+ * computation.py:199-250); the convection loop refreshes them itself every 10th iteration */
+int hx_rt_kappa_cp_refresh(hx_rt* rt);
 int hx_rt_conv_adjust(hx_rt* rt, int itervalue);
 int hx_rt_conv_advance(hx_rt* rt, int itervalue);
 int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps);

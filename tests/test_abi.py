@@ -60,3 +60,33 @@ def test_product_does_not_import_oracle():
                 assert not pat.search(text), os.path.join(d, f)
     text = open(os.path.join(ROOT, "helios.py")).read()
     assert not pat.search(text)
+
+
+def test_every_symbol_of_the_header_is_bound():
+    """every hx_ name that appears as a function in include/helios_hip.h has a parsed prototype (pointer-returning ones
+    included: hx_stream returns void*, which a missing prototype would truncate to a 32-bit int) and is exported"""
+    text = open(_lib.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    names = set(re.findall(r"\b(hx_[a-z0-9_]+)\s*\(", text))
+    protos = _lib.prototypes()
+    assert names and names <= set(protos), sorted(names - set(protos))
+    assert protos["hx_stream"][0] is ctypes.c_void_p
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), n
+
+
+def test_reference_gpu_build_exports_every_launcher():
+    """oracle/_ref/libhelios_ref_gfx950.so (the reference's kernels.cu built by hipcc, the pin): one ref_<kernel> entry
+    per launcher of the host build, same names"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libhelios_ref_gfx950.so")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("built where /root/reference exists")
+    from helios_amd._cproto import parse_prototypes
+    g = parse_prototypes(open(os.path.join(ROOT, "oracle", "ref_driver_gfx950.hip")).read(), "ref_")
+    h = parse_prototypes(open(os.path.join(ROOT, "oracle", "ref_driver.cpp")).read(), "ref_")
+    assert set(g) == set(h) and len(g) >= 34
+    raw = ctypes.CDLL(path)
+    for n in g:
+        assert hasattr(raw, n), n

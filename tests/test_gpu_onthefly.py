@@ -406,3 +406,25 @@ def test_sweep_with_convection_and_two_ranks(tmp_path):
     np.testing.assert_allclose(z["F_up_TOA"], spectra, rtol=1e-12)
     for k in range(3):
         assert os.path.getsize(os.path.join(str(tmp_path), "two", "cvs_%d" % k, "cvs_%d_tp.dat" % k)) > 100
+
+
+def test_sweep_with_kappa_table_equals_single_runs(tmp_path):
+    """`kappa value = file` inside a sweep: kappa and c_p are interpolated at each column's own profile before the
+    convective-stability check (as a single run does), and the output files report them"""
+    import sweep
+    mk = _host_golden_module()
+    path = os.path.join(str(tmp_path), "delad.dat")
+    mk.write_kappa_file(path, False, const_kappa=0.1)
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "20 6 5 11",
+            "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "ks",
+            "-radiative_equilibrium_criterion", "1e-4", "-kappa_value", "file", "-kappa_file_path", path]
+    out = str(tmp_path) + "/"
+    cols, spectra = sweep.main(["-sweep", "internal_temperature=200,1500"] + base + ["-output_directory", out + "b/"])
+    flags = [int(c.conv_layer.sum() > 0) if c.conv_layer is not None else 0 for c in cols]
+    assert flags == [0, 1]                          # the cool column stays radiative: no spurious instability from kappa = 0
+    for k, T_int in enumerate(("200", "1500")):
+        single = _run_driver(base + ["-output_directory", out + "s/", "-name", "k%d" % k, "-internal_temperature", T_int],
+                             True)
+        assert int(cols[k].iter_value) == int(single.iter_value), k
+        np.testing.assert_allclose(cols[k].T_lay, single.T_lay, rtol=1e-12)
+        np.testing.assert_allclose(cols[k].kappa_lay, single.kappa_lay, rtol=1e-12)
