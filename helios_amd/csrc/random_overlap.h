@@ -27,6 +27,10 @@
 #pragma once
 #include "hx_common.h"
 
+#ifndef RO_SWIZZLE_XOR4
+#define RO_SWIZZLE_XOR4 0
+#endif
+
 namespace ro {
 
 constexpr int NY = 20;
@@ -85,8 +89,13 @@ __device__ __forceinline__ unsigned xor_lane(int addr, unsigned x) {
     else if constexpr (M == 7) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror
     else if constexpr (M == 15) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); // row_mirror
     else if constexpr (M == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
-    else if constexpr (M == 4)                                                              // 7 ^ 3
+    else if constexpr (M == 4) {
+        // no single DPP pattern: 7 ^ 3 as two moves.  One ds_swizzle (bit mode: and 0x1f, or 0, xor 4) on the LDS crossbar
+        // instead saves 48 vector instructions per problem but was measured slower on the same box (2.06-2.10 vs
+        // 2.015 ms per 1.01 M problems): the exchange steps wait for the crossbar's latency
+        if (RO_SWIZZLE_XOR4) return __builtin_amdgcn_ds_swizzle(v, 0x101F);
         return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+    }
     else return __builtin_amdgcn_ds_bpermute(addr, v);
 }
 

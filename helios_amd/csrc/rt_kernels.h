@@ -116,8 +116,17 @@ __global__ void __launch_bounds__(256) k_rt_nodes(KArgs a) {
 // of dependent latency per scan step).  Values arriving from outside the spectral point's k-lane group
 // are discarded by the callers' `j` conditions, so no masking is needed here.  Groups wider than a
 // DPP row (k = 32, 64) use __shfl for every distance.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {  // lanes without a source (or outside ROW_MASK) keep their own value
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 template <int N>
 __device__ __forceinline__ double from_lane_below(double v, int k) {  // value of lane (id - N)
+    if (N == 1 && k == 32) return dpp_move<0x138, 0xf>(v);  // wave_shr:1 crosses the row boundary inside the group
     if (N < 16 && k <= 16) {  // wave-uniform: the k-lane group lies inside one DPP row
         int lo = __double2loint(v), hi = __double2hiint(v);
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0x110 + (N & 15), 0xf, 0xf, false);  // row_shr:N
@@ -129,6 +138,7 @@ __device__ __forceinline__ double from_lane_below(double v, int k) {  // value o
 }
 template <int N>
 __device__ __forceinline__ double from_lane_above(double v, int k) {  // value of lane (id + N)
+    if (N == 1 && k == 32) return dpp_move<0x130, 0xf>(v);  // wave_shl:1
     if (N < 16 && k <= 16) {
         int lo = __double2loint(v), hi = __double2hiint(v);
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + (N & 15), 0xf, 0xf, false);  // row_shl:N
@@ -160,6 +170,53 @@ __device__ __forceinline__ void scan_step_up(double& A, double& Bc, int j, int k
         }
     }
 }
+
+// k = 32: the group spans two DPP rows.  Kogge-Stone inside each row (row_shl / row_shr by 1, 2, 4, 8), then the rows are
+// joined: upwards every lane of the upper row composes with the lower row's total, which `row_bcast:15` delivers; downwards
+// the lower row needs the upper row's total, lane 16 of the group, read through the scalar unit.  All in the VALU: with
+// __shfl (LDS crossbar) for every distance this tiling ran 45 % slower than k = 16.
+__device__ __forceinline__ double group_lane16(double v, int lane) {  // value of lane 16 of this lane's 32-lane group
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo_a = __builtin_amdgcn_readlane(lo, 16), lo_b = __builtin_amdgcn_readlane(lo, 48);
+    const int hi_a = __builtin_amdgcn_readlane(hi, 16), hi_b = __builtin_amdgcn_readlane(hi, 48);
+    return __hiloint2double(lane < 32 ? hi_a : hi_b, lane < 32 ? lo_a : lo_b);
+}
+
+#define HX_SCAN32_ROW_STEP(CTRL, COND)                                              \
+    {                                                                               \
+        const double A2 = dpp_move<CTRL, 0xf>(A), B2 = dpp_move<CTRL, 0xf>(Bc);     \
+        if (COND) {                                                                 \
+            Bc = fma(A, B2, Bc);                                                    \
+            A *= A2;                                                                \
+        }                                                                           \
+    }
+
+__device__ __forceinline__ void scan32_down(double& A, double& Bc, int j, int lane) {  // suffix composition over j
+    const int jr = j & 15;
+    HX_SCAN32_ROW_STEP(0x101, jr + 1 < 16)  // row_shl:1
+    HX_SCAN32_ROW_STEP(0x102, jr + 2 < 16)
+    HX_SCAN32_ROW_STEP(0x104, jr + 4 < 16)
+    HX_SCAN32_ROW_STEP(0x108, jr + 8 < 16)
+    const double A2 = group_lane16(A, lane), B2 = group_lane16(Bc, lane);
+    if (j < 16) {
+        Bc = fma(A, B2, Bc);
+        A *= A2;
+    }
+}
+
+__device__ __forceinline__ void scan32_up(double& A, double& Bc, int j) {  // prefix composition over j
+    const int jr = j & 15;
+    HX_SCAN32_ROW_STEP(0x111, jr >= 1)  // row_shr:1
+    HX_SCAN32_ROW_STEP(0x112, jr >= 2)
+    HX_SCAN32_ROW_STEP(0x114, jr >= 4)
+    HX_SCAN32_ROW_STEP(0x118, jr >= 8)
+    const double A2 = dpp_move<0x142, 0xa>(A), B2 = dpp_move<0x142, 0xa>(Bc);  // row_bcast:15 into rows 1 and 3
+    if (j >= 16) {
+        Bc = fma(A, B2, Bc);
+        A *= A2;
+    }
+}
+#undef HX_SCAN32_ROW_STEP
 
 // which spectral point / layer chunk a thread of a flux workgroup works on
 struct LaneMap {
@@ -499,12 +556,16 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     A *= al[r];
                 }
                 // inclusive suffix composition over the k lanes of this spectral point
-                scan_step_down<1>(A, Bc, m.j, k);
-                scan_step_down<2>(A, Bc, m.j, k);
-                scan_step_down<4>(A, Bc, m.j, k);
-                scan_step_down<8>(A, Bc, m.j, k);
-                scan_step_down<16>(A, Bc, m.j, k);
-                scan_step_down<32>(A, Bc, m.j, k);
+                if (k == 32) {
+                    scan32_down(A, Bc, m.j, m.lane);
+                } else {
+                    scan_step_down<1>(A, Bc, m.j, k);
+                    scan_step_down<2>(A, Bc, m.j, k);
+                    scan_step_down<4>(A, Bc, m.j, k);
+                    scan_step_down<8>(A, Bc, m.j, k);
+                    scan_step_down<16>(A, Bc, m.j, k);
+                    scan_step_down<32>(A, Bc, m.j, k);
+                }
                 double Din = from_lane_above<1>(fma(A, D_toa, Bc), k);
                 if (m.j == k - 1) Din = D_toa;
                 double D = Din;
@@ -530,12 +591,16 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     Bc = fma(al[r], Bc, t);
                     A *= al[r];
                 }
-                scan_step_up<1>(A, Bc, m.j, k);
-                scan_step_up<2>(A, Bc, m.j, k);
-                scan_step_up<4>(A, Bc, m.j, k);
-                scan_step_up<8>(A, Bc, m.j, k);
-                scan_step_up<16>(A, Bc, m.j, k);
-                scan_step_up<32>(A, Bc, m.j, k);
+                if (k == 32) {
+                    scan32_up(A, Bc, m.j);
+                } else {
+                    scan_step_up<1>(A, Bc, m.j, k);
+                    scan_step_up<2>(A, Bc, m.j, k);
+                    scan_step_up<4>(A, Bc, m.j, k);
+                    scan_step_up<8>(A, Bc, m.j, k);
+                    scan_step_up<16>(A, Bc, m.j, k);
+                    scan_step_up<32>(A, Bc, m.j, k);
+                }
                 double Uin = from_lane_below<1>(fma(A, Ubc, Bc), k);
                 if (m.j == 0) Uin = Ubc;
                 double U = Uin;
