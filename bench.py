@@ -224,9 +224,11 @@ def load_counters(workload):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, None
+    alias = {"c4": "c3"}      # same kernels on the same column shape: per-column figures scale with the column count
     with open(tpath) as f:
-        d = json.load(f).get(workload)
-    return (d, "profiles/traffic.json") if d else (None, None)
+        d = json.load(f).get(alias.get(workload, workload))
+    src = "profiles/traffic.json" + (" (per column, measured on %s)" % alias[workload] if workload in alias else "")
+    return (d, src) if d else (None, None)
 
 
 def main():

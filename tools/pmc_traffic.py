@@ -24,9 +24,10 @@ def per_kernel(path, counter):
     return {name: (n, avg) for name, n, avg in rows}
 
 
-def main(fetch_db, write_db, workload):
+def main(fetch_db, write_db, workload, valu_db=None):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
+    v = per_kernel(valu_db, "SQ_INSTS_VALU") if valu_db else {}
     out = {}
     for name in sorted(set(f) | set(w)):
         short = name.split("(")[0].replace("void ", "").strip()
@@ -34,10 +35,15 @@ def main(fetch_db, write_db, workload):
         wk = w.get(name, (0, 0.0))[1]
         out[short] = dict(launches=f.get(name, w.get(name))[0], FETCH_SIZE_KiB_raw=fk, WRITE_SIZE_KiB_raw=wk,
                           hbm_bytes_per_launch=2.0 * fk * 1024.0 + wk * 1024.0)
+        if name in v:
+            out[short]["SQ_INSTS_VALU_per_launch"] = v[name][1]      # wavefront instructions, summed over the chip
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     flux = [v for k, v in out.items() if "k_rt_flux" in k]
+    mix = [v_ for k, v_ in out.items() if "k_rt_mix_species" in k]
     data[workload] = dict(rt_flux_hbm_bytes_per_launch=flux[0]["hbm_bytes_per_launch"] if flux else None,
+                          rt_mix_hbm_bytes_per_launch=mix[0]["hbm_bytes_per_launch"] if mix else None,
+                          rt_mix_valu_instructions_per_launch=mix[0].get("SQ_INSTS_VALU_per_launch") if mix else None,
                           correction="hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half)",
                           kernels=out)
     json.dump(data, open(path, "w"), indent=1)
@@ -47,4 +53,4 @@ def main(fetch_db, write_db, workload):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "c2")
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "c2", sys.argv[4] if len(sys.argv) > 4 else None)
