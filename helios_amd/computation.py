@@ -408,15 +408,17 @@ class Compute(object):
             quant.dev_F_add_heat_sum.set(np.asarray(quant.F_add_heat_sum, np.float64))
 
     def _fused_supported(self, quant):
-        return (self.use_fused and quant.iso == 0 and quant.singlewalk == 0
-                and quant.flux_calc_method == "iteration" and _i(quant.nlayer) <= 512)
+        # isothermal layers halve the segments per layer: 1024 of them fit the register-resident sweeps
+        return (self.use_fused and quant.flux_calc_method == "iteration"
+                and _i(quant.nlayer) <= (1024 if quant.iso == 1 else 512))
 
     @staticmethod
     def _rt_flags(q):
         return dict(scat=_i(q.scat), dir_beam=_i(q.dir_beam), clouds=_i(q.clouds), scat_corr=_i(q.scat_corr),
                     geom_zenith_corr=_i(q.geom_zenith_corr), smooth=_i(q.smooth), real_star=_i(q.real_star),
                     planet_type_gas=1 if q.planet_type == "gas" else 0,
-                    kcoeff_mixing_ro=0 if q.kcoeff_mixing == "correlated-k" else 1, epsi=_f(q.epsi),
+                    kcoeff_mixing_ro=0 if q.kcoeff_mixing == "correlated-k" else 1, iso=_i(q.iso),
+                    singlewalk=_i(q.singlewalk), epsi=_f(q.epsi),
                     epsi2=_f(q.epsi2), g_0=_f(q.g_0), i2s_transition=_f(q.i2s_transition),
                     w_0_limit=_f(q.w_0_limit), w_0_scat_limit=_f(q.w_0_scat_limit),
                     delta_tau_limit=_f(q.delta_tau_limit), debug=_i(q.debug or 0))
@@ -503,6 +505,18 @@ class Compute(object):
         L = _i(quant.nlayer)
         fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in quant.species_list)
         self.ctx.timer_start()
+        if quant.singlewalk == 1:
+            # post-processing run type (computation.py:983-984): one pass -- refresh, 1000*scat+1 sweeps inside one
+            # launch of the flux kernel, quadrature -- and no temperature iteration
+            if quant.opacity_mixing == "on-the-fly":
+                self._push_vmr(quant)
+            rt.step(0, step_temperature=False)
+            self.report_diagnostics(quant)
+            ms = self.ctx.timer_stop_ms()
+            print("\nTime for radiative iteration [s]: {:.2f}".format(ms * 1e-3))
+            print("Total number of iterative steps: " + str(quant.iter_value))
+            self.sync_store_from_rt(quant)
+            return
         it = 0
         condition1 = condition2 = condition3 = True
         while condition1 and condition2 and condition3:
@@ -563,22 +577,24 @@ class Compute(object):
                   "F_net_diff", "planckband_lay", "planckband_int", "scat_cross_lay", "scat_cross_int",
                   "meanmolmass_lay", "meanmolmass_int", "delta_z_lay", "z_lay", "abort", "g_0_tot_lay",
                   "g_0_tot_int"):
+            if quant.iso == 1 and n in ("planckband_int", "scat_cross_int", "meanmolmass_int", "g_0_tot_int"):
+                continue       # the reference computes no interface values with isothermal layers: they stay zero
             v = rt.get(n, col)
             dev = getattr(quant, "dev_" + n, None)
             if dev is not None and dev.size == v.size:
                 dev.set(v)
         # opacities of every spectral point: rebuilt on the device if the fused look-up skipped them, then copied d2d
         # (the Store over-allocates the layer arrays to ninterface slabs, Q2)
-        for n, nlev in (("opac_wg_lay", L), ("opac_wg_int", I)):
+        for n, nlev in (("opac_wg_lay", L),) + ((("opac_wg_int", I),) if quant.iso == 0 else ()):
             getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n, col), Y * X * nlev * 8)
         if quant.dir_beam == 1:
-            for n in ("F_dir_wg", "Fc_dir_wg"):
+            for n in ("F_dir_wg",) + (("Fc_dir_wg",) if quant.iso == 0 else ()):
                 getattr(quant, "dev_" + n).copy_from_device(rt.device_ptr(n, col), Y * X * I * 8)
         else:
             quant.dev_F_dir_wg.fill_zero()
             quant.dev_Fc_dir_wg.fill_zero()
         if flux_state:
-            for n in ("F_up_wg", "Fc_up_wg"):
+            for n in ("F_up_wg",) + (("Fc_up_wg",) if quant.iso == 0 else ()):
                 v = rt.get(n, col)
                 dev = getattr(quant, "dev_" + n)
                 buf = np.zeros(dev.size)

@@ -61,8 +61,7 @@ void choose_workgroup(int Y, int X, int max_threads, TileGeom& g) {
     }
 }
 
-bool choose_geometry(int L, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g) {
-    const int H = 2 * L;
+bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g) {
     int best_k = 0, best_rows = 0, best_pad = 1 << 30;
     int force_k = 0;
     if (const char* e = getenv("HELIOS_RT_K")) force_k = atoi(e);  // tuning knob
@@ -126,6 +125,7 @@ KArgs make_args(hx_rt* rt) {
     a.scat = rt->f.scat; a.dir_beam = rt->f.dir_beam; a.clouds = rt->f.clouds;
     a.scat_corr = rt->f.scat_corr; a.nsweep = rt->nsweep; a.keep_down = rt->keep_down ? 1 : 0;
     a.real_star = rt->f.real_star;
+    a.iso = rt->f.iso;
     a.dim = rt->d.plancktable_dim; a.step = rt->d.plancktable_step;
     a.epsi = rt->f.epsi; a.epsi2 = rt->f.epsi2; a.g_0 = rt->f.g_0; a.i2s = rt->f.i2s_transition;
     a.w_0_limit = rt->f.w_0_limit; a.w_0_scat_limit = rt->f.w_0_scat_limit;
@@ -207,7 +207,7 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.X = a.X; f.Y = a.Y; f.L = a.L; f.I = a.I; f.H = a.H;
     f.k = a.k; f.nxb = a.nxb; f.ypb = a.ypb; f.nparts = a.nparts; f.G = a.G; f.NW = a.NW;
     f.dir_beam = a.dir_beam; f.nsweep = a.nsweep; f.keep_down = a.keep_down; f.has_vp = a.has_vp;
-    f.pl_vp = a.pl_vp; f.pl_dd = a.pl_dd; f.nplane = a.nplane;
+    f.pl_vp = a.pl_vp; f.pl_dd = a.pl_dd; f.nplane = a.nplane; f.iso = a.iso;
     f.Kconst = a.Kconst;
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
@@ -319,12 +319,15 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->d = *dims;
     rt->f = *flags;
     rt->cols.assign(columns, columns + dims->ncol);
-    rt->X = dims->nbin; rt->Y = dims->ny; rt->L = dims->nlayer; rt->I = rt->L + 1; rt->H = 2 * rt->L;
+    rt->X = dims->nbin; rt->Y = dims->ny; rt->L = dims->nlayer; rt->I = rt->L + 1;
+    // segments of the sweeps: two half-layers per layer (read.py:888-895), or the layers themselves when isothermal
+    rt->H = flags->iso ? rt->L : 2 * rt->L;
     rt->C = dims->ncol;
-    rt->nsweep = 3 * (flags->scat ? 1 : 0) + 1;  // computation.py:531-537 (iterative run type)
+    // computation.py:531-537: 3*scat+1 sweeps per iteration, 1000*scat+1 in the post-processing run type
+    rt->nsweep = (flags->singlewalk ? 1000 : 3) * (flags->scat ? 1 : 0) + 1;
     if (const char* e = getenv("HELIOS_RT_DEBUG_NSWEEP")) rt->nsweep = atoi(e);  // profiling experiments only
-    if (!choose_geometry(rt->L, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g))
-        return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512; use the per-stage API");
+    if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g))
+        return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512 (1024 isothermal layers); use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
     rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
@@ -725,7 +728,7 @@ int hx_rt_refresh(hx_rt* rt) {
         ProfScope ps(rt, "direct_beam");
         k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
-        rc = hx_internal_fdir_noniso_batch(ctx, rt->F_dir_wg, rt->Fc_dir_wg, rt->Bstar, rt->dtau_u, rt->dtau_l,
+        rc = hx_internal_fdir_noniso_batch(ctx, rt->F_dir_wg, rt->f.iso ? nullptr : rt->Fc_dir_wg, rt->Bstar, rt->dtau_u, rt->dtau_l,
                                            rt->z_lay, rt->colpar, rt->done, C, rt->f.dir_beam,
                                            rt->f.geom_zenith_corr, I, X, Y);
         if (rc) return rc;
@@ -1080,6 +1083,10 @@ int get_flux_wg(hx_rt* rt, int col, const double* tiles, const double* bc, bool 
                     const int h = j * g.ROWS + r;
                     if (h >= rt->H) continue;
                     const int node = up ? h + 1 : h;
+                    if (rt->f.iso) {  // isothermal layers: every node is an interface, there are no centre fluxes
+                        if (interface_nodes) o[c + nc * node] = tile[plane_off(r, lane, g.ROWS)];
+                        continue;
+                    }
                     const bool is_int = (node % 2) == 0;
                     if (is_int != interface_nodes) continue;
                     o[c + nc * (node / 2)] = tile[plane_off(r, lane, g.ROWS)];
@@ -1167,11 +1174,11 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
         double* o = (double*)out;
         for (size_t x = 0; x < X; x++) {
             if (lay) {
-                for (size_t i = 0; i < L; i++) o[i + x * per] = tmp[x * NN + 2 * i + 1];
+                for (size_t i = 0; i < L; i++) o[i + x * per] = tmp[x * NN + (rt->f.iso ? i : 2 * i + 1)];
                 o[L + x * per] = tmp[x * NN + rt->H + 1];
                 o[L + 1 + x * per] = tmp[x * NN + rt->H + 2];
-            } else {
-                for (size_t i = 0; i < I; i++) o[i + x * per] = tmp[x * NN + 2 * i];
+            } else {  // isothermal layers: the reference does not compute interface values (computation.py:315-329)
+                for (size_t i = 0; i < I; i++) o[i + x * per] = rt->f.iso ? 0.0 : tmp[x * NN + 2 * i];
             }
         }
         return 0;

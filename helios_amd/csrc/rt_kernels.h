@@ -24,6 +24,7 @@ struct KArgs {
     int X, Y, L, I, H, C;
     int k, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk, coef_nbx;
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
+    int iso;                   // isothermal layers: H = L segments between the interfaces, one coefficient set per layer
     int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
     double Kconst;             // 2 pi eps: source prefactor when E == 1 (scat_corr == 0)
     int dim, step;
@@ -50,7 +51,7 @@ struct KArgs {
 struct FluxArgs {
     int X, Y, L, I, H;
     int k, nxb, ypb, nparts, G, NW;
-    int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane;
+    int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane, iso;
     double Kconst;
     const hx_rt_column* colpar;
     const double *Bn, *coef, *U0_in, *boaK, *Fdir0, *surf_albedo, *gauss_w;
@@ -96,6 +97,7 @@ __global__ void __launch_bounds__(256) k_rt_nodes(KArgs a) {
             } else {
                 double Tn;
                 if (n == a.H + 2) Tn = T[a.L];
+                else if (a.iso) Tn = T[min(n, a.L - 1)];  // isothermal layers: "node" n = layer n (slot H is not used)
                 else if (n & 1) Tn = T[(n - 1) >> 1];
                 else Tn = interface_T(T, n >> 1, a.L);
                 v = planck_lookup(a.planck_grid, Tn, x, a.X, a.dim, a.step);
@@ -292,17 +294,26 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
         const double* mmi = a.mmm_int + (size_t)col * a.I;
         const double* dcu = a.dcol_u + (size_t)col * a.L;
         const double* dcl = a.dcol_l + (size_t)col * a.L;
+        const double* pint = a.p_int + (size_t)col * a.I;
+        const double grav = a.colpar[col].g;
         for (int h = threadIdx.x; h < a.H; h += blockDim.x) {
-            const int i = h >> 1, ii = i + (h & 1);
-            sh_mu[h] = (mmi[ii] + mml[i]) / 2.0;
-            sh_dc[h] = (h & 1) ? dcu[i] : dcl[i];
+            if (a.iso) {  // whole layers (calc_trans_iso, kernels.cu:1015-1104): delta_colmass of host_functions.py:733
+                sh_mu[h] = mml[h];
+                sh_dc[h] = (pint[h] - pint[h + 1]) / grav;
+            } else {
+                const int i = h >> 1, ii = i + (h & 1);
+                sh_mu[h] = (mmi[ii] + mml[i]) / 2.0;
+                sh_dc[h] = (h & 1) ? dcu[i] : dcl[i];
+            }
         }
         const double* scl_g = a.scat_cross_lay + col * bandI;
         const double* sci_g = a.scat_cross_int + col * bandI;
         for (int t = threadIdx.x; t < a.H * NBX; t += blockDim.x) {
             const int h = t / NBX, xs = t - h * NBX, x = min(x_base + xs, a.X - 1);
-            const int i = h >> 1, ii = i + (h & 1);
-            sh_ray[t] = a.scat == 1 ? (sci_g[x + (size_t)a.X * ii] + scl_g[x + (size_t)a.X * i]) / 2.0 : 0.0;
+            const int i = a.iso ? h : h >> 1, ii = a.iso ? h : i + (h & 1);
+            double v = 0.0;
+            if (a.scat == 1) v = a.iso ? scl_g[x + (size_t)a.X * i] : (sci_g[x + (size_t)a.X * ii] + scl_g[x + (size_t)a.X * i]) / 2.0;
+            sh_ray[t] = v;
         }
     }
     __syncthreads();
@@ -316,7 +327,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             // premixed k-table look-up done while staging (kernels.cu:561-608): the opacity arrays of
             // the reference are not materialised on this path (hx_rt_get rebuilds them on demand)
             const size_t sp = nc, st = nc * a.npress;
-            for (int pass = 0; pass < 2; pass++) {
+            for (int pass = 0; pass < (a.iso ? 1 : 2); pass++) {
                 const int nlev = pass == 0 ? a.L : a.I;
                 const TPIndex* tp = (pass == 0 ? a.tp_lay : a.tp_int) + (size_t)col * a.I;
                 double* dst = pass == 0 ? sh_lay : sh_int;
@@ -347,8 +358,9 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             const double* opi = a.opac_wg_int + col * wgI;
             for (int lev = run; lev < a.L; lev += nrun)
                 sh_lay[(size_t)lev * TSP + q0] = cq >= 0 ? opl[(size_t)cq + nc * lev] : 0.0;
-            for (int lev = run; lev < a.I; lev += nrun)
-                sh_int[(size_t)lev * TSP + q0] = cq >= 0 ? opi[(size_t)cq + nc * lev] : 0.0;
+            if (!a.iso)
+                for (int lev = run; lev < a.I; lev += nrun)
+                    sh_int[(size_t)lev * TSP + q0] = cq >= 0 ? opi[(size_t)cq + nc * lev] : 0.0;
         }
     }
     __syncthreads();
@@ -364,30 +376,36 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
         const int h = j * ROWS + r;
         double alpha = 1.0, beta = 0.0, up = 0.0, vp = 0.0, dd = 0.0, du = 0.0;
         if (valid && h < a.H) {
-            const int i = h >> 1;
-            const bool lower = (h & 1) == 0;
-            // lower half averages (interface i, centre i); upper half (centre i, interface i+1)
+            const int i = a.iso ? h : h >> 1;
+            const bool lower = a.iso || (h & 1) == 0;
+            // lower half averages (interface i, centre i); upper half (centre i, interface i+1); isothermal layers take
+            // the layer-centre values as they are
             const int ii = lower ? i : i + 1;
             const size_t b_l = x + (size_t)a.X * i, b_i = x + (size_t)a.X * ii;
             double g0 = a.g_0, ray = 0.0, csc = 0.0, cab = 0.0;
             if (a.clouds == 1) {
                 const double* gl = a.g0_tot_lay + col * bandI;
                 const double* gi = a.g0_tot_int + col * bandI;
-                g0 = lower ? (gi[b_i] + gl[b_l]) / 2.0 : (gl[b_l] + gi[b_i]) / 2.0;
                 const double* al = a.cl_abs_lay + col * bandI;
                 const double* ai = a.cl_abs_int + col * bandI;
-                cab = lower ? (ai[b_i] + al[b_l]) / 2.0 : (al[b_l] + ai[b_i]) / 2.0;
+                if (a.iso) {
+                    g0 = gl[b_l];
+                    cab = al[b_l];
+                } else {
+                    g0 = lower ? (gi[b_i] + gl[b_l]) / 2.0 : (gl[b_l] + gi[b_i]) / 2.0;
+                    cab = lower ? (ai[b_i] + al[b_l]) / 2.0 : (al[b_l] + ai[b_i]) / 2.0;
+                }
             }
             if (a.scat == 1) {
                 ray = sh_ray[(size_t)h * NBX + xs];
                 if (a.clouds == 1) {
                     const double* sl = a.cl_sc_lay + col * bandI;
                     const double* si = a.cl_sc_int + col * bandI;
-                    csc = lower ? (si[b_i] + sl[b_l]) / 2.0 : (sl[b_l] + si[b_i]) / 2.0;
+                    csc = a.iso ? sl[b_l] : (lower ? (si[b_i] + sl[b_l]) / 2.0 : (sl[b_l] + si[b_i]) / 2.0);
                 }
             }
-            const double o_l = sh_lay[(size_t)i * TSP + q], o_i = sh_int[(size_t)ii * TSP + q];
-            const double kap = lower ? (o_i + o_l) / 2.0 : (o_l + o_i) / 2.0;
+            const double o_l = sh_lay[(size_t)i * TSP + q], o_i = a.iso ? o_l : sh_int[(size_t)ii * TSP + q];
+            const double kap = a.iso ? o_l : (lower ? (o_i + o_l) / 2.0 : (o_l + o_i) / 2.0);
             const double mu = sh_mu[h], dcol = sh_dc[h];
             const double w0 = single_scat_albedo(ray + csc, kap * mu + cab, a.w_0_limit);
             const double dtau_gas = dcol * (kap + ray / mu);
@@ -403,7 +421,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             beta = -s.N * invM;
             const double K = 2.0 * HX_PI * a.epsi * (1.0 - w0) / (s.E - w0);
             double u, v;
-            if (dtau < a.dtau_limit) {
+            if (a.iso || dtau < a.dtau_limit) {  // isothermal source: B (N + M - P) (kernels.cu:1442, :1640-1643)
                 u = v = (s.N + s.M - s.P) / 2.0;
             } else {
                 const double qq = a.epsi / (s.E * (1.0 - w0 * g0)) * (s.P - s.M + s.N) / dtau;
@@ -417,7 +435,8 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 const double* Fd = a.F_dir_wg + col * wgI;
                 const double* Fc = a.Fc_dir_wg + col * wgI;
                 const double Fbot = lower ? Fd[(size_t)c + nc * i] : Fc[(size_t)c + nc * i];
-                const double Ftop = lower ? Fc[(size_t)c + nc * i] : Fd[(size_t)c + nc * (i + 1)];
+                const double Ftop = a.iso ? Fd[(size_t)c + nc * (i + 1)]
+                                          : (lower ? Fc[(size_t)c + nc * i] : Fd[(size_t)c + nc * (i + 1)]);
                 const double dn = Fbot / nmu * (s.Gm * s.M + s.Gp * s.N) - Ftop / nmu * s.Gm * s.P;
                 const double upw = Ftop / nmu * (s.Gm * s.N + s.Gp * s.M) - Fbot / nmu * s.P * s.Gp;
                 dd = dmin(0.0, dn) * invM;
@@ -456,6 +475,12 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
     const double* mml = a.mmm_lay + (size_t)col * a.I;
     const double* mmi = a.mmm_int + (size_t)col * a.I;
     const size_t b = x + (size_t)a.X * i, k = c + nc * i;
+    if (a.iso) {  // one optical depth per layer (calc_trans_iso, kernels.cu:1082), kept in the "upper" array
+        const double* pint = a.p_int + (size_t)col * a.I;
+        const double ray = a.scat == 1 ? scl[b] : 0.0;
+        a.dtau_u[col * nc * a.L + k] = (pint[i] - pint[i + 1]) / a.colpar[col].g * (opl[k] + ray / mml[i]);
+        return;
+    }
     double ray_up = 0, ray_low = 0;
     if (a.scat == 1) {
         ray_up = (scl[b] + sci[b + a.X]) / 2.0;
@@ -471,6 +496,8 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 // ---- per iteration: all two-stream sweeps + Gauss quadrature ---------------------------------
 // grid (nblk_x, C).  A workgroup owns nxb bins and walks their ny/ypb groups of Gauss points one
 // after the other, so the Gauss sum of a bin is completed inside the workgroup (fixed order).
+// (k = 32 / ROWS = 7 held to 128 VGPRs for four wavefronts per SIMD through amdgpu_waves_per_eu spills 49 dwords inside
+// the sweeps: 0.62 ms against 0.42 ms at its natural 169 registers and 0.40 ms for k = 16 -- not done.)
 template <int ROWS>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
@@ -527,7 +554,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int h = min(m.j * ROWS + r, a.H - 1);
-            const double Bb = Bx[h], Bt = Bx[h + 1], upc = sd[r], vpc = su[r];
+            const double Bb = Bx[h], Bt = a.iso ? Bb : Bx[h + 1], upc = sd[r], vpc = su[r];
             sd[r] = upc * Bb + vpc * Bt;
             su[r] = upc * Bt + vpc * Bb;
         }
@@ -608,7 +635,8 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                 for (int r = 0; r < ROWS; r++) {
                     const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
                     U = fma(al[r], U, fma(be[r], Dh, su[r]));
-                    if ((m.j * ROWS + r) & 1) U = tiny_abs(U);  // interface nodes only (reference quirk, kernels.cu:1763)
+                    // interface nodes only (reference quirk, kernels.cu:1763; isothermal layers: every node, :1509)
+                    if (a.iso || ((m.j * ROWS + r) & 1)) U = tiny_abs(U);
                     Uo[r] = U;
                 }
             }
@@ -632,7 +660,10 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             for (int r = 0; r < ROWS; r++) {
                 const int h = m.j * ROWS + r;
                 if (h < a.H) {
-                    if ((h & 1) == 0) st[h >> 1] = w * Do[r];           // D at interface h/2
+                    if (a.iso) {                                        // every node is an interface
+                        st[h] = w * Do[r];
+                        st[I + h + 1] = w * Uo[r];
+                    } else if ((h & 1) == 0) st[h >> 1] = w * Do[r];    // D at interface h/2
                     else st[I + ((h + 1) >> 1)] = w * Uo[r];            // U at interface (h+1)/2
                 }
             }

@@ -153,8 +153,12 @@ k_fdir_plane(double* __restrict__ F_dir, double* __restrict__ Fc_dir,
         const int col = blockIdx.z;
         if (bb.done[col]) return;
         mu_star = bb.colpar[col].mu_star; R_star = bb.colpar[col].R_star; a = bb.colpar[col].a;
-        F_dir += col * nc * ninterface; Fc_dir += col * nc * ninterface;
-        dtau_u += col * nc * (ninterface - 1); dtau_l += col * nc * (ninterface - 1);
+        F_dir += col * nc * ninterface;
+        dtau_u += col * nc * (ninterface - 1);
+        if (NONISO) {
+            Fc_dir += col * nc * ninterface;
+            dtau_l += col * nc * (ninterface - 1);
+        }
         star += (size_t)col * nbin * star_stride;
     }
     const int x = (int)(c / ny);
@@ -190,8 +194,12 @@ k_fdir_sphere(double* __restrict__ F_dir, double* __restrict__ Fc_dir,
         if (bb.done[col]) return;
         mu_star = bb.colpar[col].mu_star; R_star = bb.colpar[col].R_star; a = bb.colpar[col].a;
         R_planet = bb.colpar[col].R_planet;
-        F_dir += col * nc * ninterface; Fc_dir += col * nc * ninterface;
-        dtau_u += col * nc * (ninterface - 1); dtau_l += col * nc * (ninterface - 1);
+        F_dir += col * nc * ninterface;
+        dtau_u += col * nc * (ninterface - 1);
+        if (NONISO) {
+            Fc_dir += col * nc * ninterface;
+            dtau_l += col * nc * (ninterface - 1);
+        }
         star += (size_t)col * nbin * star_stride;
         z_lay += (size_t)col * (ninterface - 1);
     }
@@ -335,14 +343,26 @@ int hx_internal_fdir_noniso_batch(hx_context* ctx, double* F_dir_wg, double* Fc_
                                   int dir_beam, int geom_zenith_corr, int ninterface, int nbin, int ny) {
     const int nb = hx_cdiv((long long)ny * nbin, 256);
     const BeamBatch bb{colpar, done};
-    if (geom_zenith_corr == 1)
-        k_fdir_sphere<true><<<dim3(nb, ninterface, ncol), 256, 0, ctx->stream>>>(
-            F_dir_wg, Fc_dir_wg, star, 1, delta_tau_wg_upper, delta_tau_wg_lower, z_lay, 0.0, 0.0, 0.0, 0.0,
-            dir_beam, ninterface, nbin, ny, bb);
-    else
-        k_fdir_plane<true><<<dim3(nb, 1, ncol), 256, 0, ctx->stream>>>(
-            F_dir_wg, Fc_dir_wg, star, 1, delta_tau_wg_upper, delta_tau_wg_lower, 0.0, 0.0, 0.0, dir_beam,
-            ninterface, nbin, ny, bb);
+    const bool noniso = Fc_dir_wg != nullptr;  // isothermal layers (fdir_iso): one optical depth per layer, no centres
+    if (geom_zenith_corr == 1) {
+        if (noniso)
+            k_fdir_sphere<true><<<dim3(nb, ninterface, ncol), 256, 0, ctx->stream>>>(
+                F_dir_wg, Fc_dir_wg, star, 1, delta_tau_wg_upper, delta_tau_wg_lower, z_lay, 0.0, 0.0, 0.0, 0.0,
+                dir_beam, ninterface, nbin, ny, bb);
+        else
+            k_fdir_sphere<false><<<dim3(nb, ninterface, ncol), 256, 0, ctx->stream>>>(
+                F_dir_wg, nullptr, star, 1, delta_tau_wg_upper, nullptr, z_lay, 0.0, 0.0, 0.0, 0.0, dir_beam,
+                ninterface, nbin, ny, bb);
+    } else {
+        if (noniso)
+            k_fdir_plane<true><<<dim3(nb, 1, ncol), 256, 0, ctx->stream>>>(
+                F_dir_wg, Fc_dir_wg, star, 1, delta_tau_wg_upper, delta_tau_wg_lower, 0.0, 0.0, 0.0, dir_beam,
+                ninterface, nbin, ny, bb);
+        else
+            k_fdir_plane<false><<<dim3(nb, 1, ncol), 256, 0, ctx->stream>>>(
+                F_dir_wg, nullptr, star, 1, delta_tau_wg_upper, nullptr, 0.0, 0.0, 0.0, dir_beam, ninterface, nbin,
+                ny, bb);
+    }
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

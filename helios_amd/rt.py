@@ -24,7 +24,8 @@ class RtFlags(ctypes.Structure):
                 ("scat_corr", ctypes.c_int32), ("geom_zenith_corr", ctypes.c_int32),
                 ("smooth", ctypes.c_int32), ("real_star", ctypes.c_int32),
                 ("planet_type_gas", ctypes.c_int32), ("kcoeff_mixing_ro", ctypes.c_int32),
-                ("debug", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6),
+                ("debug", ctypes.c_int32), ("iso", ctypes.c_int32), ("singlewalk", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 4),
                 ("epsi", ctypes.c_double), ("epsi2", ctypes.c_double), ("g_0", ctypes.c_double),
                 ("i2s_transition", ctypes.c_double), ("w_0_limit", ctypes.c_double),
                 ("w_0_scat_limit", ctypes.c_double), ("delta_tau_limit", ctypes.c_double),
@@ -245,7 +246,8 @@ def batch_from_case(ctx, c, ncol=1, nspecies=0, columns=None):
     flags = dict(scat=int(c.scat), dir_beam=int(c.dir_beam), clouds=int(c.clouds),
                  scat_corr=int(c.scat_corr), geom_zenith_corr=int(c.geom_zenith_corr),
                  smooth=int(c.smooth), real_star=int(c.real_star), planet_type_gas=1,
-                 kcoeff_mixing_ro=1, epsi=float(c.epsi), epsi2=float(c.epsi2), g_0=float(c.g_0),
+                 kcoeff_mixing_ro=1, iso=int(c.get("iso", 0)), singlewalk=int(c.get("singlewalk", 0)),
+                 epsi=float(c.epsi), epsi2=float(c.epsi2), g_0=float(c.g_0),
                  i2s_transition=float(c.i2s_transition), w_0_limit=float(c.w_0_limit),
                  w_0_scat_limit=float(c.w_0_scat_limit), delta_tau_limit=float(c.delta_tau_limit))
     col = dict(g=float(c.g), a=float(c.a), R_planet=float(c.R_planet), R_star=float(c.R_star),

@@ -323,7 +323,10 @@ typedef struct hx_rt_flags {
     int32_t scat, dir_beam, clouds, scat_corr, geom_zenith_corr, smooth, real_star, planet_type_gas;
     int32_t kcoeff_mixing_ro;     /* 1 = random overlap, 0 = correlated-k (param.dat:110) */
     int32_t debug;
-    int32_t reserved[6];
+    int32_t iso;                  /* 1 = isothermal layers (fband_iso / calc_trans_iso / fdir_iso), read.py:888-935 */
+    int32_t singlewalk;           /* 1 = post-processing run type: 1000*scat+1 sweeps, no temperature iteration
+                                     (computation.py:531-537) */
+    int32_t reserved[4];
     double epsi, epsi2, g_0, i2s_transition, w_0_limit, w_0_scat_limit, delta_tau_limit;
     double reserved_d[9];
 } hx_rt_flags;

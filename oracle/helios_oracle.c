@@ -3,7 +3,9 @@
  * CPU restatement (plain C, OpenMP over wavelength bins) of the reference's hot-path arithmetic.
  * Every function cites the reference lines it follows (paths relative to /root/reference).
  * Expressions keep the reference's operand order so that the results agree with the reference's
- * own kernels run on the host (oracle/_ref) to the last few ulp; compile with -ffp-contract=off.
+ * own kernels to the last few ulp (host build) / to what FMA contraction does to cancelling terms
+ * (the gfx950 build that generated tests/golden/: tolerances in tests/golden_checks.py); compile with
+ * -ffp-contract=off.
  */
 #include "helios_oracle.h"
 

@@ -10,11 +10,15 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
  * product path (helios_amd/ + libhelios_hip.so) never does.
  *
- * Parity pin: every function here is checked against the reference's own kernels compiled for the
- * host (oracle/_ref, built from the reference sources where they lie) in tests/test_oracle_vs_ref.py
- * and against the golden vectors committed under tests/golden/ (generated from oracle/_ref by
- * tests/golden/make_golden.py).  The reference ships no tests or golden vectors of its own
- * (SURVEY.md §4).
+ * Parity pin: every function here is held to the golden vectors committed under tests/golden/, which
+ * the REFERENCE ITSELF produced on an MI355X: its source/kernels.cu compiled unmodified by hipcc for
+ * gfx950 (oracle/_ref/libhelios_ref_gfx950.so, recipe in oracle/Makefile, launch geometry of
+ * source/computation.py in oracle/ref_driver_gfx950.hip; generator tests/golden/make_golden.py
+ * --backend gfx950) -- stage chains, mixing branches, the matrix solver, 64-bin x 100-layer columns and
+ * whole radiation loops to convergence (tests/test_golden.py, tests/test_loop_golden.py).  On the GPU box
+ * the same library runs next to the HIP kernels (tests/test_gpu_reference.py).  A host build of the same
+ * file through oracle/ref_shim.h (oracle/_ref/libhelios_ref.so, tests/test_oracle_vs_ref.py) is a CPU-side
+ * cross-check only.  The reference ships no tests or golden vectors of its own.
  */
 #ifndef HELIOS_ORACLE_H
 #define HELIOS_ORACLE_H

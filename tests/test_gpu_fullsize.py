@@ -114,6 +114,50 @@ def _upload_species(rt, c, xs, nb):
     return slices
 
 
+def test_config2_full_size_sampled_bins_vs_oracle(ctx, port):
+    """the headline configuration (10 000 x 100 x 20, premixed, isotropic scattering): 64 bins of the first refresh and
+    flux solve against the oracle, three iterations of temperature steps against the oracle's steps fed with the
+    library's own totals"""
+    import bench
+    from helios_amd.rt import batch_from_case
+    c = bench.build_case(bench.WORKLOADS["c2"], 20242)
+    c.T_lay = 900.0 + 600.0 * (np.log10(np.append(c.p_lay, c.p_lay[0])) + 1.0) / 10.0
+    xs, nb = _blocks(c.nbin)
+    rt = batch_from_case(ctx, c, ncol=1)
+    try:
+        rt.keep_down_fluxes(True)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        got = {k: rt.get(k) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int", "F_up_band",
+                                      "F_down_band", "F_up_wg", "F_down_wg", "Fc_up_wg")}
+        grid = rt.get("planck_grid")
+        tot = {k: rt.get(k) for k in ("F_up_tot", "F_down_tot", "F_net", "T_lay")}
+    finally:
+        rt.close()
+    for x0 in xs:
+        b = _block_case(c, x0, nb)
+        s = _oracle_block(port, b, grid, c, x0, nb, cases.refresh_premixed)
+        _compare_block(got, s, c, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg", "F_down_wg", "Fc_up_wg"),
+                       ("scat_cross_lay", "scat_cross_int", "F_up_band", "F_down_band"))
+    # totals = sum over ALL bins of the band fluxes (checked per bin above), then the reference's temperature step
+    dl = np.asarray(c.opac_deltawave)
+    I = c.nlayer + 1
+    np.testing.assert_allclose(tot["F_up_tot"], (got["F_up_band"].reshape(I, c.nbin) * dl).sum(1), rtol=1e-12)
+    np.testing.assert_allclose(tot["F_down_tot"], (got["F_down_band"].reshape(I, c.nbin) * dl).sum(1), rtol=1e-12)
+    b = _block_case(c, 0, nb)
+    s = cases.alloc_state(b)
+    s.F_up_tot[:], s.F_down_tot[:], s.F_net[:] = tot["F_up_tot"], tot["F_down_tot"], tot["F_net"]
+    T0 = np.asarray(c.T_lay, float).copy()
+    b.T_lay = T0.copy()
+    s.meanmolmass_lay[:] = 2.3 * 1.6605390666e-24
+    port.rad_temp_iter(s.F_down_tot, s.F_up_tot, s.F_net, s.F_net_diff, b.T_lay, b.p_lay, b.p_int, s.abort, s.T_store,
+                       s.deltat_prefactor, b.F_add_heat_lay, b.F_add_heat_sum, b.F_smooth, b.F_smooth_sum, b.c_p_lay,
+                       s.meanmolmass_lay, 0, b.foreplay, b.g, b.nlayer, b.physical_tstep, b.rad_convergence_limit,
+                       b.adapt_interval, b.smooth, b.plancktable_dim, b.plancktable_step, b.F_intern, b.no_atmo)
+    np.testing.assert_allclose(tot["T_lay"], b.T_lay, rtol=1e-12)
+    assert np.abs(tot["T_lay"] - T0).max() > 1e-3
+
+
 def test_config3_full_size_sampled_bins_vs_oracle(ctx, port):
     """20 species at 10 000 x 100: mixed opacities, scattering and the first flux solve of 64 bins against the oracle;
     k-distributions stay ascending and fluxes non-negative everywhere"""

@@ -35,6 +35,11 @@ FUSED_CONFIGS = {
     "L200_i2s": dict(nbin=6, nlayer=200, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),  # config-5 flags: 4 planes + clouds
     "L512": dict(nbin=3, nlayer=512, dir_beam=1),   # the fused path's largest column: k=64, 16 rows per lane
     "smallest": dict(nbin=2, nlayer=4),             # two bins, four layers (the height integration needs a layer below 10 bar)
+    # isothermal layers (fband_iso / calc_trans_iso / fdir_iso): one segment per layer
+    "iso": dict(iso=1, nbin=11, nlayer=20),
+    "iso_clouds_beam": dict(iso=1, nbin=9, nlayer=37, clouds=1, scat_corr=1, g_0=0.2, dir_beam=1, albedo=0.15),
+    "iso_zenith_L100": dict(iso=1, nbin=6, nlayer=100, dir_beam=1, geom_zenith_corr=1, zenith_deg=70.0),
+    "iso_noscat": dict(iso=1, scat=0, nbin=7, nlayer=16),
 }
 
 
@@ -60,9 +65,9 @@ def test_fused_vs_oracle_single_wavefront_workgroups(ctx, port, name, monkeypatc
     fh.compare(f, o, c0, rtol=1e-7)
 
 
-@pytest.mark.parametrize("name", [n for n in gc.CHAIN_NAMES if not n.startswith("iso")])
+@pytest.mark.parametrize("name", gc.CHAIN_NAMES)
 def test_fused_golden(ctx, name):
-    """the fused path against the reference-generated golden vectors (non-isothermal configs)"""
+    """the fused path against the reference-generated golden vectors (isothermal and non-isothermal layers)"""
     c, z = gc.load_chain(name)
     for n_iter, prefix, rtol in ((1, "it1.", 1e-9), (12, "it12.", 1e-7)):
         f = fh.run_fused(ctx, c, n_iter)

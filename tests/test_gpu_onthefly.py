@@ -267,6 +267,14 @@ def test_run_helios_post_processing_of_a_converged_profile(tmp_path):
     assert np.all(np.isfinite(a)) and a.min() >= 0
     assert abs(a @ it.opac_deltawave - b @ it.opac_deltawave) < 0.05 * (b @ it.opac_deltawave)
     assert os.path.getsize(os.path.join(wd, "run_post", "run_post_contribution.dat")) > 100
+    # the same pass through the per-stage entry points (1001 launches of hx_fband_iso): the fused kernel runs the 1001
+    # sweeps in registers inside one launch
+    ps = _run_driver(base + ["-name", "run_post2", "-run_type", "post-processing", "-path_to_temperature_file",
+                             os.path.join(wd, "run", "run_tp.dat")], False)
+    np.testing.assert_allclose(pp.F_up_band, ps.F_up_band, rtol=1e-9, atol=1e-13 * ps.F_up_band.max())
+    np.testing.assert_allclose(pp.F_down_band, ps.F_down_band, rtol=1e-9, atol=1e-13 * ps.F_down_band.max())
+    np.testing.assert_allclose(pp.contr_func_band, ps.contr_func_band, rtol=1e-9, atol=1e-13 * ps.contr_func_band.max())
+    np.testing.assert_allclose(pp.F_net, ps.F_net, rtol=1e-8, atol=1e-11 * np.abs(ps.F_up_tot).max())
 
 
 CONV_ARGV = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",
