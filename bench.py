@@ -420,6 +420,16 @@ def main():
         "spectrum_checksum": float(np.sum(spec)),
         "roofline": roofline,
     }
+    if world > 1:
+        # N = 1 runs another workload (config 2): what ONE GPU does on this workload, measured with the same command
+        # at --gpus 1 and committed under profiles/, so that a scaling efficiency can be formed from like numbers
+        ref = os.path.join(ROOT, "profiles", "r02_c4_bench_64columns.json")
+        if wname == "c4" and ncol == WORKLOADS["c4"]["columns_per_gpu"] and os.path.exists(ref):
+            with open(ref) as f:
+                one = json.loads(f.read().strip().splitlines()[-1])
+            line["single_gpu_same_workload"] = dict(value=one["value"], ms_per_step=one["ms_per_step"],
+                                                    source="profiles/r02_c4_bench_64columns.json (python bench.py "
+                                                           "--workload c4 on one MI355X)")
     rt.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, seed)
