@@ -676,6 +676,9 @@ int hx_rt_refresh(hx_rt* rt) {
         for (const Species& sp : rt->species) any_ro = any_ro || (sp.absorbing && rt->f.kcoeff_mixing_ro && !sp.is_cia);
         if (Y != ro::NY && any_ro) return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 (got %d)", Y);
         HX_REQUIRE(ctx, Y <= ro::NY, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 20 Gauss points");
+        int nabs = 0;
+        for (const Species& sp : rt->species) nabs += sp.absorbing ? 1 : 0;
+        HX_REQUIRE(ctx, nabs <= MIX_MAX_ABSORBERS, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 64 absorbers");
     }
     KArgs a = make_args(rt);
     {   // interface temperatures (and node Planck values) of the CURRENT layer temperatures

@@ -85,11 +85,26 @@ __global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, cons
     mmm_lay[(size_t)col * I + i] = num / tot * HX_AMU;
 }
 
+constexpr int MIX_MAX_ABSORBERS = 64;  // LDS images of the species list: 1.25 KB next to ro::Shared, 16 wavefronts per CU
+
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_rt_mix_species(MixArgs a) {
     __shared__ ro::Shared sh;
+    // what the species loop needs per absorber, staged once per wavefront: table base, correlated-k flag, and -- per
+    // level -- the factor vmr * mass / mu.  (Read straight from the argument block these were chains of dependent
+    // global loads inside the loop: the scalar registers are all taken, so the compiler fetched them through the
+    // vector memory path and waited for each; same-box A/B 68.6 -> 67.7 ms per refresh at config 3.)
+    __shared__ const double* s_tab[MIX_MAX_ABSORBERS];
+    __shared__ double s_fac[MIX_MAX_ABSORBERS];
+    __shared__ int s_info[MIX_MAX_ABSORBERS];  // species index << 1 | random-overlap flag
     const int lane = threadIdx.x;
     ro::Lane ln;
     ro::init(sh, ln, lane, a.gauss_w, a.gauss_y);
+    const int nabs = a.nabs;
+    if (lane < nabs) {
+        const int s = a.abs_list[lane];
+        s_tab[lane] = a.sp[s].pretab;
+        s_info[lane] = s << 1 | ((s == 0 || a.sp[s].ro == 0) ? 0 : 1);  // correlated-k: first species, CIA (:3302-3310)
+    }
     ro::Counters cnt;
     const long long nlev = a.L + a.I, per_col = nlev * a.X, npair = per_col * a.C;
     const long long chunk = (npair + gridDim.x - 1) / gridDim.x;
@@ -97,10 +112,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     const size_t nc = (size_t)a.Y * a.X, st_p = nc, st_t = nc * a.npress;
     long long lev_cur = -1;
     TPIndex tp = {};
-    const double* fac = nullptr;
     double* out_level = nullptr;
     size_t pl_dd = 0, pl_ud = 0, pl_du = 0, pl_uu = 0;  // table planes of the level's four (T, P) corners: wave-uniform
     bool skip = false;
+    // Three groups of 20 lanes fetch three absorbers at a time: lane 20 g + y holds Gauss point y of absorber kb + g.
+    // The next triple's table corners are requested before the present triple is mixed, so that even a run of negligible
+    // absorbers (a few dozen instructions each) does not wait for memory.
+    const int grp = lane / ro::NY, y = lane - grp * ro::NY;
+    const bool loader = grp < 3 && y < a.Y;
     for (long long pair = p0; pair < p1; pair++) {
         const long long cl = pair / a.X;  // column * nlev + level
         const int x = (int)(pair - cl * a.X);
@@ -111,37 +130,34 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
             const int i = lay ? lev : lev - a.L;
             skip = a.done[col] != 0;
             tp = (lay ? a.tp_lay : a.tp_int)[(size_t)col * a.I + i];
-            fac = (lay ? a.fac_lay : a.fac_int) + ((size_t)col * a.I + i) * a.S;
+            const double* fac = (lay ? a.fac_lay : a.fac_int) + ((size_t)col * a.I + i) * a.S;
             out_level = (lay ? a.opac_wg_lay : a.opac_wg_int) + (size_t)col * nc * a.I + nc * i;
             pl_dd = st_p * tp.pdown + st_t * tp.tdown;
             pl_ud = st_p * tp.pup + st_t * tp.tdown;
             pl_du = st_p * tp.pdown + st_t * tp.tup;
             pl_uu = st_p * tp.pup + st_t * tp.tup;
+            ro::sync();
+            if (lane < nabs) s_fac[lane] = fac[s_info[lane] >> 1];
+            ro::sync();
         }
         if (skip) continue;
-        // Three groups of 20 lanes fetch three absorbers at a time: lane 20 g + y holds Gauss point y of absorber
-        // kb + g.  The next triple's table corners are requested before the present triple is mixed, so that even a run
-        // of negligible absorbers (a few dozen instructions each) does not wait for memory.
-        const int grp = lane / ro::NY, y = lane - grp * ro::NY;
-        const bool loader = grp < 3 && y < a.Y;
         const unsigned off = (unsigned)(a.Y * x + y);  // inside a table plane: the same for all corners of all species
         double c_dd = 0.0, c_ud = 0.0, c_du = 0.0, c_uu = 0.0;
-        if (loader && grp < a.nabs) {
-            const double* tab = a.sp[a.abs_list[grp]].pretab;
+        if (loader && grp < nabs) {
+            const double* tab = s_tab[grp];
             c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];
         }
         double mixv = 0.0;  // nullify_opac_scat_arrays (host_functions.py:1050-1056)
-        for (int kb = 0; kb < a.nabs; kb += 3) {
+        for (int kb = 0; kb < nabs; kb += 3) {
             const double raw_mine = blend_tp(c_dd, c_ud, c_du, c_uu, tp, true);
-            if (loader && kb + 3 + grp < a.nabs) {
-                const double* tab = a.sp[a.abs_list[kb + 3 + grp]].pretab;
+            if (loader && kb + 3 + grp < nabs) {
+                const double* tab = s_tab[kb + 3 + grp];
                 c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];
             }
-            for (int j = 0; j < 3 && kb + j < a.nabs; j++) {
-                const int s = a.abs_list[kb + j];
+            for (int j = 0; j < 3 && kb + j < nabs; j++) {
                 const double raw = ro::shfl((ro::NY * j + y) << 2, raw_mine);  // lanes 0..19: from group j
-                const double add = fac[s] * raw;
-                if (s == 0 || a.sp[s].ro == 0) mixv += add;  // correlated-k (:3302-3310)
+                const double add = s_fac[kb + j] * raw;
+                if ((s_info[kb + j] & 1) == 0) mixv += add;
                 else mixv = ro::mix(sh, ln, lane, mixv, add, cnt);
             }
         }
