@@ -166,7 +166,18 @@ def _ro_cases():
     out["tiny_min"] = (np.sort(10.0 ** rng.uniform(-300, 6, shape), axis=2),
                        np.sort(10.0 ** rng.uniform(-300, 6, shape), axis=2) / fac)
     out["dominated"] = (generic, np.sort(generic[..., ::-1] * 0.03, axis=2) / fac)
+    # levels that differ little from their predecessor (the same order, a slowly drifting one, drifting with exact ties)
+    lev = np.arange(nlev)[:, None, None]
+    base_m, base_a = generic[:1], np.sort(10.0 ** rng.uniform(-4, 0, (1, nbin, ny)), axis=2) / fac
+    out["levels_same_order"] = (base_m * 1.3 ** lev, base_a * 1.3 ** lev)
+    out["levels_drifting"] = (base_m * (1.0 + 0.01 * lev), base_a * (1.0 - 0.012 * lev) * (1.0 + 0.004 * lev * gy_like(ny)))
+    out["levels_drifting_ties"] = (np.round(base_m, 2) + 0.01 + 0.0 * lev, (np.round(base_a * fac, 2) + 0.01) / fac * (1.0 + 0.5 * (lev % 2)))
     return (ny, nbin, nlev), out
+
+
+def gy_like(ny):
+    return np.linspace(0.0, 1.0, ny)[None, None, :]
+
 
 
 def _ro_run(impl):
