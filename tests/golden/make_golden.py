@@ -267,8 +267,14 @@ def loop_fixture(name):
     cases.setup_planck(ref, c, s)
     data = {"meta": meta(), "planck_grid": s.planck_grid.copy(), "crit_relaxation_numbers": np.array(relax, np.int64)}
     for k, v in c0.items():
-        data["in." + k] = np.asarray(v)
-    n, snaps, reason = ld.radiation_loop(ref, c, s, ld.SNAP_AT, crit_relaxation_numbers=relax)
+        if k != "species":
+            data["in." + k] = np.asarray(v)
+    for i, sp in enumerate(c0.get("species") or []):     # the species list as plain arrays
+        for k, v in sp.items():
+            if v is not None:
+                data["species.%d.%s" % (i, k)] = np.asarray(v)
+    n, snaps, reason = ld.radiation_loop(ref, c, s, ld.SNAP_AT, crit_relaxation_numbers=relax,
+                                         refresh=ld.loop_refresh(c))
     data["iter_count"] = np.array(n)
     data["reason"] = np.array(reason)
     for at, sn in snaps.items():
@@ -309,6 +315,7 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=HERE)
     ap.add_argument("--only", default="")
     ap.add_argument("--compare", default="")
+    ap.add_argument("--loop-names", default="", help="comma-separated subset of the loop fixtures")
     a = ap.parse_args()
     if a.compare:
         compare(a.compare)
@@ -328,7 +335,7 @@ if __name__ == "__main__":
             big_fixture(name, cfg)
     if not only or "loop" in only:
         import loop_driver as ld
-        for name in ld.LOOP_NAMES:
+        for name in (a.loop_names.split(",") if a.loop_names else ld.LOOP_NAMES):
             loop_fixture(name)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("wrote fixtures to %s, %.1f KB total" % (OUT, tot / 1024.0))

@@ -28,6 +28,18 @@ def load_chain(name, directory=None, prefix="chain_"):
               "clouds", "scat_corr", "geom_zenith_corr", "real_star", "plancktable_dim",
               "plancktable_step", "adapt_interval", "foreplay", "smooth", "no_atmo"):
         c[k] = int(c[k])
+    nsp = 1 + max([int(k.split(".")[1]) for k in z.files if k.startswith("species.")], default=-1)
+    if nsp:
+        c.species = []
+        for i in range(nsp):
+            sp = dict(pretab=None, scat=None)
+            for k in z.files:
+                if k.startswith("species.%d." % i):
+                    v = z[k]
+                    sp[k.split(".", 2)[2]] = v.item() if v.ndim == 0 else v.copy()
+            for k in ("absorbing", "scattering", "is_h2o", "is_cia"):
+                sp[k] = bool(sp[k])
+            c.species.append(sp)
     return c, z
 
 

@@ -12,6 +12,7 @@ Control flow followed line by line:
     :880-883  3*scat+1 sweeps,  :888 quadrature
     :906      temperature step only once iter >= foreplay
     :927-932  abortsum = sum(abort);  :938 condition1 = abortsum < nlayer + 1
+    :941-943  time-stepped runs: condition3 = (iter + 1) * physical_tstep < runtime_limit
     :946-952  every 100th iteration: condition2 = T_lay[nlayer] < dim*step - 2
     :954      iter += 1
     :974-975  rad_convergence_limit *= 10 when the NEW iter value is in crit_relaxation_numbers
@@ -37,15 +38,15 @@ def snapshot(c, s):
 
 
 def radiation_loop(impl, c, s, snap_at=(), max_nr_iterations=20000, crit_relaxation_numbers=(),
-                   refresh=cases.refresh_premixed, on_iteration=None):
+                   refresh=cases.refresh_premixed, on_iteration=None, runtime_limit=None):
     """runs the loop until the reference's loop would leave it.  Returns (iter_count, snaps, reason)
     with snaps[n] = state after n completed iterations for n in snap_at, snaps['end'] = final state."""
     snaps = {}
     it = 0
     L = c.nlayer
-    condition1 = condition2 = True
+    condition1 = condition2 = condition3 = True
     reason = "converged"
-    while condition1 and condition2:
+    while condition1 and condition2 and condition3:
         cases.interpolate_temperatures_and_planck(impl, c, s)
         if it % 10 == 0:
             refresh(impl, c, s)
@@ -53,6 +54,10 @@ def radiation_loop(impl, c, s, snap_at=(), max_nr_iterations=20000, crit_relaxat
         cases.integrate_and_step(impl, c, s, it)
         abortsum = int(s.abort.sum()) if it >= c.foreplay else 0
         condition1 = abortsum < L + 1
+        if c.physical_tstep != 0 and runtime_limit is not None:      # :941-943, with the iteration index before the increment
+            condition3 = (it + 1) * c.physical_tstep < runtime_limit
+            if not condition3:
+                reason = "runtime limit"
         if it % 100 == 0:
             condition2 = bool(c.T_lay[L] < c.plancktable_dim * c.plancktable_step - 2)
             if not condition2:
@@ -85,13 +90,22 @@ def loop_case(name):
         relax = (60,)
     elif name == "clouds_g0_i2s":
         kw.update(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0)
+    elif name == "onthefly":
+        # opacities mixed on the fly at every refresh: 4 absorbers (one CIA pair), water-vapour and H2 scattering
+        kw.update(nbin=5)
     else:
         raise KeyError(name)
     c = cases.make_case(**kw)
     if name == "noscat_relax":
         c.rad_convergence_limit = 1e-9
+    if name == "onthefly":
+        cases.add_species(c, nspecies=4)
     return c, relax
 
 
-LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s")
+def loop_refresh(c):
+    return cases.refresh_onthefly if c.get("species") else cases.refresh_premixed
+
+
+LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s", "onthefly")
 SNAP_AT = (1, 10, 11, 50)

@@ -11,8 +11,8 @@ import loop_driver as ld
 
 @pytest.mark.parametrize("name", ld.LOOP_NAMES)
 def test_oracle_loop_golden(port, name):
-    gc.check_loop(lambda c, s, relax: ld.radiation_loop(port, c, s, ld.SNAP_AT, crit_relaxation_numbers=relax)[:2],
-                  name)
+    gc.check_loop(lambda c, s, relax: ld.radiation_loop(port, c, s, ld.SNAP_AT, crit_relaxation_numbers=relax,
+                                                        refresh=ld.loop_refresh(c))[:2], name)
 
 
 @pytest.mark.parametrize("name", gc.BIG_NAMES)
