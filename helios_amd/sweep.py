@@ -251,17 +251,20 @@ def _finish_column(computer, q, reader, writer):
 def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_output=True):
     """run every column of `overrides_list` (this rank's share if `dist` is initialised); returns
     (columns of this rank as Stores, emission spectra of ALL columns [ncol_total, nbin] in sweep order)"""
-    from .parallel import gather_spectra, shard_columns
+    import os
+    from .parallel import column_list, gather_spectra
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     if world > len(overrides_list):
         raise ValueError("%d ranks for %d columns: a sweep needs at least one column per rank" % (world, len(overrides_list)))
-    lo, hi = shard_columns(len(overrides_list), rank, world)
+    # neighbours in a sweep (similar planets) converge after similar numbers of iterations: dealing the columns out in
+    # turn spreads the long-running ones over the ranks; HELIOS_SWEEP_PARTITION=block keeps contiguous blocks
+    mine_cols = column_list(len(overrides_list), rank, world, os.environ.get("HELIOS_SWEEP_PARTITION", "cyclic"))
     computer = comp.Compute()
     writer = write_mod.Write()
     shared = {}
     columns = []
-    for k in range(lo, hi):
+    for k in mine_cols:
         ov = dict(overrides_list[k])
         ov.setdefault("name", "%s_%d" % (_base_name(base_argv), k))
         q, reader = _prepare_column(base_argv, ov, shared)
@@ -302,7 +305,7 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
               % (timing["batch"], timing["loops"], timing["finish"]))
     if world > 1:
         # columns converge after different numbers of iterations: how unevenly the ranks were loaded
-        mine = dict(rank=rank, columns=hi - lo, loops=timing["loops"],
+        mine = dict(rank=rank, columns=len(mine_cols), loops=timing["loops"],
                     iterations=int(sum(int(q.iter_value or 0) for q, _ in columns)))
         every = [None] * world
         dist.all_gather_object(every, mine)
@@ -314,7 +317,7 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
                                               [e["iterations"] for e in every]))
     X = int(columns[0][0].nbin) if columns else 0
     local = np.array([np.asarray(q.F_up_band)[-X:] for q, _ in columns]).reshape(len(columns), X)
-    spectra = gather_spectra(local, dist, coll_device)
+    spectra = gather_spectra(local, dist, coll_device, columns=mine_cols)
     return [q for q, _ in columns], spectra
 
 

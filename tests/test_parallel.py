@@ -19,20 +19,29 @@ def test_shard_columns_covers_everything():
     assert shard_columns(512, 3, 8) == (192, 256)
 
 
-def _worker(rank, world, port, ncol, q):
+def test_column_lists():
+    from helios_amd.parallel import column_list
+    for mode in ("block", "cyclic"):
+        for ncol, world in ((512, 8), (10, 4), (7, 2)):
+            seen = sorted(c for r in range(world) for c in column_list(ncol, r, world, mode))
+            assert seen == list(range(ncol))
+    assert column_list(10, 1, 4, "cyclic") == [1, 5, 9] and column_list(10, 1, 4, "block") == [3, 4, 5]
+
+
+def _worker(rank, world, port, ncol, q, mode="block"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    from helios_amd.parallel import gather_spectra, shard_columns
+    from helios_amd.parallel import column_list, gather_spectra
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    a, b = shard_columns(ncol, rank, world)
-    local = np.array([[c * 100.0 + k for k in range(5)] for c in range(a, b)]).reshape(b - a, 5)
-    full = gather_spectra(local, dist)
+    cols = column_list(ncol, rank, world, mode)
+    local = np.array([[c * 100.0 + k for k in range(5)] for c in cols]).reshape(len(cols), 5)
+    full = gather_spectra(local, dist, columns=cols if mode == "cyclic" else None)
     q.put((rank, full))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ncol", [6, 7])
-def test_gather_spectra_gloo_world2(ncol):
+@pytest.mark.parametrize("ncol,mode", [(6, "block"), (7, "block"), (7, "cyclic"), (5, "cyclic")])
+def test_gather_spectra_gloo_world2(ncol, mode):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -40,7 +49,7 @@ def test_gather_spectra_gloo_world2(ncol):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, ncol, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ncol, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
