@@ -759,6 +759,11 @@ class Compute(object):
         adjustment on the host"""
         if not (quant.singlewalk == 0 and quant.convection == 1):
             return
+        if quant.iso == 1:
+            # the reference skips the stability test with isothermal layers and then sums a conv_unstable that was never
+            # built (computation.py:1004-1009, quantities.py:134: `sum(None)` raises TypeError): say what is wrong instead
+            raise IOError("ERROR: convective adjustment needs non-isothermal layers (the reference cannot run this "
+                          "combination either); set 'isothermal layers = no' or 'convective adjustment = no'")
         if self._fused_supported(quant) and quant.rt is not None and quant.physical_tstep == 0:
             return self._convection_loop_fused(quant, write, read)
         if quant.rt is not None:      # the per-stage loop continues from the fused state

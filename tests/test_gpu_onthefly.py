@@ -282,6 +282,23 @@ CONV_ARGV = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", 
              "-radiative_equilibrium_criterion", "1e-4", "-internal_temperature", "1500", "-kappa_value", "0.2"]
 
 
+def test_isothermal_layers_iterate_on_the_fused_path_and_refuse_convection(tmp_path):
+    """`isothermal layers = yes` in an iterative run: the radiation loop on the fused path ends where the per-stage loop
+    ends; with convective adjustment the reference fails with a TypeError (computation.py:1004-1009) -- here a clear
+    message"""
+    argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
+            "-number_of_layers", "24", "-maximum_number_of_iterations", "20000", "-name", "isoit",
+            "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
+            "-isothermal_layers", "yes"]
+    a = _run_driver(argv + ["-convective_adjustment", "no"], True)
+    b = _run_driver(argv + ["-convective_adjustment", "no"], False)
+    assert int(a.iso) == 1 and int(a.iter_value) == int(b.iter_value) > 3
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-8)
+    np.testing.assert_allclose(a.F_up_band, b.F_up_band, rtol=1e-7, atol=1e-12 * b.F_up_band.max())
+    with pytest.raises(IOError, match="non-isothermal"):
+        _run_driver(argv + ["-convective_adjustment", "yes"], True)
+
+
 @pytest.mark.parametrize("extra", [[], ["-direct_irradiation_beam", "yes", "-surface_albedo", "0.2"]])
 def test_convection_loop_on_device_reaches_the_host_driven_equilibrium(tmp_path, extra):
     """the convection loop with the convective adjustment on the GPU (hx_rt_conv_*) against the per-stage loop whose
