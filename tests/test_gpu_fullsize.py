@@ -324,3 +324,97 @@ def test_config2_full_size_all_bins_vs_the_reference_on_the_gpu(ctx):
         np.testing.assert_allclose(got[k], want[k], rtol=1e-10, err_msg=k)
     np.testing.assert_allclose(got["F_net"], want["F_net"], rtol=1e-9, atol=1e-12 * np.abs(want["F_up_tot"]).max())
     np.testing.assert_allclose(got["T_lay"], want["T_lay"], rtol=1e-9)
+
+
+def test_config3_full_size_all_bins_vs_the_reference_on_the_gpu(ctx):
+    """config 3 against THE REFERENCE ITSELF at full size: its opac_species_interpol + add_to_mixed_opac (one thread per
+    point, 9.6 KB of scratch, adjacent-swap sort) fold the 20 absorbers into 2.01 million (bin, level) points on this GPU,
+    then its transmission / sweep / quadrature kernels run the first iteration; every bin's mixed opacities, scattering
+    cross-sections and band fluxes are compared with the one-launch species loop of the fused path"""
+    import bench
+    import oracle
+    from impls import RefImpl
+    from helios_amd import phys_const as pc
+    from helios_amd import synthetic as syn
+    from helios_amd.rt import batch_from_case
+    lib = oracle.refgpu
+    if lib is None:
+        pytest.skip("oracle/_ref/libhelios_ref_gfx950.so not present")
+    ref = RefImpl(lib)
+    c0 = bench.build_case(bench.WORKLOADS["c3"], 20242)
+    c0.T_lay = 900.0 + 600.0 * (np.log10(np.append(c0.p_lay, c0.p_lay[0])) + 1.0) / 10.0
+    X, Y, L, I = c0.nbin, c0.ny, c0.nlayer, c0.nlayer + 1
+    c = _block_case(c0, 0, X)
+    s = cases.alloc_state(c)
+    held = []
+    for d in (c, s):
+        for k, v in list(d.items()):
+            if isinstance(v, np.ndarray) and v.nbytes > (1 << 20):
+                d[k] = lib.buf(v)
+                held.append(d[k])
+    rt = batch_from_case(ctx, c0, ncol=1, nspecies=len(c0.species))
+    try:
+        # the species loop of computation.py:1454-1501 through the reference's kernels, one table on the host at a time
+        ref.temp_inter(c.T_lay, c.T_int, I)
+        vl = np.array([np.full(L, sp["vmr"]) for sp in c0.species])
+        vi = np.array([np.full(I, sp["vmr"]) for sp in c0.species])
+        w = np.array([sp["weight"] for sp in c0.species])
+        s.meanmolmass_lay[:] = (vl * w[:, None]).sum(0) / vl.sum(0) * pc.AMU
+        s.meanmolmass_int[:] = (vi * w[:, None]).sum(0) / vi.sum(0) * pc.AMU
+        spec_l, spec_i = lib.buf(np.zeros(Y * X * I)), lib.buf(np.zeros(Y * X * I))
+        held += [spec_l, spec_i]
+        sc_l, sc_i = np.zeros(X * L), np.zeros(X * I)
+        scat_l, scat_i = np.zeros(X * L), np.zeros(X * I)
+        for k, sp in enumerate(c0.species):
+            tab = sp["pretab"]
+            if isinstance(tab, str):
+                tab = syn.ktable(np.random.default_rng(sp["table_seed"]), X, Y, c0.ktemp, c0.kpress, c0.gauss_y)
+            rt.set_species(k, tab, sp["scat"], sp["weight"], is_h2o=0, is_cia=0, in_mu=1)
+            if tab is not None:
+                d_tab = lib.buf(tab)
+                del tab
+                ref.opac_species_interpol(c.T_lay, c0.ktemp, c0.p_lay, c0.kpress, d_tab, spec_l, c0.npress, c0.ntemp, Y, X, L)
+                ref.opac_species_interpol(c.T_int, c0.ktemp, c0.p_int, c0.kpress, d_tab, spec_i, c0.npress, c0.ntemp, Y, X, I)
+                d_tab.free()
+                ref.add_to_mixed_opac(np.ascontiguousarray(vl[k]), spec_l, s.opac_wg_lay, s.meanmolmass_lay, c0.gauss_weight,
+                                      c0.gauss_y, sp["weight"] * pc.AMU, k, 1, Y, X, L)
+                ref.add_to_mixed_opac(np.ascontiguousarray(vi[k]), spec_i, s.opac_wg_int, s.meanmolmass_int, c0.gauss_weight,
+                                      c0.gauss_y, sp["weight"] * pc.AMU, k, 1, Y, X, I)
+            if sp["scat"] is not None:
+                sc_l[:], sc_i[:] = np.tile(sp["scat"], L), np.tile(sp["scat"], I)
+                ref.add_to_mixed_scat(np.ascontiguousarray(vl[k]), sc_l, scat_l, X, L)
+                ref.add_to_mixed_scat(np.ascontiguousarray(vi[k]), sc_i, scat_i, X, I)
+        s.scat_cross_lay.set(scat_l) if hasattr(s.scat_cross_lay, "set") else s.scat_cross_lay.__setitem__(slice(None), scat_l)
+        s.scat_cross_int.set(scat_i) if hasattr(s.scat_cross_int, "set") else s.scat_cross_int.__setitem__(slice(None), scat_i)
+        rt.set_column_vmr(-1, vl, vi)
+        rt.build_planck_table(1)
+        grid = rt.get("planck_grid")
+        rt.run(0, 1)
+        got = {k: rt.get(k) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int", "F_up_band",
+                                      "F_down_band", "F_net", "T_lay")}
+        # the rest of the first iteration through the reference: Planck, transmission, sweeps, quadrature, step
+        s.planck_grid.set(grid) if hasattr(s.planck_grid, "set") else s.planck_grid.__setitem__(slice(None), grid)
+        ref.planck_interpol_layer(c.T_lay, s.planckband_lay, s.planck_grid, c.starflux, c.real_star, L, X,
+                                  c.plancktable_dim, c.plancktable_step)
+        ref.planck_interpol_interface(c.T_int, s.planckband_int, s.planck_grid, I, X, c.plancktable_dim, c.plancktable_step)
+        cases.refresh_transmission(ref, c, s)
+        cases.flux_sweeps(ref, c, s)
+        cases.integrate_and_step(ref, c, s, 0)
+        want = {k: (s[k].get() if hasattr(s[k], "get") else s[k]) for k in ("opac_wg_lay", "opac_wg_int", "F_up_band",
+                                                                          "F_down_band", "F_net")}
+        want.update(scat_cross_lay=scat_l, scat_cross_int=scat_i, T_lay=c.T_lay)
+    finally:
+        rt.close()
+        for b in held:
+            if b.ptr:
+                b.free()
+    nwg = Y * X * L
+    np.testing.assert_allclose(got["opac_wg_lay"][:nwg], want["opac_wg_lay"][:nwg], rtol=5e-11)
+    np.testing.assert_allclose(got["opac_wg_int"], want["opac_wg_int"], rtol=5e-11)
+    np.testing.assert_allclose(got["scat_cross_lay"], want["scat_cross_lay"], rtol=1e-12)
+    np.testing.assert_allclose(got["scat_cross_int"], want["scat_cross_int"], rtol=1e-12)
+    for k in ("F_up_band", "F_down_band"):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-13 * want[k].max(), err_msg=k)
+    np.testing.assert_allclose(got["F_net"], want["F_net"], rtol=1e-9, atol=1e-12 * np.abs(want["F_up_band"]).max() * 1e3)
+    # the step divides F_net[i] - F_net[i+1], a difference of sums over 10 000 bins: 100 x the flux tolerance (1.1e-9 seen)
+    np.testing.assert_allclose(got["T_lay"], want["T_lay"], rtol=1e-7)
