@@ -208,6 +208,8 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.k = a.k; f.nxb = a.nxb; f.ypb = a.ypb; f.nparts = a.nparts; f.G = a.G; f.NW = a.NW;
     f.dir_beam = a.dir_beam; f.nsweep = a.nsweep; f.keep_down = a.keep_down; f.has_vp = a.has_vp;
     f.pl_vp = a.pl_vp; f.pl_dd = a.pl_dd; f.nplane = a.nplane; f.iso = a.iso;
+    static const int debug_skip = [] { const char* e = getenv("HELIOS_RT_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
+    f.debug_skip = debug_skip;
     f.Kconst = a.Kconst;
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;

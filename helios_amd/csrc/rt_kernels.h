@@ -51,7 +51,7 @@ struct KArgs {
 struct FluxArgs {
     int X, Y, L, I, H;
     int k, nxb, ypb, nparts, G, NW;
-    int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane, iso;
+    int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane, iso, debug_skip;
     double Kconst;
     const hx_rt_column* colpar;
     const double *Bn, *coef, *U0_in, *boaK, *Fdir0, *surf_albedo, *gauss_w;
@@ -228,15 +228,22 @@ struct LaneMap {
     size_t tile;      // index of this lane's wavefront tile within the column
 };
 
+// threadIdx.x behind an optimisation barrier: what is derived from it is recomputed where it is used instead of being
+// carried (and, in a kernel at the register limit, spilled to scratch) across the sweeps
+__device__ __forceinline__ int opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // workgroup bx covers bins [bx*nxb, (bx+1)*nxb) and walks the nparts groups of ypb Gauss points
 template <class Args>
-__device__ __forceinline__ LaneMap lane_map(const Args& a, int bx, int part) {
+__device__ __forceinline__ LaneMap lane_map(const Args& a, int bx, int part, int tid) {
     LaneMap m;
-    const int tid = threadIdx.x;
     m.lane = tid & 63;
     m.wv = tid >> 6;
-    m.j = m.lane % a.k;
-    const int s_local = tid / a.k;
+    m.j = m.lane & (a.k - 1);                       // k is a power of two (choose_workgroup)
+    const int s_local = tid >> (31 - __clz(a.k));
     m.xl = s_local / a.ypb;
     m.yl = s_local - m.xl * a.ypb;
     m.x = bx * a.nxb + m.xl;
@@ -520,7 +527,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     __syncthreads();
 
     for (int part = 0; part < a.nparts; part++) {
-        const LaneMap m = lane_map(a, bx, part);
+        const LaneMap m = lane_map(a, bx, part, opaque_tid());
         // coefficient planes and up-flux state -> registers.  The tiles are streamed once per launch: non-temporal
         // loads AND stores together keep them from displacing the node and band arrays the neighbouring kernels and
         // the next workgroups find in the L2 (same-box A/B: k_rt_flux 400 -> 386 us, k_rt_nodes 16 -> 14.4,
@@ -550,6 +557,9 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             Fdir0 = a.Fdir0[col * nc + m.sp];
             albedo = a.surf_albedo[(size_t)col * a.X + m.x];
         }
+        // the quadrature weight is requested here, with the tiles: asked for after the sweeps it was a dependent load
+        // into a saturated memory system, several microseconds per tile with nothing to hide behind
+        const double w = m.valid ? 0.5 * a.gauss_w[m.y] : 0.0;
         const double* Bx = sB + (size_t)(m.valid ? m.xl : 0) * NN;
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
@@ -642,42 +652,64 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             }
         }
 
-        // state back to HBM
+        // Gauss quadrature of the interface fluxes: stage[yl][xl][dir][i], summed over yl in order.
+        // The lane map is derived afresh (e for "epilogue"): carried across the sweeps it lived in scratch
+        const LaneMap e = lane_map(a, bx, part, opaque_tid());
+        auto store_state = [&]() {
+            const size_t eoff = e.tile * (size_t)ROWS * 64 + e.lane;
+            if (!(a.debug_skip & 2)) {
+                double* ut = a.Utile + col * a.flux_col + eoff;
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store(Uo[r], utile + r * 64);
-        if (a.keep_down) {
-            double* dtile = a.Dtile + col * a.flux_col + toff;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store(Do[r], dtile + r * 64);
-        }
-        if (m.valid && m.j == 0) a.U0[col * nc + m.sp] = U0;
-
-        // Gauss quadrature of the interface fluxes: stage[yl][xl][dir][i], summed over yl in order
-        if (m.valid) {
-            const double w = 0.5 * a.gauss_w[m.y];
-            double* st = stage + ((size_t)m.yl * a.nxb + m.xl) * 2 * I;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const int h = m.j * ROWS + r;
-                if (h < a.H) {
-                    if (a.iso) {                                        // every node is an interface
-                        st[h] = w * Do[r];
-                        st[I + h + 1] = w * Uo[r];
-                    } else if ((h & 1) == 0) st[h >> 1] = w * Do[r];    // D at interface h/2
-                    else st[I + ((h + 1) >> 1)] = w * Uo[r];            // U at interface (h+1)/2
-                }
+                for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store(Uo[r], ut + r * 64);
             }
-            if (m.j == 0) st[I + 0] = w * U0;
-            if (m.j * ROWS <= a.H - 1 && a.H - 1 < (m.j + 1) * ROWS) st[a.L] = w * D_toa;
+            if (a.keep_down) {
+                double* dtile = a.Dtile + col * a.flux_col + eoff;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store(Do[r], dtile + r * 64);
+            }
+            if (e.valid && e.j == 0) a.U0[col * nc + e.sp] = U0;
+        };
+        if (!(a.debug_skip & 1)) {  // profiling only (HELIOS_RT_DEBUG_SKIP): bit 0 no quadrature, bit 1 no state stores
+            if (e.valid) {
+                // Row r of this lane is node h = h0 + r.  Staggered grid: an even node gives D at interface h/2, an odd
+                // one U at interface (h+1)/2 -- with the lane's parity p folded into two base pointers the rows use
+                // compile-time offsets (26 separately computed LDS addresses did not fit the register file: they were
+                // reloaded from scratch, one memory round trip per row and tile)
+                const int h0 = e.j * ROWS, nrow = a.H - h0;
+                double* st = stage + ((size_t)e.yl * a.nxb + e.xl) * 2 * I;
+                if (a.iso) {                                            // every node is an interface
+                    double *pd = st + h0, *pu = st + I + h0 + 1;
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++)
+                        if (r < nrow) {
+                            pd[r] = w * Do[r];
+                            pu[r] = w * Uo[r];
+                        }
+                } else {
+                    const bool p = h0 & 1;
+                    const int q = (h0 + (p ? 1 : 0)) >> 1;
+                    double* pe = st + q + (p ? I : 0);                  // rows 0, 2, ...: D (p = 0) or U (p = 1)
+                    double* po = st + q + (p ? -1 : I);                 // rows 1, 3, ...: U (p = 0) or D (p = 1)
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++)
+                        if (r < nrow) {
+                            if ((r & 1) == 0) pe[r >> 1] = w * (p ? Uo[r] : Do[r]);
+                            else po[(r + 1) >> 1] = w * (p ? Do[r] : Uo[r]);
+                        }
+                }
+                if (e.j == 0) st[I + 0] = w * U0;
+                if (h0 <= a.H - 1 && a.H - 1 < h0 + ROWS) st[a.L] = w * D_toa;
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
+                const int xl = t / (2 * I), rest = t - xl * 2 * I;
+                double s = acc[t];
+                for (int yl = 0; yl < a.ypb; yl++) s += stage[((size_t)yl * a.nxb + xl) * 2 * I + rest];
+                acc[t] = s;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
-            const int xl = t / (2 * I), rest = t - xl * 2 * I;
-            double s = acc[t];
-            for (int yl = 0; yl < a.ypb; yl++) s += stage[((size_t)yl * a.nxb + xl) * 2 * I + rest];
-            acc[t] = s;
-        }
-        __syncthreads();
+        store_state();
     }
     // band fluxes of this workgroup's bins, internal layout [x][i]
     for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) {
