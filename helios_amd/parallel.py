@@ -1,8 +1,8 @@
 """Multi-GPU layer: independent atmosphere columns are partitioned over the ranks (one process per GPU) -- in
 contiguous blocks (`shard_columns`) or dealt out in turn (`column_list(..., "cyclic")`: neighbours in a parameter sweep
-need similar numbers of iterations, so dealing them out evens the load without any exchange); the iteration path has
-NO collective.  The only exchange is one gather of the output spectra at the
-end of a run, done with torch.distributed -- backend "nccl" is RCCL over xGMI on ROCm,
+need similar numbers of iterations, so dealing them out evens the load without any exchange) or claimed chunk by chunk
+from a shared work list as a rank retires the columns it holds (`WorkList`); the iteration path has NO collective.
+The only exchange is one gather of the output spectra at the end of a run, done with torch.distributed -- backend "nccl" is RCCL over xGMI on ROCm,
 "gloo" is used by the CPU tests.  The reference has no counterpart (single process, single device).
 """
 import numpy as np
@@ -26,6 +26,37 @@ def column_list(ncol_total, rank, world, mode="block"):
     return list(range(a, b))
 
 
+class WorkList:
+    """The columns of a sweep as a shared work list: ranks claim the next `chunk` columns when they have retired the
+    ones they hold, so a rank whose columns converge early takes over work from the others.  A claim
+    is one atomic add on the process group's key-value store (the TCP store torch.distributed.run already provides) --
+    a host-side counter, not a collective: no rank ever waits for another.  Without a process group the list is local."""
+
+    KEY = "helios_amd/worklist/next"
+
+    def __init__(self, ncol_total, chunk, dist=None, store=None, key=None):
+        self.ncol = int(ncol_total)
+        self.chunk = max(1, int(chunk))
+        self.key = key or self.KEY
+        self._local_next = 0
+        self.store = store
+        if self.store is None and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.distributed import distributed_c10d as c10d
+            self.store = c10d._get_default_store()
+        self.claimed = []
+
+    def claim(self):
+        """the next columns of this rank (ascending, at most `chunk`), or [] when the list is exhausted"""
+        if self.store is not None:
+            start = int(self.store.add(self.key, self.chunk)) - self.chunk
+        else:
+            start = self._local_next
+            self._local_next += self.chunk
+        cols = list(range(start, min(start + self.chunk, self.ncol)))
+        self.claimed += cols
+        return cols
+
+
 def gather_spectra(local, dist=None, device=None, columns=None):
     """all-gather per-column output vectors: local [ncol_local, n] -> [ncol_total, n] on every rank.
     Column counts may differ between ranks (padding to the maximum, then trimming).  `columns`: the global indices of
@@ -36,11 +67,15 @@ def gather_spectra(local, dist=None, device=None, columns=None):
     import torch
     world = dist.get_world_size()
     dev = device if device is not None else "cpu"
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev))
-    counts = [int(c.item()) for c in counts]
+    shapes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(shapes, torch.tensor([local.shape[0], local.shape[1] if local.ndim == 2 else 0],
+                                         dtype=torch.int64, device=dev))
+    counts = [int(c[0].item()) for c in shapes]
+    width = max(int(c[1].item()) for c in shapes)       # a rank of a dynamic sweep may have claimed nothing
+    if local.shape[0] == 0:
+        local = np.zeros((0, width))
     nmax = max(counts)
-    pad = np.zeros((nmax, local.shape[1] + 1))          # last entry of a row: its global column index
+    pad = np.zeros((nmax, width + 1))                   # last entry of a row: its global column index
     pad[:local.shape[0], :-1] = local
     pad[:local.shape[0], -1] = -1.0 if columns is None else np.asarray(columns, np.float64)
     mine = torch.from_numpy(pad).to(dev)

@@ -248,36 +248,23 @@ def _finish_column(computer, q, reader, writer):
         setattr(q, name, None)
 
 
-def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_output=True):
-    """run every column of `overrides_list` (this rank's share if `dist` is initialised); returns
-    (columns of this rank as Stores, emission spectra of ALL columns [ncol_total, nbin] in sweep order)"""
-    import os
-    from .parallel import column_list, gather_spectra
-    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    if world > len(overrides_list):
-        raise ValueError("%d ranks for %d columns: a sweep needs at least one column per rank" % (world, len(overrides_list)))
-    # neighbours in a sweep (similar planets) converge after similar numbers of iterations: dealing the columns out in
-    # turn spreads the long-running ones over the ranks; HELIOS_SWEEP_PARTITION=block keeps contiguous blocks
-    mine_cols = column_list(len(overrides_list), rank, world, os.environ.get("HELIOS_SWEEP_PARTITION", "cyclic"))
-    computer = comp.Compute()
-    writer = write_mod.Write()
-    shared = {}
-    columns = []
-    for k in mine_cols:
+def _run_columns(base_argv, overrides_list, cols, computer, writer, shared, columns, timing, write_output):
+    """prepare the columns `cols`, run them as device batches (one per batch signature) to the end of both loops, write
+    their files and append them to `columns`"""
+    import time
+    fresh = []
+    for k in cols:
         ov = dict(overrides_list[k])
         ov.setdefault("name", "%s_%d" % (_base_name(base_argv), k))
         q, reader = _prepare_column(base_argv, ov, shared)
         q._ctx = computer.ctx
         q.sweep_index = k
-        columns.append((q, reader))
+        fresh.append((q, reader))
     groups = {}
-    for q, reader in columns:
+    for q, reader in fresh:
         if not computer._fused_supported(q):
             raise IOError("sweeps run on the fused path: iterative run type, non-isothermal layers, flux iteration method")
         groups.setdefault(_batch_signature(q), []).append((q, reader))
-    import time
-    timing = dict(batch=0.0, loops=0.0, finish=0.0)
     for members in groups.values():
         quants = [q for q, _ in members]
         t0 = time.perf_counter()
@@ -300,6 +287,42 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
         for q in quants:
             q.rt = None
         rt.close()
+    columns += fresh
+
+
+def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_output=True):
+    """run every column of `overrides_list` (this rank's share if `dist` is initialised); returns
+    (columns of this rank as Stores, emission spectra of ALL columns [ncol_total, nbin] in sweep order)"""
+    import os
+    from .parallel import column_list, gather_spectra
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if world > len(overrides_list):
+        raise ValueError("%d ranks for %d columns: a sweep needs at least one column per rank" % (world, len(overrides_list)))
+    # neighbours in a sweep (similar planets) converge after similar numbers of iterations: dealing the columns out in
+    # turn spreads the long-running ones over the ranks; HELIOS_SWEEP_PARTITION=block keeps contiguous blocks
+    # HELIOS_SWEEP_PARTITION=dynamic[:chunk]: a shared work list instead -- every rank claims `chunk` columns (default:
+    # an eighth of its even share), runs them as one batch, retires them and claims again until the list is empty
+    mode = os.environ.get("HELIOS_SWEEP_PARTITION", "cyclic")
+    computer = comp.Compute()
+    writer = write_mod.Write()
+    shared = {}
+    columns = []
+    import time
+    timing = dict(batch=0.0, loops=0.0, finish=0.0)
+    if mode.startswith("dynamic"):
+        from .parallel import WorkList
+        chunk = int(mode.split(":")[1]) if ":" in mode else max(1, len(overrides_list) // (8 * world))
+        work = WorkList(len(overrides_list), chunk, dist)
+        claims = iter(work.claim, [])
+        mine_cols = work.claimed
+    else:
+        claims = iter([column_list(len(overrides_list), rank, world, mode)])
+        mine_cols = None
+    for claimed in claims:
+        _run_columns(base_argv, overrides_list, claimed, computer, writer, shared, columns, timing, write_output)
+    if mine_cols is None:
+        mine_cols = [q.sweep_index for q, _ in columns]
     if rank == 0:
         print("\nSweep timing [s]: batch set-up %.2f, iteration loops %.2f, diagnostics + output files %.2f"
               % (timing["batch"], timing["loops"], timing["finish"]))
@@ -319,6 +342,12 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
     local = np.array([np.asarray(q.F_up_band)[-X:] for q, _ in columns]).reshape(len(columns), X)
     spectra = gather_spectra(local, dist, coll_device, columns=mine_cols)
     return [q for q, _ in columns], spectra
+
+
+def wavelength_grid(base_argv, overrides):
+    """the wavelength grid of a sweep, for a rank that ran none of its columns"""
+    q, _ = _prepare_column(base_argv, dict(overrides), {})
+    return q.opac_wave
 
 
 def _base_name(argv):

@@ -38,8 +38,9 @@ def main(argv=None):
     overrides = sw.expand_sweep(spec)
     columns, spectra = sw.run_sweep(base, overrides, dist, coll_device)
     rank = dist.get_rank() if dist is not None else 0
-    if rank == 0 and columns:
-        q = columns[0]
+    if rank == 0:
+        # (with HELIOS_SWEEP_PARTITION=dynamic the other ranks may have retired every column before rank 0 claimed one)
+        wavelength = columns[0].opac_wave if columns else sw.wavelength_grid(base, overrides[0])
         out_dir = None
         for i, a in enumerate(base):
             if a == "-output_directory":
@@ -48,7 +49,7 @@ def main(argv=None):
         os.makedirs(out_dir, exist_ok=True)
         keys = sorted({k_ for o in overrides for k_ in o})
         np.savez(os.path.join(out_dir, sw._base_name(base) + "_sweep_spectra.npz"), F_up_TOA=spectra,
-                 wavelength=np.asarray(q.opac_wave), **{"param_" + k_: np.array([str(o.get(k_, "")) for o in overrides])
+                 wavelength=np.asarray(wavelength), **{"param_" + k_: np.array([str(o.get(k_, "")) for o in overrides])
                                                         for k_ in keys})
         print("\nSweep of %d columns on %d GPU(s) finished." % (len(overrides), world))
     if dist is not None:

@@ -449,6 +449,35 @@ def test_sweep_with_convection_and_two_ranks(tmp_path):
         assert os.path.getsize(os.path.join(str(tmp_path), "two", "cvs_%d" % k, "cvs_%d_tp.dat" % k)) > 100
 
 
+def test_sweep_from_a_shared_work_list_on_two_ranks(tmp_path):
+    """HELIOS_SWEEP_PARTITION=dynamic:1 -- two ranks (gloo hook: both on GPU 0) claim the six columns one at a time from
+    the shared list, each column runs in a batch of its own: same spectra, in sweep order, as the one-batch sweep; every
+    column's files are there exactly once"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "20 6 5 11",
+            "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "wl",
+            "-radiative_equilibrium_criterion", "1e-4", "-convective_adjustment", "no"]
+    spec = "internal_temperature=150,600,1100;f_factor=0.25,0.5"
+    import sweep
+    cols, spectra = sweep.main(["-sweep", spec] + base + ["-output_directory", str(tmp_path) + "/one/"])
+    assert len({int(c.iter_value) for c in cols}) > 1           # the columns do need different numbers of iterations
+    env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo", HELIOS_SWEEP_PARTITION="dynamic:1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29527", "sweep.py", "-sweep", spec] + base +
+                       ["-output_directory", str(tmp_path) + "/two/"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "Load over 2 ranks" in p.stdout
+    z = np.load(os.path.join(str(tmp_path), "two", "wl_sweep_spectra.npz"))
+    np.testing.assert_allclose(z["F_up_TOA"], spectra, rtol=1e-12)
+    for k in range(6):
+        a = open(os.path.join(str(tmp_path), "one", "wl_%d" % k, "wl_%d_tp.dat" % k)).read()
+        b = open(os.path.join(str(tmp_path), "two", "wl_%d" % k, "wl_%d_tp.dat" % k)).read()
+        assert a == b, k
+
+
 def test_sweep_with_kappa_table_equals_single_runs(tmp_path):
     """`kappa value = file` inside a sweep: kappa and c_p are interpolated at each column's own profile before the
     convective-stability check (as a single run does), and the output files report them"""

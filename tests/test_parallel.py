@@ -69,3 +69,54 @@ def test_expand_sweep():
     import pytest
     with pytest.raises(ValueError):
         expand_sweep("number_of_layers=10,20")        # changes the batch itself, cannot vary inside it
+
+
+def test_work_list_without_a_process_group():
+    from helios_amd.parallel import WorkList
+    w = WorkList(7, 3)
+    got = list(iter(w.claim, []))
+    assert got == [[0, 1, 2], [3, 4, 5], [6]] and w.claimed == list(range(7))
+
+
+def _worklist_worker(rank, world, port, ncol, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as dist
+    from helios_amd.parallel import WorkList, gather_spectra
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    work = WorkList(ncol, chunk, dist)
+    for cols in iter(work.claim, []):
+        time.sleep(0.02 * (1 + 4 * rank) * len(cols))       # rank 1 is five times slower per column
+    cols = work.claimed
+    local = np.array([[c * 100.0 + k for k in range(5)] for c in cols]).reshape(len(cols), 5)
+    full = gather_spectra(local, dist, columns=cols)
+    q.put((rank, cols, full))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ncol,chunk", [(23, 2), (3, 8)])
+def test_work_list_gloo_world2(ncol, chunk):
+    """two ranks claim chunks from the shared list until it is empty: every column exactly once, the faster rank retires
+    more of them, and the spectra still come back in sweep order (also when one rank got nothing)"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worklist_worker, args=(r, 2, port, ncol, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in procs:
+        rank, cols, full = q.get(timeout=120)
+        res[rank] = (cols, full)
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res[0][0] + res[1][0]) == list(range(ncol))
+    if ncol > chunk:
+        assert len(res[0][0]) > len(res[1][0]) > 0
+    want = np.array([[c * 100.0 + k for k in range(5)] for c in range(ncol)])
+    for rank in res:
+        np.testing.assert_array_equal(res[rank][1], want)
