@@ -82,6 +82,7 @@ struct hx_rt {
     double *mmm_lay = nullptr, *mmm_int = nullptr;                                    // I each
     double *cl_abs_lay = nullptr, *cl_abs_int = nullptr, *cl_sc_lay = nullptr, *cl_sc_int = nullptr,
            *cl_g0_lay = nullptr, *cl_g0_int = nullptr, *g0_tot_lay = nullptr, *g0_tot_int = nullptr;  // X*I
+    double *half_ray = nullptr, *half_g0 = nullptr, *half_cab = nullptr, *half_csc = nullptr;  // X*H, bin-major
     double *vmr_lay = nullptr, *vmr_int = nullptr;                                    // nspecies*I
     double *delta_z = nullptr, *z_lay = nullptr;                                      // L
     double *dtau_u = nullptr, *dtau_l = nullptr;                                      // Y*X*L (beam only)

@@ -139,6 +139,7 @@ KArgs make_args(hx_rt* rt) {
     a.mmm_lay = rt->mmm_lay; a.mmm_int = rt->mmm_int;
     a.cl_abs_lay = rt->cl_abs_lay; a.cl_abs_int = rt->cl_abs_int; a.cl_sc_lay = rt->cl_sc_lay;
     a.cl_sc_int = rt->cl_sc_int; a.g0_tot_lay = rt->g0_tot_lay; a.g0_tot_int = rt->g0_tot_int;
+    a.half_ray = rt->half_ray; a.half_g0 = rt->half_g0; a.half_cab = rt->half_cab; a.half_csc = rt->half_csc;
     a.F_dir_wg = rt->F_dir_wg; a.Fc_dir_wg = rt->Fc_dir_wg; a.F_dir_band_n = rt->F_dir_band_n;
     a.gauss_w = rt->gauss_w; a.deltawave = rt->deltawave;
     a.diag = rt->f.debug == 1 ? rt->ctx->diag : nullptr;
@@ -228,7 +229,10 @@ void launch_coef_tpb(hx_rt* rt, KArgs a) {
     const int TS = TPB * g.S, TSP = TS;
     const int NBX = g.nxb * ((TPB - 1) / (g.NW * g.nparts) + 2);
     a.coef_nbx = NBX;
-    const size_t shmem = ((size_t)(rt->L + rt->I) * TSP + (size_t)rt->H * (NBX + 2)) * sizeof(double) + 2 * TS * sizeof(int);
+    size_t shmem = ((size_t)(rt->L + rt->I) * TSP + (size_t)rt->H * (NBX + 2)) * sizeof(double) + 2 * TS * sizeof(int);
+    const size_t cloud_image = 3 * (size_t)rt->H * NBX * sizeof(double);
+    a.cloud_lds = a.clouds == 1 && shmem + cloud_image <= 80 * 1024;  // keep two workgroups per CU
+    if (a.cloud_lds) shmem += cloud_image;
     if (shmem > 64 * 1024 && !rt->coef_shmem_raised) {
         (void)hipFuncSetAttribute((const void*)k_rt_coef<ROWS, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)shmem);
@@ -333,6 +337,9 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
     rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
+    // tiles per workgroup of k_rt_coef: 16 spectral points staged side by side (128-byte runs of the k-table) -- 4 tiles
+    // at k = 16, 8 at k = 32 (config 5, same box: 2 tiles 6.4 ms, 4 tiles 4.5 ms, 8 tiles 3.4 ms per refresh)
+    rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
@@ -357,6 +364,10 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
         RT_ALLOC(rt->cl_g0_lay, C * X * I); RT_ALLOC(rt->cl_g0_int, C * X * I);
     }
     RT_ALLOC(rt->g0_tot_lay, C * X * I); RT_ALLOC(rt->g0_tot_int, C * X * I);
+    RT_ALLOC(rt->half_ray, C * X * rt->H);
+    if (flags->clouds) {
+        RT_ALLOC(rt->half_g0, C * X * rt->H); RT_ALLOC(rt->half_cab, C * X * rt->H); RT_ALLOC(rt->half_csc, C * X * rt->H);
+    }
     if (dims->nspecies > 0) {
         RT_ALLOC(rt->vmr_lay, C * dims->nspecies * I); RT_ALLOC(rt->vmr_int, C * dims->nspecies * I);
         RT_ALLOC(rt->spec_lay, nc * I); RT_ALLOC(rt->spec_int, nc * I);
@@ -743,6 +754,8 @@ int hx_rt_refresh(hx_rt* rt) {
     }
     {
         ProfScope ps(rt, "rt_coef");
+        k_rt_half_bands<<<dim3(hx_cdiv(X, 32), hx_cdiv(rt->H, 32), C), 256, 0, ctx->stream>>>(a);
+        HX_LAUNCH_CHECK(ctx);
         a.from_table = fused_lookup ? 1 : 0;
         DISPATCH_ROWS(launch_coef, rt, a);
         HX_LAUNCH_CHECK(ctx);

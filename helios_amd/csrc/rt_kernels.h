@@ -23,6 +23,7 @@ namespace hx {
 struct KArgs {
     int X, Y, L, I, H, C;
     int k, ROWS, S, nxb, ypb, nparts, G, NW, nblk_x, nblk, nplane, nchunk, coef_nbx;
+    int cloud_lds;             // k_rt_coef stages the clouds' half-layer terms in LDS (when they fit)
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
     int iso;                   // isothermal layers: H = L segments between the interfaces, one coefficient set per layer
     int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
@@ -33,6 +34,7 @@ struct KArgs {
     const double *T_lay, *p_lay, *p_int, *dcol_u, *dcol_l, *surf_albedo, *Bstar, *planck_grid;
     const double *opac_wg_lay, *opac_wg_int, *scat_cross_lay, *scat_cross_int, *mmm_lay, *mmm_int;
     const double *cl_abs_lay, *cl_abs_int, *cl_sc_lay, *cl_sc_int, *g0_tot_lay, *g0_tot_int;
+    double *half_ray, *half_g0, *half_cab, *half_csc;  // [C][X][H] half-layer band quantities, bin-major (k_rt_half_bands)
     const double *F_dir_wg, *Fc_dir_wg, *F_dir_band_n, *gauss_w, *deltawave;
     double *T_int, *Bn, *coef, *Utile, *Dtile, *U0, *boaK, *Fdir0;
     double *dtau_u, *dtau_l;
@@ -254,6 +256,45 @@ __device__ __forceinline__ LaneMap lane_map(const Args& a, int bx, int part, int
     return m;
 }
 
+// ---- per refresh: band quantities of the half-layers, bin-major ---------------------------------
+// grid (ceil(X/32), ceil(H/32), C), 256 threads.  The band arrays are level-major ([i][x], the reference's layout); a
+// workgroup of k_rt_coef needs ALL half-layers of one or two bins, which there is one 64-byte sector per double.  This
+// transposes them once per refresh (32 x 32 tiles through LDS) into [x][h] rows that k_rt_coef stages with unit stride:
+// Rayleigh cross-section and, with clouds, asymmetry parameter, absorption and scattering cross-sections -- the
+// half-layer averages of calc_trans_noniso (kernels.cu:1131-1177), or the layer values themselves (calc_trans_iso).
+__global__ void __launch_bounds__(256) k_rt_half_bands(KArgs a) {
+    __shared__ double tile[4][32][33];
+    const int col = blockIdx.z;
+    if (a.done[col]) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t bandI = (size_t)a.X * a.I;
+    const double* src_i[4] = {a.scat_cross_int + col * bandI, a.g0_tot_int + col * bandI, a.cl_abs_int + col * bandI,
+                              a.cl_sc_int + col * bandI};
+    const double* src_l[4] = {a.scat_cross_lay + col * bandI, a.g0_tot_lay + col * bandI, a.cl_abs_lay + col * bandI,
+                              a.cl_sc_lay + col * bandI};
+    double* dst[4] = {a.half_ray, a.half_g0, a.half_cab, a.half_csc};
+    const int nq = a.clouds == 1 ? 4 : 1;
+    const int x = blockIdx.x * 32 + tx;
+    for (int hh = ty; hh < 32; hh += 8) {
+        const int h = blockIdx.y * 32 + hh;
+        if (x < a.X && h < a.H) {
+            const int i = a.iso ? h : h >> 1, ii = a.iso ? h : i + (h & 1);
+            const size_t b_l = x + (size_t)a.X * i, b_i = x + (size_t)a.X * ii;
+            for (int q = 0; q < nq; q++) {
+                const bool on = q == 1 || q == 2 || a.scat == 1;  // Rayleigh and cloud scattering only with scat = 1
+                tile[q][hh][tx] = !on ? 0.0 : a.iso ? src_l[q][b_l] : (src_i[q][b_i] + src_l[q][b_l]) / 2.0;
+            }
+        }
+    }
+    __syncthreads();
+    const int h = blockIdx.y * 32 + tx;
+    for (int xx = ty; xx < 32; xx += 8) {
+        const int xo = blockIdx.x * 32 + xx;
+        if (xo < a.X && h < a.H)
+            for (int q = 0; q < nq; q++) dst[q][((size_t)col * a.X + xo) * a.H + h] = tile[q][tx][xx];
+    }
+}
+
 // ---- per refresh: compact coefficient tiles ---------------------------------------------------
 // grid (ceil(ntiles / COEF_TPB), C), COEF_TPB wavefronts per workgroup, one tile each.  The opacities
 // live in the reference's layout [y + ny*x + ny*nbin*level] (level slowest), so the spectral points of
@@ -275,7 +316,15 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     double* sh_ray = sh_int + (size_t)a.I * TSP;    // [H][NBX]  Rayleigh cross-section of the half-layers
     double* sh_mu = sh_ray + (size_t)a.H * NBX;     // [H]       mean molecular mass of the half-layers
     double* sh_dc = sh_mu + a.H;                    // [H]       column mass of the half-layers
-    int* c_of_q = (int*)(sh_dc + a.H);              // [TS] global spectral-point index or -1
+    // clouds: asymmetry parameter, absorption and scattering cross-sections of the half-layers, [H][NBX] each.  They do
+    // not depend on the Gauss point; read per lane from the band arrays (level-strided: one 64-byte sector per double)
+    // they were 18 scattered loads per half-layer -- config 5's k_rt_coef 7.4 ms per refresh against 2.9 ms expected
+    // from config 2's rate
+    const size_t ncl = a.cloud_lds ? (size_t)a.H * NBX : 0;
+    double* sh_g0 = sh_dc + a.H;
+    double* sh_cab = sh_g0 + ncl;
+    double* sh_csc = sh_cab + ncl;
+    int* c_of_q = (int*)(sh_csc + ncl);             // [TS] global spectral-point index or -1
     int* x_of_q = c_of_q + TS;
     const size_t nc = (size_t)a.Y * a.X;
     const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
@@ -313,14 +362,16 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 sh_dc[h] = (h & 1) ? dcu[i] : dcl[i];
             }
         }
-        const double* scl_g = a.scat_cross_lay + col * bandI;
-        const double* sci_g = a.scat_cross_int + col * bandI;
+        // bin-major rows written by k_rt_half_bands: consecutive threads read consecutive half-layers of a bin
         for (int t = threadIdx.x; t < a.H * NBX; t += blockDim.x) {
-            const int h = t / NBX, xs = t - h * NBX, x = min(x_base + xs, a.X - 1);
-            const int i = a.iso ? h : h >> 1, ii = a.iso ? h : i + (h & 1);
-            double v = 0.0;
-            if (a.scat == 1) v = a.iso ? scl_g[x + (size_t)a.X * i] : (sci_g[x + (size_t)a.X * ii] + scl_g[x + (size_t)a.X * i]) / 2.0;
-            sh_ray[t] = v;
+            const int xs = t / a.H, h = t - xs * a.H, x = min(x_base + xs, a.X - 1);
+            const size_t src = ((size_t)col * a.X + x) * a.H + h;
+            sh_ray[(size_t)h * NBX + xs] = a.half_ray[src];
+            if (a.cloud_lds) {
+                sh_g0[(size_t)h * NBX + xs] = a.half_g0[src];
+                sh_cab[(size_t)h * NBX + xs] = a.half_cab[src];
+                sh_csc[(size_t)h * NBX + xs] = a.half_csc[src];
+            }
         }
     }
     __syncthreads();
@@ -388,29 +439,18 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             // lower half averages (interface i, centre i); upper half (centre i, interface i+1); isothermal layers take
             // the layer-centre values as they are
             const int ii = lower ? i : i + 1;
-            const size_t b_l = x + (size_t)a.X * i, b_i = x + (size_t)a.X * ii;
             double g0 = a.g_0, ray = 0.0, csc = 0.0, cab = 0.0;
-            if (a.clouds == 1) {
-                const double* gl = a.g0_tot_lay + col * bandI;
-                const double* gi = a.g0_tot_int + col * bandI;
-                const double* al = a.cl_abs_lay + col * bandI;
-                const double* ai = a.cl_abs_int + col * bandI;
-                if (a.iso) {
-                    g0 = gl[b_l];
-                    cab = al[b_l];
-                } else {
-                    g0 = lower ? (gi[b_i] + gl[b_l]) / 2.0 : (gl[b_l] + gi[b_i]) / 2.0;
-                    cab = lower ? (ai[b_i] + al[b_l]) / 2.0 : (al[b_l] + ai[b_i]) / 2.0;
-                }
+            if (a.cloud_lds) {
+                g0 = sh_g0[(size_t)h * NBX + xs];
+                cab = sh_cab[(size_t)h * NBX + xs];
+                csc = sh_csc[(size_t)h * NBX + xs];
+            } else if (a.clouds == 1) {  // the staged image would not fit the LDS: from the bin-major rows
+                const size_t src = ((size_t)col * a.X + x) * a.H + h;
+                g0 = a.half_g0[src];
+                cab = a.half_cab[src];
+                csc = a.half_csc[src];
             }
-            if (a.scat == 1) {
-                ray = sh_ray[(size_t)h * NBX + xs];
-                if (a.clouds == 1) {
-                    const double* sl = a.cl_sc_lay + col * bandI;
-                    const double* si = a.cl_sc_int + col * bandI;
-                    csc = a.iso ? sl[b_l] : (lower ? (si[b_i] + sl[b_l]) / 2.0 : (sl[b_l] + si[b_i]) / 2.0);
-                }
-            }
+            if (a.scat == 1) ray = sh_ray[(size_t)h * NBX + xs];
             const double o_l = sh_lay[(size_t)i * TSP + q], o_i = a.iso ? o_l : sh_int[(size_t)ii * TSP + q];
             const double kap = a.iso ? o_l : (lower ? (o_i + o_l) / 2.0 : (o_l + o_i) / 2.0);
             const double mu = sh_mu[h], dcol = sh_dc[h];
