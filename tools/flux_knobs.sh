@@ -7,6 +7,6 @@ for i in $(seq $REPS); do
   for v in "$@"; do
     skip=${v%%:*}; ns=${v#*:}; [ "$ns" = "$v" ] && ns=""
     echo -n "skip=$skip nsweep=${ns:-4}: "
-    HELIOS_RT_DEBUG_SKIP=$skip ${ns:+HELIOS_RT_DEBUG_NSWEEP=$ns} python3 $R/tools/step_profile.py 2>&1 | tail -1 | cut -c1-140
+    env HELIOS_RT_DEBUG_SKIP=$skip ${ns:+HELIOS_RT_DEBUG_NSWEEP=$ns} python3 $R/tools/step_profile.py 2>&1 | tail -1 | cut -c1-140
   done
 done
