@@ -20,9 +20,9 @@ __device__ __forceinline__ double planck_term(int n, double y1, double y2) {
                             6.0 * y1 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn));
 }
 
-__global__ void __launch_bounds__(256)
-k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
-              const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T, int step) {
+__device__ __forceinline__ void planck_row_entry(double* __restrict__ grid, const double* __restrict__ lambda_edge,
+                                                 const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T,
+                                                 int step) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y;
     if (x >= nbin) return;
@@ -41,6 +41,19 @@ k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
         for (int n = 1; n < 200; n++) acc += D * planck_term(n, y_bot, y_top);
     }
     grid[x + (size_t)r * nbin] = acc / dlambda[x];
+}
+
+__global__ void __launch_bounds__(256)
+k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
+              const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T, int step) {
+    planck_row_entry(grid, lambda_edge, dlambda, nbin, Tstar, nrow_T, step);
+}
+
+// one row at the stellar temperature (a name of its own, so that kernel statistics do not average it with the table)
+__global__ void __launch_bounds__(256)
+k_planck_star_row(double* __restrict__ row, const double* __restrict__ lambda_edge,
+                  const double* __restrict__ dlambda, int nbin, double Tstar) {
+    planck_row_entry(row, lambda_edge, dlambda, nbin, Tstar, 0, 1);
 }
 
 // incident-energy correction (kernels.cu:420-468): ONE block sums dlambda*F over all bins in a
@@ -163,8 +176,7 @@ int hx_plancktable(hx_context* ctx, double* planck_grid, const double* lambda_ed
 // internal (not part of the C-ABI): the stellar row only, for per-column stars of a batch
 int hx_internal_planck_star_row(hx_context* ctx, double* row, const double* lambda_edge,
                                 const double* deltalambda, int nwave, double Tstar) {
-    k_plancktable<<<dim3(hx_cdiv(nwave, 256), 1), 256, 0, ctx->stream>>>(row, lambda_edge, deltalambda,
-                                                                        nwave, Tstar, 0, 1);
+    k_planck_star_row<<<dim3(hx_cdiv(nwave, 256), 1), 256, 0, ctx->stream>>>(row, lambda_edge, deltalambda, nwave, Tstar);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }
