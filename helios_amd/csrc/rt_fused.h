@@ -55,6 +55,7 @@ struct hx_rt {
     double *T_lay_ref = nullptr, *T_int_ref = nullptr;  // temperatures of the last refresh
     int nchunk;  // x-chunks of the totals reduction
     int coef_tpb = 4;  // k_rt_coef: tiles (wavefronts) per workgroup
+    hipError_t shmem_rc = hipSuccess;
     bool conv_shmem_raised = false;  // dynamic-LDS limit of the convection kernels lifted (deep atmospheres)
     bool coef_shmem_raised = false;  // k_rt_coef's dynamic-LDS limit lifted above 64 KiB (deep atmospheres)
 

@@ -219,8 +219,16 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.F_up_band_n = a.F_up_band_n;
     f.coef_col = a.coef_col; f.flux_col = a.flux_col;
     f.done = a.done;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
-                       rt->ctx->stream, f);
+    static const int generic = [] { const char* e = getenv("HELIOS_RT_GENERIC_SCANS"); return e ? atoi(e) : 0; }();
+    if (g.k == 16 && !generic)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 16>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                           rt->ctx->stream, f);
+    else if (g.k == 32 && !generic)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 32>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                           rt->ctx->stream, f);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                           rt->ctx->stream, f);
 }
 template <int ROWS, int TPB>
 void launch_coef_tpb(hx_rt* rt, KArgs a) {
@@ -271,18 +279,22 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
         default: fn<16>(rt, a); break;            \
     }
 
+template <int ROWS>
+void raise_flux_shmem(hx_rt* rt, int shmem) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    rt->shmem_rc = e;
+}
+
 int set_flux_shmem_limits(hx_rt* rt) {
     const size_t shmem = flux_shmem_bytes(rt);
     if (shmem > 160 * 1024) return rt_fail(rt, HX_E_UNSUPPORTED, "workgroup LDS demand exceeds 160 KiB");
     if (shmem <= 64 * 1024) return 0;
-    const void* fns[16] = {(const void*)k_rt_flux<1>, (const void*)k_rt_flux<2>, (const void*)k_rt_flux<3>,
-                           (const void*)k_rt_flux<4>, (const void*)k_rt_flux<5>, (const void*)k_rt_flux<6>,
-                           (const void*)k_rt_flux<7>, (const void*)k_rt_flux<8>, (const void*)k_rt_flux<9>,
-                           (const void*)k_rt_flux<10>, (const void*)k_rt_flux<11>, (const void*)k_rt_flux<12>,
-                           (const void*)k_rt_flux<13>, (const void*)k_rt_flux<14>, (const void*)k_rt_flux<15>,
-                           (const void*)k_rt_flux<16>};
-    HX_HIP(rt->ctx, hipFuncSetAttribute(fns[rt->g.ROWS - 1], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)shmem));
+    DISPATCH_ROWS(raise_flux_shmem, rt, (int)shmem);
+    HX_HIP(rt->ctx, rt->shmem_rc);
     return 0;
 }
 

@@ -256,6 +256,76 @@ __device__ __forceinline__ LaneMap lane_map(const Args& a, int bx, int part, int
     return m;
 }
 
+// ---- scans with the lanes per spectral point known at compile time (K = 16, 32) ------------------------------
+// The neighbour's map arrives through DPP; a lane that has no neighbour inside its 16-lane row receives the identity
+// map (A2 = 1: `old` keeps 1.0's high word, bound_ctrl zeroes the rest; B2 = 0), so the composition is unconditional --
+// no compare, no selects, no wave-uniform branches on k.  Composing with the identity is exact: same bits as the
+// generic path's `if (j + N < k)`.
+template <int CTRL>
+__device__ __forceinline__ void compose_row_neighbour(double& A, double& Bc) {
+    const int a_lo = __builtin_amdgcn_update_dpp(0, __double2loint(A), CTRL, 0xf, 0xf, true);
+    const int a_hi = __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(A), CTRL, 0xf, 0xf, false);
+    const int b_lo = __builtin_amdgcn_update_dpp(0, __double2loint(Bc), CTRL, 0xf, 0xf, true);
+    const int b_hi = __builtin_amdgcn_update_dpp(0, __double2hiint(Bc), CTRL, 0xf, 0xf, true);
+    Bc = fma(A, __hiloint2double(b_hi, b_lo), Bc);
+    A *= __hiloint2double(a_hi, a_lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_or_zero(double v) {  // the DPP-selected lane's value, 0.0 where there is none
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K>
+__device__ __forceinline__ void scan_down_fixed(double& A, double& Bc, int j, int lane) {  // suffix composition over j
+    compose_row_neighbour<0x101>(A, Bc);  // row_shl:1
+    compose_row_neighbour<0x102>(A, Bc);
+    compose_row_neighbour<0x104>(A, Bc);
+    compose_row_neighbour<0x108>(A, Bc);
+    if (K == 32) {
+        const double A2 = group_lane16(A, lane), B2 = group_lane16(Bc, lane);
+        if (j < 16) {
+            Bc = fma(A, B2, Bc);
+            A *= A2;
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void scan_up_fixed(double& A, double& Bc, int j) {  // prefix composition over j
+    compose_row_neighbour<0x111>(A, Bc);  // row_shr:1
+    compose_row_neighbour<0x112>(A, Bc);
+    compose_row_neighbour<0x114>(A, Bc);
+    compose_row_neighbour<0x118>(A, Bc);
+    if (K == 32) {
+        const double A2 = dpp_move<0x142, 0xa>(A), B2 = dpp_move<0x142, 0xa>(Bc);  // row_bcast:15 into rows 1 and 3
+        if (j >= 16) {
+            Bc = fma(A, B2, Bc);
+            A *= A2;
+        }
+    }
+}
+// value of the lane below / above inside the group; the group's first / last lane gets something its caller overrides
+template <int K>
+__device__ __forceinline__ double below_fixed(double v) {
+    return K == 16 ? dpp_or_zero<0x111>(v) : dpp_or_zero<0x138>(v);  // row_shr:1 / wave_shr:1
+}
+template <int K>
+__device__ __forceinline__ double above_fixed(double v) {
+    return K == 16 ? dpp_or_zero<0x101>(v) : dpp_or_zero<0x130>(v);  // row_shl:1 / wave_shl:1
+}
+template <int K>
+__device__ __forceinline__ double group_first_lane(double v, int lane) {  // lane 0 of this lane's K-lane group
+    if (K == 16) return dpp_or_zero<0x150>(v);  // row_newbcast:0
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo_a = __builtin_amdgcn_readlane(lo, 0), lo_b = __builtin_amdgcn_readlane(lo, 32);
+    const int hi_a = __builtin_amdgcn_readlane(hi, 0), hi_b = __builtin_amdgcn_readlane(hi, 32);
+    return __hiloint2double(lane < 32 ? hi_a : hi_b, lane < 32 ? lo_a : lo_b);
+}
+// tiny_abs with the threshold as data: 1e-100 where the reference applies it, 0.0 (never true) where it does not
+__device__ __forceinline__ double tiny_abs_below(double F, double thr) { return fabs(F) < thr ? fabs(F) : F; }
+
 // ---- per refresh: band quantities of the half-layers, bin-major ---------------------------------
 // grid (ceil(X/32), ceil(H/32), C), 256 threads.  The band arrays are level-major ([i][x], the reference's layout); a
 // workgroup of k_rt_coef needs ALL half-layers of one or two bins, which there is one 64-byte sector per double.  This
@@ -327,7 +397,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     int* c_of_q = (int*)(sh_csc + ncl);             // [TS] global spectral-point index or -1
     int* x_of_q = c_of_q + TS;
     const size_t nc = (size_t)a.Y * a.X;
-    const size_t wgI = nc * a.I, bandI = (size_t)a.X * a.I;
+    const size_t wgI = nc * a.I;
     const int x_base = (blockIdx.x * COEF_TPB) / (a.NW * a.nparts) * a.nxb;  // first bin of the first tile
     // spectral points of this workgroup's tiles
     for (int q = threadIdx.x; q < TS; q += blockDim.x) {
@@ -545,7 +615,8 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 // after the other, so the Gauss sum of a bin is completed inside the workgroup (fixed order).
 // (k = 32 / ROWS = 7 held to 128 VGPRs for four wavefronts per SIMD through amdgpu_waves_per_eu spills 49 dwords inside
 // the sweeps: 0.62 ms against 0.42 ms at its natural 169 registers and 0.40 ms for k = 16 -- not done.)
-template <int ROWS>
+// K: lanes per spectral point when known at compile time (16 or 32: the scans are straight-line DPP code), 0: a.k
+template <int ROWS, int K = 0>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = blockIdx.y;
@@ -557,7 +628,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     double* stage = acc + (size_t)a.nxb * 2 * I;     // [ypb][nxb][2][I]
     const hx_rt_column cp = a.colpar[col];
     const size_t nc = (size_t)a.Y * a.X;
-    const int k = a.k;
+    const int k = K ? K : a.k;
 
     for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
         const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
@@ -619,10 +690,13 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
         const double D_toa = (1.0 - a.dir_beam) * cp.f_factor * (rs * rs) * HX_PI * Bx[a.H + 1];
         const double B_surf = Bx[a.H + 2];
 
+        // rows (r even, r odd) of this lane whose up-flux the reference makes positive when it is tiny: the odd nodes
+        const bool odd0 = (m.j * ROWS) & 1;
+        const double thr_even = (a.iso || odd0) ? 1e-100 : 0.0, thr_odd = (a.iso || !odd0) ? 1e-100 : 0.0;
         for (int sweep = 0; sweep < a.nsweep; sweep++) {
             // ---------------- down: TOA -> BOA ----------------
             {
-                double Ubelow = from_lane_below<1>(Uo[ROWS - 1], k);  // U at the bottom node of this chunk
+                double Ubelow = K ? below_fixed<K>(Uo[ROWS - 1]) : from_lane_below<1>(Uo[ROWS - 1], k);  // U at the bottom node of this chunk
                 if (m.j == 0) Ubelow = U0;
                 double A = 1.0, Bc = 0.0;
 #pragma unroll
@@ -633,7 +707,9 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     A *= al[r];
                 }
                 // inclusive suffix composition over the k lanes of this spectral point
-                if (k == 32) {
+                if (K) {
+                    scan_down_fixed<K>(A, Bc, m.j, m.lane);
+                } else if (k == 32) {
                     scan32_down(A, Bc, m.j, m.lane);
                 } else {
                     scan_step_down<1>(A, Bc, m.j, k);
@@ -643,7 +719,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     scan_step_down<16>(A, Bc, m.j, k);
                     scan_step_down<32>(A, Bc, m.j, k);
                 }
-                double Din = from_lane_above<1>(fma(A, D_toa, Bc), k);
+                double Din = K ? above_fixed<K>(fma(A, D_toa, Bc)) : from_lane_above<1>(fma(A, D_toa, Bc), k);
                 if (m.j == k - 1) Din = D_toa;
                 double D = Din;
 #pragma unroll
@@ -655,10 +731,10 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             }
             // ---------------- BOA boundary ----------------
             if (m.j == 0) U0 = albedo * (Fdir0 + Do[0]) + (1.0 - albedo) * HX_PI * boaK * B_surf;
-            const double Ubc = __shfl(U0, 0, k);
+            const double Ubc = K ? group_first_lane<K>(U0, m.lane) : __shfl(U0, 0, k);
             // ---------------- up: BOA -> TOA ----------------
             {
-                double Dabove = from_lane_above<1>(Do[0], k);  // D at the top node of this chunk
+                double Dabove = K ? above_fixed<K>(Do[0]) : from_lane_above<1>(Do[0], k);  // D at the top node of this chunk
                 if (m.j == k - 1) Dabove = D_toa;
                 double A = 1.0, Bc = 0.0;
 #pragma unroll
@@ -668,7 +744,9 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     Bc = fma(al[r], Bc, t);
                     A *= al[r];
                 }
-                if (k == 32) {
+                if (K) {
+                    scan_up_fixed<K>(A, Bc, m.j);
+                } else if (k == 32) {
                     scan32_up(A, Bc, m.j);
                 } else {
                     scan_step_up<1>(A, Bc, m.j, k);
@@ -678,7 +756,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     scan_step_up<16>(A, Bc, m.j, k);
                     scan_step_up<32>(A, Bc, m.j, k);
                 }
-                double Uin = from_lane_below<1>(fma(A, Ubc, Bc), k);
+                double Uin = K ? below_fixed<K>(fma(A, Ubc, Bc)) : from_lane_below<1>(fma(A, Ubc, Bc), k);
                 if (m.j == 0) Uin = Ubc;
                 double U = Uin;
 #pragma unroll
@@ -686,7 +764,8 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                     const double Dh = r < ROWS - 1 ? Do[r + 1] : Dabove;
                     U = fma(al[r], U, fma(be[r], Dh, su[r]));
                     // interface nodes only (reference quirk, kernels.cu:1763; isothermal layers: every node, :1509)
-                    if (a.iso || ((m.j * ROWS + r) & 1)) U = tiny_abs(U);
+                    if (K) U = tiny_abs_below(U, (r & 1) ? thr_odd : thr_even);
+                    else if (a.iso || ((m.j * ROWS + r) & 1)) U = tiny_abs(U);
                     Uo[r] = U;
                 }
             }
