@@ -222,7 +222,7 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.F_up_band_n = a.F_up_band_n;
     f.coef_col = a.coef_col; f.flux_col = a.flux_col;
     f.done = a.done;
-    static const int generic = [] { const char* e = getenv("HELIOS_RT_GENERIC_SCANS"); return e ? atoi(e) : 0; }();
+    const bool generic = rt->generic_scans;
     if (g.k == 16 && !generic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 16>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                            rt->ctx->stream, f);
@@ -352,6 +352,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
     rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
+    if (const char* e = getenv("HELIOS_RT_GENERIC_SCANS")) rt->generic_scans = atoi(e) != 0;  // read per batch: tests
     // tiles per workgroup of k_rt_coef: 16 spectral points staged side by side (128-byte runs of the k-table) -- 4 tiles
     // at k = 16, 8 at k = 32 (config 5, same box: 2 tiles 6.4 ms, 4 tiles 4.5 ms, 8 tiles 3.4 ms per refresh)
     rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));

@@ -28,7 +28,7 @@ FUSED_CONFIGS = {
     "ny1": dict(ny=1, nbin=17),
     "L100": dict(nbin=24, nlayer=100),          # k=16, 13 rows per lane: the BASELINE shape
     "L105": dict(nbin=12, nlayer=105),          # the reference's default layer count
-    "L50": dict(nbin=21, nlayer=50, clouds=1),  # k=8, two bins per workgroup
+    "L50": dict(nbin=21, nlayer=50, clouds=1),  # k=16, 7 rows per lane (k=8 before the compile-time scans were preferred)
     "L200": dict(nbin=7, nlayer=200, dir_beam=1),  # k=32, two Gauss-point partials per bin
     "L33_ny16": dict(nbin=9, nlayer=33, ny=16),
     "L400": dict(nbin=5, nlayer=400, clouds=1, g_0=0.1),   # k=64: one spectral point per wavefront, >64 KiB LDS in k_rt_coef
@@ -63,6 +63,25 @@ def test_fused_vs_oracle_single_wavefront_workgroups(ctx, port, name, monkeypatc
     f, grid = fh.run_fused(ctx, c0, 12, with_planck_grid=True)
     o = fh.run_oracle(port, c0, 12, planck_grid=grid)
     fh.compare(f, o, c0, rtol=1e-7)
+
+
+@pytest.mark.parametrize("name,k", [("L100", 16), ("L200", 32), ("L50", 16), ("clouds_g0", 16), ("iso_zenith_L100", 16),
+                                    ("L200_i2s", 32), ("L100", 32), ("L50", 8)])
+def test_compile_time_scans_equal_the_generic_kernel_bit_for_bit(ctx, name, k, monkeypatch):
+    """k_rt_flux<ROWS, K> (straight-line DPP scans for K = 16 / 32, identity fill instead of selects, row_newbcast)
+    against k_rt_flux<ROWS, 0> (runtime k, the kernel of rounds 1-2 and still the one for k = 8 and 64): the same bits in
+    every flux and temperature after 12 iterations, in both workgroup shapes.  (k = 8 has no compile-time variant: the
+    pair is then the same kernel, which pins the knob itself.)"""
+    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    monkeypatch.setenv("HELIOS_RT_K", str(k))
+    for threads in ("64", "320"):
+        monkeypatch.setenv("HELIOS_RT_MAXTHREADS", threads)
+        monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "0")
+        a = fh.run_fused(ctx, c0, 12)
+        monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "1")
+        b = fh.run_fused(ctx, c0, 12)
+        for key in fh.keys_for(c0):
+            np.testing.assert_array_equal(a[key], b[key], err_msg="%s, %s threads" % (key, threads))
 
 
 @pytest.mark.parametrize("name", gc.CHAIN_NAMES)
