@@ -63,7 +63,7 @@ void choose_workgroup(int Y, int X, int max_threads, TileGeom& g) {
 
 bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g) {
     // lanes per spectral point: the fewest padded nodes, with the kernels whose scans are written for a compile-time
-    // lane count (k = 16, 32) preferred -- measured at 10 000 bins: 50 layers 0.172 ms (k = 16, 12 % padding) against
+    // lane count (k = 16, 32, 64) preferred -- measured at 10 000 bins: 50 layers 0.172 ms (k = 16, 12 % padding) against
     // 0.210 ms (k = 8, 4 %), 60 layers 0.194 against 0.256 ms
     int best_k = 0, best_rows = 0, best_cost = 1 << 30;
     int force_k = 0;
@@ -72,7 +72,7 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
         const int rows = (H + k - 1) / k;
         if (rows > 16) continue;
         if (force_k && k != force_k) continue;
-        const int cost = k * rows * ((k == 16 || k == 32) ? 100 : 125);
+        const int cost = k * rows * (k >= 16 ? 100 : 125);
         if (cost < best_cost) {
             best_cost = cost;
             best_k = k;
@@ -229,6 +229,9 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     else if (g.k == 32 && !generic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 32>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                            rt->ctx->stream, f);
+    else if (g.k == 64 && !generic)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 64>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                           rt->ctx->stream, f);
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                            rt->ctx->stream, f);
@@ -289,6 +292,8 @@ void raise_flux_shmem(hx_rt* rt, int shmem) {
         e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     rt->shmem_rc = e;
 }
 

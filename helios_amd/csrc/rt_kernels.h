@@ -278,15 +278,28 @@ __device__ __forceinline__ double dpp_or_zero(double v) {  // the DPP-selected l
     return __hiloint2double(hi, lo);
 }
 
+// value of lane SRC of the wavefront, through the scalar unit
+template <int SRC>
+__device__ __forceinline__ double wave_lane(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), SRC), __builtin_amdgcn_readlane(__double2loint(v), SRC));
+}
+
 template <int K>
 __device__ __forceinline__ void scan_down_fixed(double& A, double& Bc, int j, int lane) {  // suffix composition over j
     compose_row_neighbour<0x101>(A, Bc);  // row_shl:1
     compose_row_neighbour<0x102>(A, Bc);
     compose_row_neighbour<0x104>(A, Bc);
     compose_row_neighbour<0x108>(A, Bc);
-    if (K == 32) {
+    if (K == 32 || K == 64) {  // rows 0 and 2 take the total of the row above them: its first lane, 16 or 48
         const double A2 = group_lane16(A, lane), B2 = group_lane16(Bc, lane);
-        if (j < 16) {
+        if ((lane & 16) == 0) {
+            Bc = fma(A, B2, Bc);
+            A *= A2;
+        }
+    }
+    if (K == 64) {             // rows 0 and 1 take the total of rows 2 and 3, which lane 32 now holds
+        const double A2 = wave_lane<32>(A), B2 = wave_lane<32>(Bc);
+        if (lane < 32) {
             Bc = fma(A, B2, Bc);
             A *= A2;
         }
@@ -298,9 +311,16 @@ __device__ __forceinline__ void scan_up_fixed(double& A, double& Bc, int j) {  /
     compose_row_neighbour<0x112>(A, Bc);
     compose_row_neighbour<0x114>(A, Bc);
     compose_row_neighbour<0x118>(A, Bc);
-    if (K == 32) {
+    if (K == 32 || K == 64) {
         const double A2 = dpp_move<0x142, 0xa>(A), B2 = dpp_move<0x142, 0xa>(Bc);  // row_bcast:15 into rows 1 and 3
-        if (j >= 16) {
+        if (j & 16) {
+            Bc = fma(A, B2, Bc);
+            A *= A2;
+        }
+    }
+    if (K == 64) {
+        const double A2 = dpp_move<0x143, 0xc>(A), B2 = dpp_move<0x143, 0xc>(Bc);  // row_bcast:31 into rows 2 and 3
+        if (j >= 32) {
             Bc = fma(A, B2, Bc);
             A *= A2;
         }
@@ -318,6 +338,7 @@ __device__ __forceinline__ double above_fixed(double v) {
 template <int K>
 __device__ __forceinline__ double group_first_lane(double v, int lane) {  // lane 0 of this lane's K-lane group
     if (K == 16) return dpp_or_zero<0x150>(v);  // row_newbcast:0
+    if (K == 64) return wave_lane<0>(v);
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const int lo_a = __builtin_amdgcn_readlane(lo, 0), lo_b = __builtin_amdgcn_readlane(lo, 32);
     const int hi_a = __builtin_amdgcn_readlane(hi, 0), hi_b = __builtin_amdgcn_readlane(hi, 32);
@@ -615,7 +636,7 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 // after the other, so the Gauss sum of a bin is completed inside the workgroup (fixed order).
 // (k = 32 / ROWS = 7 held to 128 VGPRs for four wavefronts per SIMD through amdgpu_waves_per_eu spills 49 dwords inside
 // the sweeps: 0.62 ms against 0.42 ms at its natural 169 registers and 0.40 ms for k = 16 -- not done.)
-// K: lanes per spectral point when known at compile time (16 or 32: the scans are straight-line DPP code), 0: a.k
+// K: lanes per spectral point when known at compile time (16, 32, 64: the scans are straight-line DPP code), 0: a.k
 template <int ROWS, int K = 0>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];

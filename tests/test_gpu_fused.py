@@ -66,22 +66,36 @@ def test_fused_vs_oracle_single_wavefront_workgroups(ctx, port, name, monkeypatc
 
 
 @pytest.mark.parametrize("name,k", [("L100", 16), ("L200", 32), ("L50", 16), ("clouds_g0", 16), ("iso_zenith_L100", 16),
-                                    ("L200_i2s", 32), ("L100", 32), ("L50", 8)])
+                                    ("L200_i2s", 32), ("L100", 32), ("L50", 8), ("L400", 64), ("L512", 64), ("L200", 64)])
 def test_compile_time_scans_equal_the_generic_kernel_bit_for_bit(ctx, name, k, monkeypatch):
-    """k_rt_flux<ROWS, K> (straight-line DPP scans for K = 16 / 32, identity fill instead of selects, row_newbcast)
-    against k_rt_flux<ROWS, 0> (runtime k, the kernel of rounds 1-2 and still the one for k = 8 and 64): the same bits in
-    every flux and temperature after 12 iterations, in both workgroup shapes.  (k = 8 has no compile-time variant: the
+    """k_rt_flux<ROWS, K> (straight-line DPP scans for K = 16 / 32 / 64, identity fill instead of selects, row_newbcast)
+    against k_rt_flux<ROWS, 0> (runtime k, the kernel of rounds 1-2 and still the one for k = 8): the same bits in
+    every flux and temperature after 12 iterations, in both workgroup shapes (k = 64: to rounding, see below).  (k = 8 has no compile-time variant: the
     pair is then the same kernel, which pins the knob itself.)"""
     c0 = cases.make_case(**FUSED_CONFIGS[name])
     monkeypatch.setenv("HELIOS_RT_K", str(k))
     for threads in ("64", "320"):
         monkeypatch.setenv("HELIOS_RT_MAXTHREADS", threads)
-        monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "0")
-        a = fh.run_fused(ctx, c0, 12)
-        monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "1")
-        b = fh.run_fused(ctx, c0, 12)
-        for key in fh.keys_for(c0):
-            np.testing.assert_array_equal(a[key], b[key], err_msg="%s, %s threads" % (key, threads))
+        # k = 64: the generic kernel composes over distances 1 .. 32, the compile-time one inside the rows first and then
+        # the row totals -- another association of the same products (k = 32 does the same in both): equal to rounding
+        # after one iteration; after twelve the temperature iteration has amplified that as it does any rounding
+        # difference (cf. the tolerances of test_fused_vs_oracle)
+        for n_iter, rtol in ((1, 1e-12), (12, 1e-7)) if k == 64 else ((12, 0.0),):
+            monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "0")
+            a = fh.run_fused(ctx, c0, n_iter)
+            monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "1")
+            b = fh.run_fused(ctx, c0, n_iter)
+            for key in fh.keys_for(c0):
+                msg = "%s, %s threads, %d iterations" % (key, threads, n_iter)
+                if rtol == 0.0:
+                    np.testing.assert_array_equal(a[key], b[key], err_msg=msg)
+                else:
+                    scale = np.abs(b[key]).max() if np.size(b[key]) else 0.0
+                    # the temperature step divides differences of nearly equal fluxes: its output carries their
+                    # rounding amplified (1e-10 observed at 512 layers after one step)
+                    loose = key in ("T_lay", "T_int", "delta_t_prefactor")
+                    np.testing.assert_allclose(a[key], b[key], rtol=max(rtol, 1e-8) if loose else rtol,
+                                               atol=1e-13 * scale, err_msg=msg)
 
 
 @pytest.mark.parametrize("name", gc.CHAIN_NAMES)
