@@ -245,7 +245,7 @@ void launch_coef_tpb(hx_rt* rt, KArgs a) {
     a.coef_nbx = NBX;
     size_t shmem = ((size_t)(rt->L + rt->I) * TSP + (size_t)rt->H * (NBX + 2)) * sizeof(double) + 2 * TS * sizeof(int);
     const size_t cloud_image = 3 * (size_t)rt->H * NBX * sizeof(double);
-    a.cloud_lds = a.clouds == 1 && shmem + cloud_image <= 80 * 1024;  // keep two workgroups per CU
+    a.cloud_lds = a.clouds == 1 && rt->cloud_lds && shmem + cloud_image <= 80 * 1024;  // keep two workgroups per CU
     if (a.cloud_lds) shmem += cloud_image;
     if (shmem > 64 * 1024 && !rt->coef_shmem_raised) {
         (void)hipFuncSetAttribute((const void*)k_rt_coef<ROWS, TPB>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -358,6 +358,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
     rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
     if (const char* e = getenv("HELIOS_RT_GENERIC_SCANS")) rt->generic_scans = atoi(e) != 0;  // read per batch: tests
+    if (const char* e = getenv("HELIOS_RT_CLOUD_LDS")) rt->cloud_lds = atoi(e) != 0;  // 0: k_rt_coef's fallback path (tests)
     // tiles per workgroup of k_rt_coef: 16 spectral points staged side by side (128-byte runs of the k-table) -- 4 tiles
     // at k = 16, 8 at k = 32 (config 5, same box: 2 tiles 6.4 ms, 4 tiles 4.5 ms, 8 tiles 3.4 ms per refresh)
     rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));

@@ -98,6 +98,19 @@ def test_compile_time_scans_equal_the_generic_kernel_bit_for_bit(ctx, name, k, m
                                                atol=1e-13 * scale, err_msg=msg)
 
 
+@pytest.mark.parametrize("name", ["clouds_g0", "L50", "L200_i2s", "iso_clouds_beam", "L400"])
+def test_cloud_terms_from_lds_or_from_the_bin_major_rows(ctx, name, monkeypatch):
+    """k_rt_coef takes the clouds' half-layer terms from its LDS image when that fits and straight from the rows
+    k_rt_half_bands writes when it does not: the same bits either way"""
+    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    monkeypatch.setenv("HELIOS_RT_CLOUD_LDS", "1")
+    a = fh.run_fused(ctx, c0, 12)
+    monkeypatch.setenv("HELIOS_RT_CLOUD_LDS", "0")
+    b = fh.run_fused(ctx, c0, 12)
+    for key in fh.keys_for(c0):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+
+
 @pytest.mark.parametrize("name", gc.CHAIN_NAMES)
 def test_fused_golden(ctx, name):
     """the fused path against the reference-generated golden vectors (isothermal and non-isothermal layers)"""
