@@ -111,6 +111,29 @@ def test_cloud_terms_from_lds_or_from_the_bin_major_rows(ctx, name, monkeypatch)
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)
 
 
+def test_batches_give_their_device_memory_back(ctx):
+    """batches (premixed, with clouds, deep column) created, stepped and closed over and over: after a few warm-up
+    rounds (the HIP allocator keeps some blocks for itself) the free device memory no longer moves, and a batch that
+    fails to build (513 layers) leaves nothing behind either"""
+    from helios_amd._lib import HeliosHipError
+
+    def round_():
+        for cfg in (dict(nbin=24, nlayer=100), dict(nbin=9, nlayer=50, clouds=1, scat_corr=1, g_0=0.2),
+                    dict(nbin=5, nlayer=400, dir_beam=1)):
+            fh.run_fused(ctx, cases.make_case(**cfg), 2, keys=["T_lay"])
+        with pytest.raises(HeliosHipError):
+            fh.run_fused(ctx, cases.make_case(nbin=3, nlayer=513), 1, keys=["T_lay"])
+
+    for _ in range(3):
+        round_()
+    ctx.synchronize()
+    free0 = ctx.mem_info()[0]
+    for _ in range(12):
+        round_()
+    ctx.synchronize()
+    assert abs(ctx.mem_info()[0] - free0) <= 1 << 20, (free0, ctx.mem_info())
+
+
 @pytest.mark.parametrize("name", gc.CHAIN_NAMES)
 def test_fused_golden(ctx, name):
     """the fused path against the reference-generated golden vectors (isothermal and non-isothermal layers)"""
