@@ -188,9 +188,8 @@ __device__ inline int conv_zones(const ConvColumn& c, ConvTables& t) {
 }
 
 // host_functions.py:368-506: every zone goes onto the adiabat of its enthalpy-conserving mean potential temperature
-__device__ inline void conv_correct(const ConvColumn& c, ConvTables& t, int fudging) {
+__device__ inline void conv_correct_zones(const ConvColumn& c, ConvTables& t, int fudging, int nz) {
     const int L = c.L;
-    const int nz = conv_zones(c, t);
     for (int n = 0; n < nz; n++) {
         double fudge = 1.0;
         if (fudging == 1) {
@@ -233,6 +232,10 @@ __device__ inline void conv_correct(const ConvColumn& c, ConvTables& t, int fudg
     }
 }
 
+__device__ inline void conv_correct(const ConvColumn& c, ConvTables& t, int fudging) {
+    conv_correct_zones(c, t, fudging, conv_zones(c, t));
+}
+
 // host_functions.py:509-542
 __device__ inline void convective_adjustment(const ConvColumn& c, ConvTables& t) {
     int unstable = conv_check(c, t);
@@ -257,14 +260,47 @@ struct ConvShared {
     int count;
 };
 
-__device__ inline void conv_find_lim(const ConvColumn& c, ConvShared& sh, int tid) {
+// the first layer pair at p_lay <= 10 ends the check / mark loops of the reference (a `break`): the smallest such index
+__device__ inline void conv_find_lim(const ConvColumn& c, ConvShared& sh, int tid, int nthr) {
+    if (tid == 0) sh.lim = c.L - 1 < 0 ? 0 : c.L - 1;
+    __syncthreads();
+    int mine = 1 << 30;
+    for (int i = tid; i < c.L - 1; i += nthr)
+        if (c.p_lay[i] <= 1e1) { mine = i; break; }  // ascending i per thread: its first hit is its smallest
+    if (mine < (1 << 30)) atomicMin(&sh.lim, mine);
+    __syncthreads();
+}
+
+// conv_zones by the whole workgroup: the flags by all threads, the (few) zone boundaries compacted by the first
+// wavefront with ballots, in ascending order as the sequential walk finds them.  Returns the number of zones (uniform).
+__device__ inline int conv_zones_wg(const ConvColumn& c, ConvTables& t, ConvShared& sh, int tid, int nthr) {
+    const int L = c.L;
+    for (int i = tid; i < L; i += nthr) t.in_zone[i + 1] = (c.conv_unstable[i] == 1 || c.conv_layer[i] == 1) ? 1 : 0;
     if (tid == 0) {
-        int lim = c.L - 1;
-        for (int i = 0; i < c.L - 1; i++)
-            if (c.p_lay[i] <= 1e1) { lim = i; break; }
-        sh.lim = lim < 0 ? 0 : lim;
+        t.in_zone[0] = (c.conv_unstable[L] == 1 || c.conv_layer[L] == 1) ? 1 : 0;
+        t.in_zone[L + 1] = 0;
     }
     __syncthreads();
+    if (tid < 64) {
+        int ns = 0, ne = 0;
+        for (int base = -1; base < L; base += 64) {  // i = base + lane runs over -1 .. L-1
+            const int i = base + tid;
+            const bool in = i < L && t.in_zone[i + 1] != 0;
+            const bool st = in && (i == -1 || !t.in_zone[i]);
+            const bool en = in && !t.in_zone[i + 2];
+            const unsigned long long ms = __ballot(st), me = __ballot(en);
+            const unsigned long long below = tid == 0 ? 0ull : (~0ull >> (64 - tid));
+            if (st) t.starts[ns + __popcll(ms & below)] = i;
+            if (en) t.ends[ne + __popcll(me & below)] = i;
+            ns += __popcll(ms);
+            ne += __popcll(me);
+        }
+        if (tid == 0) sh.count = ns == ne ? ns : 0;
+    }
+    __syncthreads();
+    const int nz = sh.count;
+    __syncthreads();
+    return nz;
 }
 
 __device__ inline int conv_check_wg(const ConvColumn& c, ConvTables& t, ConvShared& sh, int tid, int nthr) {
@@ -316,17 +352,19 @@ __device__ inline void conv_mark_layers_wg(const ConvColumn& c, ConvTables& t, C
 }
 
 __device__ inline void convective_adjustment_wg(const ConvColumn& c, ConvTables& t, ConvShared& sh, int tid, int nthr) {
-    conv_find_lim(c, sh, tid);
+    conv_find_lim(c, sh, tid, nthr);
     int unstable = conv_check_wg(c, t, sh, tid, nthr);
     int guard = 0;
     while (unstable > 0 && guard++ < 100000) {
         conv_mark_layers_wg(c, t, sh, 0, tid, nthr);
-        if (tid == 0) conv_correct(c, t, 0);
+        const int nz = conv_zones_wg(c, t, sh, tid, nthr);
+        if (tid == 0) conv_correct_zones(c, t, 0, nz);
         __syncthreads();
         unstable = conv_check_wg(c, t, sh, tid, nthr);
     }
     conv_mark_layers_wg(c, t, sh, 1, tid, nthr);
-    if (tid == 0) conv_correct(c, t, 1);
+    const int nz = conv_zones_wg(c, t, sh, tid, nthr);
+    if (tid == 0) conv_correct_zones(c, t, 1, nz);
     __syncthreads();
 }
 

@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(1024) k_rt_totals_c(TotalsCArgs q) {
     conv_stage_in(c, g, t, conv_smem, threadIdx.x, blockDim.x);
     __shared__ ConvShared sh;
     __shared__ int s_convective;
-    conv_find_lim(c, sh, threadIdx.x);
+    conv_find_lim(c, sh, threadIdx.x, blockDim.x);
     conv_mark_layers_wg(c, t, sh, 1, threadIdx.x, blockDim.x);
     int go = 0;
     if (!q.physical_tstep_on) {  // with a physical time step the reference leaves the loop here
