@@ -111,6 +111,30 @@ def test_cloud_terms_from_lds_or_from_the_bin_major_rows(ctx, name, monkeypatch)
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)
 
 
+@pytest.mark.parametrize("k", [16, 32, 64])
+def test_every_row_count_of_the_compile_time_kernels(ctx, k, monkeypatch):
+    """k_rt_flux<ROWS, K> for ROWS = 1 .. 16 at K = 16, 32, 64 (columns of k/2, k, 3k/2, ... layers, and one layer
+    less: a partly filled last lane) against the runtime-k kernel after three iterations: the same bits for K = 16 and
+    32, fluxes to 1e-12 for K = 64 (another association of the scan, see above)"""
+    monkeypatch.setenv("HELIOS_RT_K", str(k))
+    keys = ["F_up_wg", "F_down_wg", "Fc_up_wg", "Fc_down_wg", "F_up_band", "F_down_band", "F_net"]
+    for rows in range(1, 17):
+        for nlayer in sorted({max(2, rows * k // 2), max(2, rows * k // 2 - 1)}):
+            if (2 * nlayer + k - 1) // k != rows:
+                continue
+            c0 = cases.make_case(nbin=3, nlayer=nlayer, dir_beam=rows % 2, clouds=1 if rows % 3 == 0 else 0)
+            monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "0")
+            a = fh.run_fused(ctx, c0, 3, keys=keys)
+            monkeypatch.setenv("HELIOS_RT_GENERIC_SCANS", "1")
+            b = fh.run_fused(ctx, c0, 3, keys=keys)
+            for key in keys:
+                msg = "%s, k = %d, ROWS = %d, %d layers" % (key, k, rows, nlayer)
+                if k == 64:
+                    np.testing.assert_allclose(a[key], b[key], rtol=1e-12, atol=1e-13 * np.abs(b[key]).max(), err_msg=msg)
+                else:
+                    np.testing.assert_array_equal(a[key], b[key], err_msg=msg)
+
+
 def test_batches_give_their_device_memory_back(ctx):
     """batches (premixed, with clouds, deep column) created, stepped and closed over and over: after a few warm-up
     rounds (the HIP allocator keeps some blocks for itself) the free device memory no longer moves, and a batch that
