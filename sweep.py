@@ -4,7 +4,8 @@
     python sweep.py -sweep "internal_temperature=100,300,1000;f_factor=0.25,0.5" -opacity_mixing synthetic -name grid
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 sweep.py -sweep "..." ...
 
-All other options are those of helios.py.  Column k writes its files to <output>/<name>_<k>/; rank 0 also writes
+All other options are those of helios.py.  HELIOS_SWEEP_PARTITION = cyclic (default: columns dealt out in turn) | block |
+dynamic[:chunk] (ranks claim chunks of columns from a shared work list as they retire the ones they hold).  Column k writes its files to <output>/<name>_<k>/; rank 0 also writes
 <output>/<name>_sweep_spectra.npz with the emission spectra of all columns and the swept parameter values.
 """
 import os
