@@ -427,6 +427,8 @@ def main():
         if wname == "c4" and ncol == WORKLOADS["c4"]["columns_per_gpu"] and os.path.exists(ref):
             with open(ref) as f:
                 one = json.loads(f.read().strip().splitlines()[-1])
+            line["scaling_note"] = ("the N = 1 default is config 2, the configuration the metric is quoted on; this line is "
+                                    "config 4 (17x the work per bin*layer*iteration): divide by single_gpu_same_workload")
             line["single_gpu_same_workload"] = dict(value=one["value"], ms_per_step=one["ms_per_step"],
                                                     source="profiles/r02_c4_bench_64columns.json (python bench.py "
                                                            "--workload c4 on one MI355X)")
