@@ -308,12 +308,32 @@ def main():
                         ("conv_unstable", np.zeros(L + 1, np.int32)), ("dampara", np.array([-1.0]))):
             rt.set_state(-1, name, v)
         run = rt.conv_run
-    # warm-up: W untimed steps starting at iteration 0 (includes the first refresh)
+    # warm-up: W untimed steps starting at iteration 0 (includes the first refresh) ...
+    tw = time.perf_counter()
     run(0, warmup)
+    ctx.synchronize()
+    # ... and, when those took less than 25 ms, further untimed decades until the device has been busy that long: a GPU
+    # that comes out of idle runs its first milliseconds slower (20 timed steps after 5 warm-up steps read 0.440 ms,
+    # after 45 0.417 ms, after 205 0.417 ms at config 2).  Whole decades, so that the timed window sees the opacity
+    # refreshes where it would have seen them; reported as device_warmup_iterations.
+    device_warmup = 0
+    while time.perf_counter() - tw < 0.025 and device_warmup < 200:
+        run(warmup + device_warmup, 10)
+        ctx.synchronize()
+        device_warmup += 10
+    if dist is not None:   # every rank the same number of iterations (the slowest decides nothing here: take the max)
+        t = torch.tensor([device_warmup], dtype=torch.int64, device=coll_device)
+        allw = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allw, t)
+        most = max(int(x.item()) for x in allw)
+        if most > device_warmup:
+            run(warmup + device_warmup, most - device_warmup)
+            device_warmup = most
+    start = warmup + device_warmup
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    run(warmup, steps)
+    run(start, steps)
     ev_ms = ctx.timer_stop_ms()
     barrier()
     dt_local = time.perf_counter() - t0
@@ -334,9 +354,9 @@ def main():
     tm = rt.traffic_model()
     counters, counter_source = load_counters(wname)
     if args.profile_steps > 0:
-        it0 = warmup + steps
+        it0 = start + steps
         it0 += (-it0) % 10 + 1                      # start right after a refresh boundary
-        run(warmup + steps, it0 - (warmup + steps))
+        run(start + steps, it0 - (start + steps))
         ctx.synchronize()
         ctx.timer_start()
         run(it0, 9)                                 # nine iterations without a refresh
@@ -404,7 +424,8 @@ def main():
     line = {
         "metric": "rad-conv iterations/sec x (lambda-bins x layers)",
         "value": value, "unit": "bin*layer*iterations/s", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+        "warmup": warmup, "device_warmup_iterations": device_warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": w["desc"], "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
                    "species": len(c.species) if c.species else 0,
@@ -420,10 +441,17 @@ def main():
         "spectrum_checksum": float(np.sum(spec)),
         "roofline": roofline,
     }
+    ref = os.path.join(ROOT, "profiles", "r02_c4_bench_64columns.json")
+    if world == 1 and wname == "c2" and ncol == 1 and os.path.exists(ref):
+        # the 1/2/4/8-GPU series is config 4 (the default at N > 1); its N = 1 member, for whoever forms an efficiency
+        with open(ref) as f:
+            one = json.loads(f.read().strip().splitlines()[-1])
+        line["scaling_series_n1"] = dict(workload=one["config"]["workload"], value=one["value"],
+                                         ms_per_step=one["ms_per_step"],
+                                         source="profiles/r02_c4_bench_64columns.json (python bench.py --workload c4)")
     if world > 1:
         # N = 1 runs another workload (config 2): what ONE GPU does on this workload, measured with the same command
         # at --gpus 1 and committed under profiles/, so that a scaling efficiency can be formed from like numbers
-        ref = os.path.join(ROOT, "profiles", "r02_c4_bench_64columns.json")
         if wname == "c4" and ncol == WORKLOADS["c4"]["columns_per_gpu"] and os.path.exists(ref):
             with open(ref) as f:
                 one = json.loads(f.read().strip().splitlines()[-1])
