@@ -42,7 +42,10 @@ class WorkList:
         self.store = store
         if self.store is None and dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             from torch.distributed import distributed_c10d as c10d
-            self.store = c10d._get_default_store()
+            try:
+                self.store = c10d._get_default_store()
+            except Exception as e:      # a torch without that accessor: pass `store=` (e.g. a TCPStore) explicitly
+                raise RuntimeError("WorkList needs the process group's key-value store; pass store=...") from e
         self.claimed = []
 
     def claim(self):
