@@ -38,11 +38,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--max-iterations", type=int, default=5000)
+    ap.add_argument("--nbin", type=int, default=0, help="override the workload's number of bins")
+    ap.add_argument("--nlayer", type=int, default=0, help="override the workload's number of layers")
     a = ap.parse_args()
     lib = oracle.refgpu
     if lib is None:
         raise SystemExit("oracle/_ref/libhelios_ref_gfx950.so (or a GPU) is not available")
-    w = bench.WORKLOADS[a.workload]
+    w = dict(bench.WORKLOADS[a.workload])
+    if a.nbin:
+        w["nbin"] = a.nbin
+    if a.nlayer:
+        w["nlayer"] = a.nlayer
     c0 = bench.build_case(w, 20242)
     X, Y, L, I = c0.nbin, c0.ny, c0.nlayer, c0.nlayer + 1
     from helios_amd import phys_const as pc
@@ -137,7 +143,7 @@ def main():
         return float(np.abs(x - y).max() / np.abs(y).max())
 
     out = {
-        "workload": w["desc"],
+        "workload": w["desc"], "nbin": int(X), "nlayer": int(L),
         "reference_kernels_on_this_gpu": {"iterations": int(n_ref), "left_the_loop": reason, "seconds": ref_s},
         "libhelios_hip": {"iterations": ours_iters, "seconds": ours_s},
         "same_iteration_count": ours_iters == int(n_ref),
