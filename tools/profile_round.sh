@@ -25,6 +25,7 @@ traffic() { # traffic <workload> <bench args...>: FETCH_SIZE, WRITE_SIZE and SQ_
 # counters first: bench.py quotes profiles/traffic.json in its roofline object
 traffic c2 --steps 20 --warmup 10
 traffic c3 --steps 10 --warmup 10
+traffic c5 --steps 10 --warmup 10
 cp profiles/traffic.json $O/traffic.json
 python3 bench.py > $O/c2_bench.json 2> $O/bench.err
 stats c2 --steps 50 --warmup 10
