@@ -284,6 +284,48 @@ def loop_fixture(name):
     print("loop_%s: %d iterations (%s)" % (name, n, reason))
 
 
+def loopconv_fixture(name, hostref=False):
+    """radiation loop + convection loop (source/computation.py:827-1174) of a small column: iteration counts,
+    conv_layer / conv_unstable / marked_red, T_lay, F_net, totals and TOA spectrum after 1, 10, 11, 50, 400 iterations
+    of the convection loop and at its end.  Kernels: the reference's (this BACKEND).  Host steps between the kernels
+    (conv_check, mark_convective_layers, conv_correct, check_for_radiative_eq, source/host_functions.py:251-635):
+    helios_amd/host_functions.py, pinned function by function to the reference's Python -- or, with `hostref`, the
+    reference's own source/host_functions.py imported in the build container (tests/golden/make_host_golden.py
+    explains the stand-ins for pycuda / astropy, which none of these functions touch)."""
+    import contextlib
+    import io
+    import loop_driver as ld
+    if hostref:
+        import make_host_golden as mh
+        hs, _ = mh.import_reference()
+        host = "the reference's own source/host_functions.py (imported in the build container)"
+    else:
+        from helios_amd import host_functions as hs
+        host = "helios_amd/host_functions.py (pinned to the reference's Python by tests/test_host_golden.py)"
+    c0, kappa, radiative_first = ld.conv_case(name)
+    ref = reference()
+    c = c0.copy()
+    s = cases.alloc_state(c)
+    cases.setup_planck(ref, c, s)
+    m = json.loads(meta())
+    m["host_steps"] = host
+    data = {"meta": json.dumps(m), "planck_grid": s.planck_grid.copy(), "kappa": np.array(kappa),
+            "radiative_first": np.array(int(radiative_first))}
+    for k, v in c0.items():
+        data["in." + k] = np.asarray(v)
+    with contextlib.redirect_stdout(io.StringIO()):       # check_for_radiative_eq prints every 100th iteration
+        n_rad, n, snaps, q = ld.rad_conv_run(ref, hs, c, s, kappa, radiative_first)
+    data["rad_iter_count"] = np.array(n_rad)
+    data["iter_count"] = np.array(n)
+    for at, sn in snaps.items():
+        for k, v in sn.items():
+            data["%s.%s" % (("it%d" % at) if isinstance(at, int) else at, k)] = v
+    fn = "loopconv_%s%s.npz" % (name, "_hostref" if hostref else "")
+    np.savez_compressed(os.path.join(OUT, fn), **data)
+    print("%s: radiation loop %d, convection loop %d iterations, conv_layer %s"
+          % (fn, n_rad, n, "".join(str(int(v)) for v in q.conv_layer)), flush=True)
+
+
 def compare(other):
     """largest relative difference per file between the fixtures in `other` and those next to this script"""
     worst_all = 0.0
@@ -316,6 +358,8 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     ap.add_argument("--compare", default="")
     ap.add_argument("--loop-names", default="", help="comma-separated subset of the loop fixtures")
+    ap.add_argument("--hostref", default="", help="build container only: loopconv fixtures (comma-separated names) whose "
+                                                  "host steps are the reference's own imported host_functions.py")
     a = ap.parse_args()
     if a.compare:
         compare(a.compare)
@@ -337,5 +381,12 @@ if __name__ == "__main__":
         import loop_driver as ld
         for name in (a.loop_names.split(",") if a.loop_names else ld.LOOP_NAMES):
             loop_fixture(name)
+    if a.hostref:
+        for name in a.hostref.split(","):
+            loopconv_fixture(name, hostref=True)
+    elif not only or "loopconv" in only:
+        import loop_driver as ld
+        for name in ld.CONV_NAMES:
+            loopconv_fixture(name)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("wrote fixtures to %s, %.1f KB total" % (OUT, tot / 1024.0))

@@ -109,3 +109,164 @@ def loop_refresh(c):
 
 LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s", "onthefly")
 SNAP_AT = (1, 10, 11, 50)
+
+
+# ---- convection loop (source/computation.py:992-1174) ----------------------------------------------------------------
+"""Control flow followed line by line (reference source/computation.py):
+    :998-1009  kappa (a constant here: interpolate_kappa_and_cp launches nothing, :202), conv_check,
+               mark_convective_layers(stitching=0); condition = sum(conv_unstable) > 0
+    :1016      iter_value = 0 (the loop counts its own iterations)
+    :1043      temp_inter
+    :1046-1051 mean molecular mass when iter % 10 == 0 (premixed: meanmolmass_interpol for layers and interfaces)
+    :1053-1061 D2H of kappa, c_p, mu, T, F_smooth_sum; host convective_adjustment; H2D of T_lay
+    :1063-1064 temp_inter again, Planck interpolation
+    :1067-1085 opacities / transmission / heights / beam when iter % 10 == 0
+    :1086-1090 3*scat+1 sweeps (or the matrix solve), quadrature -- NO rad_temp_iter
+    :1107      mark_convective_layers(stitching=1) with the adjusted profile
+    :1110-1112 physical time step: one adjustment, no temperature iteration
+    :1116      condition = not check_for_radiative_eq or iter < 400 or sum(conv_layer) == 0
+    :1122-1149 if condition: conv_temp_iter with conv_layer / marked_red of this iteration, iter += 1
+    :1158-1159 rad_convergence_limit *= 10 when iter is in crit_relaxation_numbers
+    :1162-1165 abort when iter > max_nr_iterations
+Host steps come from `hs`: helios_amd/host_functions.py (pinned function by function to the reference's Python,
+tests/test_host_golden.py) on the GPU box, or the reference's own source/host_functions.py imported in the build
+container (tests/golden/make_golden.py --hostref)."""
+CONV_SNAP_AT = (1, 10, 11, 50, 400)
+CONV_SNAP_KEYS = SNAP_KEYS + ("F_net_diff",)
+
+
+def conv_quant(c, s, kappa, dampara="automatic"):
+    """the attributes of the reference's Store that its host functions touch in the convection loop, sharing the
+    arrays of the case `c` and the kernel state `s` (the kernels write F_net etc. in place)"""
+    L = c.nlayer
+    q = cases.Case()
+    q.nlayer, q.ninterface = L, L + 1
+    q.p_lay, q.p_int, q.T_lay = c.p_lay, c.p_int, c.T_lay
+    q.kappa_lay, q.kappa_int = np.full(L, float(kappa)), np.full(L + 1, float(kappa))
+    q.c_p_lay = c.c_p_lay
+    q.meanmolmass_lay = s.meanmolmass_lay
+    q.F_net, q.F_up_tot, q.F_down_tot, q.F_net_diff = s.F_net, s.F_up_tot, s.F_down_tot, s.F_net_diff
+    q.F_add_heat_sum, q.F_smooth_sum = c.F_add_heat_sum, c.F_smooth_sum
+    q.F_intern, q.T_star = c.F_intern, c.T_star
+    q.rad_convergence_limit = c.rad_convergence_limit
+    q.input_dampara = dampara
+    q.conv_unstable = np.zeros(L + 1, np.int32)
+    q.conv_layer = np.zeros(L + 1, np.int32)
+    q.marked_red = np.zeros(L + 1, np.int32)
+    q.converged = np.zeros(L + 1, np.int32)
+    q.iter_value = 0
+    q.delta_colmass = c.delta_colmass
+    return q
+
+
+def conv_snapshot(c, s, q):
+    out = snapshot(c, s)
+    out["F_net_diff"] = s.F_net_diff.copy()
+    for k in ("conv_layer", "conv_unstable", "marked_red"):
+        out[k] = np.asarray(q[k], np.int32).copy()
+    return out
+
+
+def mean_molecular_mass(impl, c, s):
+    """:1046-1051 -- premixed: the table look-up on layers and interfaces; on the fly: constant mixing ratios in the
+    test columns, so the value of the last refresh stands (calculate_meanmolecularmass gives the same numbers)"""
+    if c.get("species"):
+        return
+    L, I = c.nlayer, c.ninterface
+    impl.meanmolmass_interpol(c.T_lay, c.ktemp, s.meanmolmass_lay, c.opac_meanmass, c.p_lay, c.kpress, c.npress,
+                              c.ntemp, L)
+    if c.iso == 0:
+        impl.meanmolmass_interpol(c.T_int, c.ktemp, s.meanmolmass_int, c.opac_meanmass, c.p_int, c.kpress, c.npress,
+                                  c.ntemp, I)
+
+
+def convection_loop(impl, hs, c, s, kappa, snap_at=(), max_nr_iterations=20000, crit_relaxation_numbers=(),
+                    refresh=cases.refresh_premixed, dampara="automatic", on_iteration=None):
+    """runs the loop until the reference's loop would leave it; the state (c, s) is the one the radiation loop left.
+    Returns (iter_count, snaps, q): snaps[n] = state when the iteration counter has just become n."""
+    L = c.nlayer
+    q = conv_quant(c, s, kappa, dampara)
+    hs.conv_check(q)
+    hs.mark_convective_layers(q, stitching=0)
+    condition = int(np.sum(q.conv_unstable)) > 0
+    snaps = {"start": conv_snapshot(c, s, q)}
+    while condition:
+        it = int(q.iter_value)
+        impl.temp_inter(c.T_lay, c.T_int, L + 1)
+        if it % 10 == 0:
+            mean_molecular_mass(impl, c, s)
+        hs.convective_adjustment(q)
+        impl.temp_inter(c.T_lay, c.T_int, L + 1)
+        cases.interpolate_temperatures_and_planck(impl, c, s)
+        if it % 10 == 0:
+            refresh(impl, c, s)
+        cases.flux_sweeps(impl, c, s)
+        cases.integrate_and_step(impl, c, s, it, step_temperature=False)
+        hs.mark_convective_layers(q, stitching=1)
+        if c.physical_tstep != 0:
+            break
+        q.rad_convergence_limit = c.rad_convergence_limit
+        condition = (not hs.check_for_radiative_eq(q)) or it < 400 or int(np.sum(q.conv_layer)) == 0
+        if condition:
+            marked = np.ascontiguousarray(q.marked_red, np.int32)
+            impl.conv_temp_iter(s.F_net, s.F_net_diff, c.T_lay, c.p_lay, c.p_int, s.T_store, s.deltat_prefactor, marked,
+                                c.F_add_heat_lay, c.F_smooth, c.F_smooth_sum, L, it, c.adapt_interval, c.smooth,
+                                c.F_intern)
+            q.iter_value = it + 1
+            if q.iter_value in snap_at:
+                snaps[int(q.iter_value)] = conv_snapshot(c, s, q)
+            if on_iteration is not None:
+                on_iteration(int(q.iter_value), c, s, q)
+        if q.iter_value in crit_relaxation_numbers:
+            c.rad_convergence_limit *= 10.0
+        if q.iter_value > max_nr_iterations:
+            break
+    snaps["end"] = conv_snapshot(c, s, q)
+    return int(q.iter_value), snaps, q
+
+
+CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "detached")
+CONV_SIZE = dict(nbin=6, nlayer=16, ntemp=6, npress=5, plancktable_dim=800, plancktable_step=10)
+
+
+def conv_case(name):
+    """the small columns whose rad.-conv. runs are committed as goldens (tests/golden/loopconv_<name>.npz):
+    (case, kappa, run_radiation_loop_first).  `deep`: one convective zone at the bottom that includes the surface
+    (radiation loop 3001 iterations, convection loop 1121); `beam_albedo`: the same with direct beam and reflecting
+    surface; `clouds_g0_i2s`: config 5's physics (cloud decks, g0, I2S correction, beam, albedo); `detached`: the
+    convection loop entered with a profile that has two super-adiabatic regions separated by a radiative zone
+    (two zones with their own fudge factors for ~200 iterations, kappa = 0.25, no radiation loop before it)"""
+    from helios_amd import phys_const as pc
+    kw = dict(CONV_SIZE)
+    kappa, radiative_first = 2.0 / 7.0, True
+    if name in ("deep", "deep_hostref"):
+        kw.update(T_intern=450.0)
+    elif name == "beam_albedo":
+        kw.update(dir_beam=1, albedo=0.3, T_intern=350.0)
+    elif name == "clouds_g0_i2s":
+        kw.update(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0, T_intern=350.0)
+    elif name == "detached":
+        kw.update(nlayer=20, dir_beam=1, albedo=0.2, T_intern=300.0)
+        kappa, radiative_first = 0.25, False
+    else:
+        raise KeyError(name)
+    c = cases.make_case(**kw)
+    c.c_p_lay = np.full(c.nlayer, pc.R_UNIV / kappa)              # read.py:1178-1180
+    if name == "detached":
+        p = c.p_lay
+        T = 1500.0 * (p / p[0]) ** 0.10
+        T[2:6] = T[2] * (p[2:6] / p[2]) ** 0.5
+        T[6:] = T[5] * (p[6:] / p[5]) ** 0.05
+        T[9:12] = T[9] * (p[9:12] / p[9]) ** 0.45
+        T[12:] = T[11] * (p[12:] / p[11]) ** 0.03
+        c.T_lay = np.append(T, T[0] * 1.0001)
+    return c, kappa, radiative_first
+
+
+def rad_conv_run(impl, hs, c, s, kappa, radiative_first):
+    """radiation loop (when the case has one), then the convection loop from the state it leaves"""
+    n_rad = 0
+    if radiative_first:
+        n_rad, _snaps, _reason = radiation_loop(impl, c, s)
+    n, snaps, q = convection_loop(impl, hs, c, s, kappa, snap_at=CONV_SNAP_AT)
+    return n_rad, n, snaps, q

@@ -6,7 +6,8 @@ import numpy as np
 from helios_amd import quantities as quant_mod
 
 
-def store_from_case(ctx, c, crit_relaxation_numbers=(), max_nr_iterations=20000, name="case"):
+def store_from_case(ctx, c, crit_relaxation_numbers=(), max_nr_iterations=20000, name="case", convection=0,
+                    kappa=2.0 / 7.0):
     q = quant_mod.Store(ctx)
     i32, f64 = np.int32, np.float64
     for k in ("nbin", "ny", "nlayer", "ntemp", "npress", "iso", "scat", "dir_beam", "clouds", "scat_corr",
@@ -19,7 +20,7 @@ def store_from_case(ctx, c, crit_relaxation_numbers=(), max_nr_iterations=20000,
         setattr(q, k, f64(c[k]))
     q.no_atmo_mode = i32(c.no_atmo)
     q.singlewalk = i32(0)
-    q.convection = i32(0)
+    q.convection = i32(convection)
     q.opacity_mixing = "premixed"
     q.kcoeff_mixing = "correlated-k"
     q.flux_calc_method = "iteration"
@@ -29,8 +30,8 @@ def store_from_case(ctx, c, crit_relaxation_numbers=(), max_nr_iterations=20000,
     q.coupling = i32(0)
     q.add_heating = i32(0)
     q.energy_correction = i32(1)
-    q.input_kappa_value = 2.0 / 7.0
-    q.input_dampara = "auto"
+    q.input_kappa_value = np.float64(kappa)
+    q.input_dampara = "automatic"
     q.runtime_limit = f64(0)
     q.max_nr_iterations = i32(max_nr_iterations)
     q.crit_relaxation_numbers = [i32(r) for r in crit_relaxation_numbers]
@@ -41,8 +42,8 @@ def store_from_case(ctx, c, crit_relaxation_numbers=(), max_nr_iterations=20000,
               "scat_cross_all_clouds_lay", "g_0_all_clouds_lay", "abs_cross_all_clouds_int",
               "scat_cross_all_clouds_int", "g_0_all_clouds_int"):
         setattr(q, k, np.array(c[k], f64).copy())
-    q.kappa_lay = np.full(int(q.nlayer), 2.0 / 7.0)
-    q.kappa_int = np.full(int(q.nlayer) + 1, 2.0 / 7.0)
+    q.kappa_lay = np.full(int(q.nlayer), float(kappa))
+    q.kappa_int = np.full(int(q.nlayer) + 1, float(kappa))
     q.dimensions()
     q.create_zero_arrays()
     q.convert_input_list_to_array()

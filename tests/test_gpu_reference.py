@@ -281,3 +281,89 @@ def test_compute_radiation_loop_leaves_where_the_reference_does(ctx, port, capsy
     Compute(ctx).radiation_loop(q)
     assert int(q.iter_value) == n and int(q.convection) == 1
     np.testing.assert_allclose(q.dev_T_lay.get(), snaps["end"]["T_lay"], rtol=1e-8)
+
+
+def _conv_snapshot(rt, c):
+    X, I = c.nbin, c.ninterface
+    return dict(F_net=rt.get("F_net"), F_up_tot=rt.get("F_up_tot"), F_down_tot=rt.get("F_down_tot"),
+                F_net_diff=rt.get("F_net_diff"), T_lay=rt.get("T_lay"), F_up_band_TOA=rt.get("F_up_band")[X * (I - 1):],
+                F_down_band_BOA=rt.get("F_down_band")[:X], F_dir_band_BOA=rt.get("F_dir_band")[:X],
+                deltat_prefactor=rt.get("delta_t_prefactor"), conv_layer=rt.get("conv_layer"),
+                conv_unstable=rt.get("conv_unstable"), marked_red=rt.get("marked_red"))
+
+
+@pytest.mark.parametrize("name", gc.CONV_NAMES)
+def test_fused_convection_loop_golden(ctx, name):
+    """hx_rt_run to convergence, then hx_rt_conv_run (convective adjustment, sweeps, layer marking, equilibrium test and
+    temperature step on the device) against the radiation + convection loops of the reference's kernels under the
+    reference's control flow (loopconv_*.npz; deep_hostref: host steps by the reference's own Python): both iteration
+    counts, every layer flag after 1, 10, 11, 50, 400 iterations and at the end exactly, T / fluxes / spectrum 1e-6"""
+    from helios_amd import host_functions as hs
+    from helios_amd.rt import batch_from_case
+
+    def run(c, s, kappa, radiative_first):
+        L = c.nlayer
+        rt = batch_from_case(ctx, c)
+        try:
+            rt.build_planck_table(1 if c.T_star > 10 else 0)
+            n_rad = 0
+            if radiative_first:
+                done = 0
+                while not done:
+                    rt.run(n_rad, 10 - n_rad % 10)
+                    n_rad += 10 - n_rad % 10
+                    done = int(rt.get("done")[0])
+                    assert n_rad < 40000
+                n_rad = int(rt.get("iters_done")[0])
+            # entry of the loop, computation.py:998-1009 (what Compute._convection_loop_fused does)
+            q = ld.conv_quant(c, s, kappa)
+            q.T_lay = rt.get("T_lay")
+            hs.conv_check(q)
+            hs.mark_convective_layers(q, stitching=0)
+            assert q.conv_unstable.sum() > 0
+            for nm, v in (("kappa_lay", q.kappa_lay), ("kappa_int", q.kappa_int), ("c_p_lay", np.asarray(c.c_p_lay, float)),
+                          ("conv_layer", q.conv_layer), ("conv_unstable", q.conv_unstable), ("dampara", np.array([-1.0])),
+                          ("done", np.zeros(1, np.int32))):
+                rt.set_state(0, nm, v)
+            snaps = {"start": dict(T_lay=q.T_lay, conv_layer=q.conv_layer, conv_unstable=q.conv_unstable)}
+            it = 0
+            while True:
+                nxt = min([p for p in ld.CONV_SNAP_AT if p > it] + [it + 10 - it % 10])
+                rt.conv_run(it, nxt - it)
+                done = int(rt.get("done")[0])
+                it = int(rt.get("iters_done")[0]) if done else nxt
+                if done:
+                    snaps["end"] = _conv_snapshot(rt, c)
+                    return n_rad, it, snaps
+                if it in ld.CONV_SNAP_AT:
+                    snaps[it] = _conv_snapshot(rt, c)
+                assert it < 20000
+        finally:
+            rt.close()
+    gc.check_loopconv(run, name)
+
+
+@pytest.mark.parametrize("use_fused", [True, False])
+@pytest.mark.parametrize("name", [n for n in gc.CONV_NAMES if n != "detached"])
+def test_compute_convection_loop_golden(ctx, name, use_fused, capsys):
+    """the product's drivers -- Compute.radiation_loop followed by Compute.convection_loop on a Store, on the fused
+    device-resident path and through the per-stage entry points with the adjustment in helios_amd/host_functions.py --
+    against the reference-kernel loops: iteration counts, layer flags, T-P profile, net flux, emission spectrum"""
+    from helios_amd.computation import Compute
+    from store_helpers import store_from_case
+    c, z = gc.load_chain(name, prefix="loopconv_")
+    q = store_from_case(ctx, c, convection=1, kappa=float(z["kappa"]))
+    comp = Compute(ctx)
+    comp.use_fused = use_fused
+    comp.radiation_loop(q)
+    assert int(q.iter_value) == int(z["rad_iter_count"])
+    comp.convection_loop(q)
+    assert int(q.iter_value) == int(z["iter_count"])
+    X, I = c.nbin, c.ninterface
+    np.testing.assert_array_equal(np.asarray(q.conv_layer), z["end.conv_layer"])
+    np.testing.assert_array_equal(np.asarray(q.marked_red), z["end.marked_red"])
+    np.testing.assert_allclose(q.dev_T_lay.get(), z["end.T_lay"], rtol=1e-6)
+    fs = np.abs(z["end.F_up_tot"]).max()
+    np.testing.assert_allclose(q.dev_F_net.get(), z["end.F_net"], rtol=1e-6, atol=1e-9 * fs)
+    np.testing.assert_allclose(q.dev_F_up_band.get()[X * (I - 1):], z["end.F_up_band_TOA"], rtol=1e-6,
+                               atol=1e-13 * z["end.F_up_band_TOA"].max())

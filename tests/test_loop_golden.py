@@ -36,3 +36,30 @@ def test_loop_fixtures_cover_the_survey_list():
     for at in ("it1", "it10", "it11", "it50", "end"):
         assert at + ".T_lay" in z.files
     assert "gfx950" in str(z["meta"])
+
+
+@pytest.mark.parametrize("name", ld.CONV_NAMES + ("deep_hostref",))
+def test_oracle_convection_loop_golden(port, name, capsys):
+    """radiation loop + convection loop (source/computation.py:992-1174 restated in tests/loop_driver.py) through the C
+    oracle and helios_amd/host_functions.py against the loops of the reference's kernels on the MI355X
+    (loopconv_<name>.npz) and against the loop the reference's own Python host functions drove in the build container
+    (loopconv_deep_hostref.npz): same iteration counts, same layer flags, T / fluxes / spectrum within 1e-6"""
+    from helios_amd import host_functions as hs
+
+    def run(c, s, kappa, radiative_first):
+        n_rad, n, snaps, _q = ld.rad_conv_run(port, hs, c, s, kappa, radiative_first)
+        return n_rad, n, snaps
+    z = gc.check_loopconv(run, name)
+    assert ("imported" in str(z["meta"])) == name.endswith("hostref")
+
+
+def test_convection_loop_fixtures_cover_the_verdict_list():
+    for name in ld.CONV_NAMES:
+        z = np.load(gc.os.path.join(gc.GOLDEN, "loopconv_%s.npz" % name))
+        for at in ("start", "it1", "it10", "it11", "it50", "it400", "end"):
+            for k in ("T_lay", "F_net", "F_up_band_TOA", "conv_layer", "marked_red"):
+                assert "%s.%s" % (at, k) in z.files
+        assert "gfx950" in str(z["meta"]) and int(z["iter_count"]) >= 400
+    z = np.load(gc.os.path.join(gc.GOLDEN, "loopconv_detached.npz"))
+    zones = "".join(str(int(v)) for v in z["it10.conv_layer"])
+    assert "10" in zones.strip("0")                       # two zones with a radiative hole between them
