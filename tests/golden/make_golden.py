@@ -316,14 +316,15 @@ def loopconv_fixture(name, hostref=False):
     with contextlib.redirect_stdout(io.StringIO()):       # check_for_radiative_eq prints every 100th iteration
         n_rad, n, snaps, q = ld.rad_conv_run(ref, hs, c, s, kappa, radiative_first)
     data["rad_iter_count"] = np.array(n_rad)
+    data["rad_reason"] = np.array(q.rad_reason)
     data["iter_count"] = np.array(n)
     for at, sn in snaps.items():
         for k, v in sn.items():
             data["%s.%s" % (("it%d" % at) if isinstance(at, int) else at, k)] = v
     fn = "loopconv_%s%s.npz" % (name, "_hostref" if hostref else "")
     np.savez_compressed(os.path.join(OUT, fn), **data)
-    print("%s: radiation loop %d, convection loop %d iterations, conv_layer %s"
-          % (fn, n_rad, n, "".join(str(int(v)) for v in q.conv_layer)), flush=True)
+    print("%s: radiation loop %d (%s), convection loop %d iterations, conv_layer %s"
+          % (fn, n_rad, q.rad_reason, n, "".join(str(int(v)) for v in q.conv_layer)), flush=True)
 
 
 def compare(other):

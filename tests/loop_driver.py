@@ -225,24 +225,31 @@ def convection_loop(impl, hs, c, s, kappa, snap_at=(), max_nr_iterations=20000, 
     return int(q.iter_value), snaps, q
 
 
-CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "detached")
+CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "surface_jump", "detached")
 CONV_SIZE = dict(nbin=6, nlayer=16, ntemp=6, npress=5, plancktable_dim=800, plancktable_step=10)
 
 
 def conv_case(name):
     """the small columns whose rad.-conv. runs are committed as goldens (tests/golden/loopconv_<name>.npz):
-    (case, kappa, run_radiation_loop_first).  `deep`: one convective zone at the bottom that includes the surface
-    (radiation loop 3001 iterations, convection loop 1121); `beam_albedo`: the same with direct beam and reflecting
-    surface; `clouds_g0_i2s`: config 5's physics (cloud decks, g0, I2S correction, beam, albedo); `detached`: the
-    convection loop entered with a profile that has two super-adiabatic regions separated by a radiative zone
-    (two zones with their own fudge factors for ~200 iterations, kappa = 0.25, no radiation loop before it)"""
+    (case, kappa, run_radiation_loop_first).  `deep`: the radiation loop converges (1202 iterations), the equilibrium
+    profile is super-adiabatic at the bottom, the convection loop (2921) ends with one zone at the bottom; `beam_albedo`:
+    the same with direct beam and reflecting surface (rad_convergence_limit 1e-7); `clouds_g0_i2s`: config 5's physics
+    (cloud decks, g0, I2S correction, beam, albedo) -- its radiation loop leaves through the surface-temperature check
+    of iterations 0, 100, ... (computation.py:946-952: "jump directly to convective loop"), as does `surface_jump`
+    (strong internal heat); `detached`: the convection loop entered with a profile that has two super-adiabatic regions
+    separated by a radiative zone (two zones with their own fudge factors for ~200 iterations, kappa = 0.25, no
+    radiation loop before it)"""
     from helios_amd import phys_const as pc
     kw = dict(CONV_SIZE)
     kappa, radiative_first = 2.0 / 7.0, True
+    limit = 1e-8
     if name in ("deep", "deep_hostref"):
+        kw.update(T_intern=250.0)
+    elif name == "surface_jump":
         kw.update(T_intern=450.0)
     elif name == "beam_albedo":
-        kw.update(dir_beam=1, albedo=0.3, T_intern=350.0)
+        kw.update(dir_beam=1, albedo=0.3, T_intern=200.0)
+        limit = 1e-7
     elif name == "clouds_g0_i2s":
         kw.update(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0, T_intern=350.0)
     elif name == "detached":
@@ -251,6 +258,7 @@ def conv_case(name):
     else:
         raise KeyError(name)
     c = cases.make_case(**kw)
+    c.rad_convergence_limit = limit
     c.c_p_lay = np.full(c.nlayer, pc.R_UNIV / kappa)              # read.py:1178-1180
     if name == "detached":
         p = c.p_lay
@@ -265,8 +273,9 @@ def conv_case(name):
 
 def rad_conv_run(impl, hs, c, s, kappa, radiative_first):
     """radiation loop (when the case has one), then the convection loop from the state it leaves"""
-    n_rad = 0
+    n_rad, reason = 0, "not run"
     if radiative_first:
-        n_rad, _snaps, _reason = radiation_loop(impl, c, s)
+        n_rad, _snaps, reason = radiation_loop(impl, c, s)
     n, snaps, q = convection_loop(impl, hs, c, s, kappa, snap_at=CONV_SNAP_AT)
+    q.rad_reason = reason
     return n_rad, n, snaps, q

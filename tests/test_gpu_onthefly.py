@@ -302,17 +302,20 @@ def test_isothermal_layers_iterate_on_the_fused_path_and_refuse_convection(tmp_p
 @pytest.mark.parametrize("extra", [[], ["-direct_irradiation_beam", "yes", "-surface_albedo", "0.2"]])
 def test_convection_loop_on_device_reaches_the_host_driven_equilibrium(tmp_path, extra):
     """the convection loop with the convective adjustment on the GPU (hx_rt_conv_*) against the per-stage loop whose
-    adjustment runs in helios_amd/host_functions.py.  The loop amplifies 1e-10 differences through its discrete
-    decisions (time-step adaptation, layer flags) -- trajectories part after ~50 iterations and meet again at the
-    equilibrium, so the END states are compared (the step-by-step identity is the next test)."""
-    argv = CONV_ARGV + ["-output_directory", str(tmp_path) + "/"] + extra
+    adjustment runs in helios_amd/host_functions.py, both started by run_helios: same number of iterations, same
+    convective layers, T-P profile and emission spectrum to 1e-7 (measured 8e-10 / 1e-15; with the criterion at 1e-8 the
+    exit test itself is at rounding level and the two runs leave 0-60 iterations apart, 4e-10 from each other).  Both
+    loops are held to the reference's by tests/test_gpu_reference.py::test_compute_convection_loop_golden."""
+    argv = list(CONV_ARGV)
+    argv[argv.index("-radiative_equilibrium_criterion") + 1] = "1e-6"
+    argv += ["-output_directory", str(tmp_path) + "/"] + extra
     a = _run_driver(argv, True)
     b = _run_driver(argv, False)
-    assert a.conv_layer.sum() > 2 and int(a.iter_value) >= 400 and int(b.iter_value) >= 400
-    assert abs(int(a.iter_value) - int(b.iter_value)) < 0.5 * int(b.iter_value)
+    assert a.conv_layer.sum() > 2 and int(a.iter_value) >= 400
+    assert int(a.iter_value) == int(b.iter_value)
     np.testing.assert_array_equal(a.conv_layer, b.conv_layer)
-    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=2e-4)
-    np.testing.assert_allclose(a.F_up_band, b.F_up_band, rtol=2e-3, atol=1e-9 * b.F_up_band.max())
+    np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-7)
+    np.testing.assert_allclose(a.F_up_band, b.F_up_band, rtol=1e-7, atol=1e-12 * b.F_up_band.max())
     from helios_amd import host_functions as hs
     for q in (a, b):
         assert abs(hs.global_energy_imbalance(q)) < 1e-3
