@@ -280,7 +280,10 @@ def check_loopconv(run, name, rtol_T=1e-6, rtol_flux=1e-6):
                 if isinstance(at, int) and at <= 50:
                     _close(got, want, rtol=1e-9, name=key)
             elif k in ("F_net", "F_net_diff"):
-                _close(got, want, rtol=rtol_flux, atol=1e-9 * fscale, name=key)      # differences of the totals
+                # differences of the totals, which are held to 1e-6 themselves: the net flux at the bottom is 1e-2 of them.
+                # Observed: <= 1e-9 of the totals against the gfx950 build, 6e-8 against the host build of the reference
+                # after 50 iterations, while the surface still moves by 20 K per iteration (T within 2.5e-8 there)
+                _close(got, want, rtol=rtol_flux, atol=1e-6 * fscale, name=key)
             else:
                 _close(got, want, rtol=rtol_flux, atol=1e-13 * max(np.abs(want).max(), 1e-300), name=key)
     return z
