@@ -11,12 +11,15 @@ temperatures, Planck interpolation, every-10th-iteration opacity/transmission re
 two-stream sweeps, flux integration, temperature step -- all through libhelios_hip.so (hx_rt_step).
 Inputs are resident in HBM before the timed region.
 
-N = 1 (default): BASELINE config 2, the configuration the metric is quoted on.  N > 1 (default): BASELINE
-config 4 -- the 512-column parameter sweep (8 x 8 x 8 over gravity, orbital distance and internal temperature,
-SURVEY.md 8(d)) with on-the-fly mixing of 20 species -- as each GPU's share of the 8-GPU run: 64 columns per
-GPU in one batch (weak scaling: the per-GPU work is fixed; 512 columns at N = 8).  One process per GPU, columns
-sharded, no collective on the iteration path; the output spectra are gathered over RCCL once after the timed
-region.  `--workload` / `--columns-per-gpu` override the defaults.
+ONE workload for every N: `value` is config 2 on every GPU (one column per GPU, each with its own start profile; weak
+scaling, no collective on the iteration path, the emission spectra gathered over RCCL once after the timed region), so
+the N = 1 member of a 1/2/4/8 series IS the single-GPU headline.  `python bench.py --gpus N` without a launcher starts
+the N ranks itself (a child `python -m torch.distributed.run ...`, before this process touches a GPU).
+
+The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly) and config 5 (30 000
+x 200, 20 species on the fly, two cloud decks, beam, albedo, I2S); at N > 1 config 4 -- each GPU's share of the
+512-column sweep, 64 on-the-fly columns per GPU in one batch.  `steady_state_200` is the headline workload over 200
+iterations from iteration 0 (20 refreshes), SURVEY.md 8(d)'s definition of the metric.
 """
 import argparse
 import json
@@ -37,9 +40,16 @@ WORKLOADS = {
                desc="BASELINE config 1 shape: 300 bins x 50 layers, premixed"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
                desc="BASELINE config 3: on-the-fly mixing, 20 species random overlap, 10 000 bins x 100 layers"),
-    "c5": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, clouds=2, albedo=0.1, scat_corr=1,
-               desc="BASELINE config 5 shape, one column: 30 000 bins x 200 layers, non-iso scattering (I2S "
-                    "correction), two cloud decks, surface albedo; premixed table (the mixing cost is config 3's)"),
+    "c5": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, nspecies=20, clouds=2, albedo="smoothed", scat_corr=1,
+               g_0=0.3, dir_beam=1,
+               desc="BASELINE config 5, one column: 30 000 bins x 200 layers, 20 species mixed on the fly (random overlap), "
+                    "non-isotropic scattering (g0 = 0.3, I2S correction), two cloud decks, direct beam at 60 deg, surface "
+                    "albedo U(0.05, 0.4); 12 x 10 (T, P) nodes per k-table (11.5 GB of tables)"),
+    "c5premixed": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, clouds=2, albedo=0.1, scat_corr=1, g_0=0.1,
+                       desc="config 5's shape with a premixed table: 30 000 bins x 200 layers, I2S correction, two cloud "
+                            "decks, surface albedo, no beam (round 1-2's c5)"),
+    "c5small": dict(nbin=600, nlayer=200, ny=20, ntemp=6, npress=5, nspecies=6, clouds=2, albedo="smoothed", scat_corr=1,
+                    g_0=0.3, dir_beam=1, desc="config 5's physics at 600 bins x 200 layers x 6 species (quick check)"),
     "c4": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=64, sweep=True,
                desc="BASELINE config 4, one GPU's share of the 512-column sweep at 8 GPUs: 64 columns per GPU (g x a x "
                     "T_intern grid), on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
@@ -77,7 +87,8 @@ def build_case(w, seed):
     c.opac_interwave, c.opac_wave, c.opac_deltawave = syn.wavelength_grid(c.nbin)
     c.gauss_y, c.gauss_weight = syn.gauss_points(c.ny)
     c.ktemp, c.kpress = syn.tp_grid(c.ntemp, c.npress)
-    c.opac_k = syn.ktable(rng, c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+    # (with species the premixed table is never read: draw the same random numbers, skip the 0.6-1 GB array)
+    c.opac_k = syn.ktable(rng, 8 if w.get("nspecies") else c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
     c.opac_scat_cross = syn.rayleigh_table(c.opac_wave, c.ntemp, c.npress)
     c.opac_meanmass = syn.meanmass_table(c.ntemp, c.npress)
     c.p_lay, c.p_int = syn.pressure_levels(1e9, 1e-1, c.nlayer)
@@ -86,10 +97,14 @@ def build_case(w, seed):
     c.surf_albedo = np.zeros(c.nbin)
     c.starflux = np.zeros(c.nbin)
     c.c_p_lay = np.full(c.nlayer, 3.5 * pc.R_UNIV)
-    if w.get("albedo"):
+    if w.get("albedo") == "smoothed":       # U(0.05, 0.4) smoothed over 5 bins
+        c.surf_albedo = syn._smooth5(rng.uniform(0.05, 0.4, c.nbin))
+    elif w.get("albedo"):
         c.surf_albedo = np.full(c.nbin, float(w["albedo"]))
     if w.get("scat_corr"):
-        c.scat_corr, c.g_0 = 1, 0.1
+        c.scat_corr, c.g_0 = 1, float(w.get("g_0", 0.1))
+    if w.get("dir_beam"):
+        c.dir_beam = 1                      # zenith angle 60 deg: mu_star above
     if w.get("clouds"):
         c.clouds = 1            # two synthetic decks (bases at 0.1 bar and 1 mbar), SURVEY.md 8(d) config 5
         c.update(syn.cloud_arrays(c.nbin, c.nlayer, c.opac_wave, np.asarray(c.p_lay), np.asarray(c.p_int), rng))
@@ -165,7 +180,7 @@ def cpu_baseline(w, seed):
     """the CPU oracle (oracle/helios_oracle.c, OpenMP over bins) on a bounded sample of the same workload, from
     iteration 0 (one opacity refresh per 10 iterations).  Premixed: ALL bins, 30 iterations.  On-the-fly mixing
     (the reference's bubble sort of 400 sums per point and species): 4000 of the bins, 20 iterations, i.e. two
-    refreshes.  Thread count fixed at min(usable cores, 64)."""
+    refreshes.  The thread count is probed (8 ... all usable cores) and the winner stated."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     lib, flags = native_oracle()
@@ -203,19 +218,37 @@ def cpu_baseline(w, seed):
         cc.species = sp
         refresh = cases.refresh_onthefly
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(ncpu, 64))
-    lib.set_num_threads(threads)
+    T0 = np.array(c.T_lay, float).copy()
     s = cases.alloc_state(cc)
     cases.setup_planck(lib, cc, s)
+    # thread-count probe (all cores or a shown optimum): the first refresh + iteration, then three
+    # refresh-free iterations per candidate on the same state; the fastest count runs the sample
+    lib.set_num_threads(min(ncpu, 64))
+    cases.radiation_iterations(lib, cc, s, 1, refresh=refresh)
+    probe = {}
+    for th in sorted(set(t for t in (8, 16, 32, 64, 96, 128, 192, 256, ncpu) if t <= ncpu)):
+        lib.set_num_threads(th)
+        t0 = time.perf_counter()
+        cases.radiation_iterations(lib, cc, s, 3, start=1, refresh=refresh)
+        probe[th] = 3.0 / (time.perf_counter() - t0)
+    threads = max(probe, key=probe.get)
+    lib.set_num_threads(threads)
+    cc2 = cases.Case(cc)                      # the sample starts from iteration 0 on a fresh state
+    cc2.T_lay = T0
+    cc2.T_int = np.zeros(c.nlayer + 1)
+    cc2.z_lay = np.zeros(c.nlayer)
+    s = cases.alloc_state(cc2)
+    cases.setup_planck(lib, cc2, s)
     t0 = time.perf_counter()
-    cases.radiation_iterations(lib, cc, s, n_it, refresh=refresh)
+    cases.radiation_iterations(lib, cc2, s, n_it, refresh=refresh)
     dt = time.perf_counter() - t0
     return dict(value=n_it / dt * nb * c.nlayer, unit="bin*layer*iterations/s", cores=threads, kind="port",
+                host_cores=ncpu, thread_probe_iterations_per_s={str(k): round(v, 3) for k, v in probe.items()},
                 sample="%d of %d bins x %d layers x %d Gauss points%s, %d iterations from iteration 0 (one opacity "
-                       "refresh per 10), oracle/helios_oracle.c built %s with OpenMP over bins on %d threads (%d usable "
-                       "cores), %.1f s"
+                       "refresh per 10), oracle/helios_oracle.c built %s with OpenMP over bins on %d threads (the fastest "
+                       "of %s on %d usable cores, probed on refresh-free iterations), %.1f s"
                        % (nb, w["nbin"], c.nlayer, c.ny, ", %d species" % len(c.species) if species else "", n_it,
-                          flags, threads, ncpu, dt))
+                          flags, threads, sorted(probe), ncpu, dt))
 
 
 def load_counters(workload):
@@ -231,71 +264,138 @@ def load_counters(workload):
     return (d, src) if d else (None, None)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
-    ap.add_argument("--columns-per-gpu", type=int, default=None)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-steps", type=int, default=20)
-    ap.add_argument("--phase", default="radiative", choices=["radiative", "convection"],
-                    help="which loop a step is taken from: radiation_loop (default, the headline number) or "
-                         "convection_loop (convective adjustment + sweeps + temperature step, all on the device)")
-    args = ap.parse_args()
+def env_knobs(allow_debug):
+    """every HELIOS_* tuning variable that is set goes into the line; the profiling knobs that change results
+    (HELIOS_RT_DEBUG_*) are refused unless asked for"""
+    knobs = {k: v for k, v in sorted(os.environ.items())
+             if k.startswith(("HELIOS_RT_", "HELIOS_RO_", "HELIOS_SWEEP_", "HELIOS_BENCH_"))}
+    bad = [k for k in knobs if k.startswith("HELIOS_RT_DEBUG_")]
+    if bad and not allow_debug:
+        raise SystemExit("bench.py: %s set -- these profiling knobs skip work inside the kernels (results are wrong, "
+                         "times are not the product's); unset them or pass --allow-debug-knobs" % ", ".join(bad))
+    return knobs
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    # N = 1: the configuration the metric is quoted on (config 2); N > 1: the sharded parameter sweep (config 4)
-    wname = args.workload or ("c2" if world == 1 else "c4")
-    w = WORKLOADS[wname]
-    heavy = bool(w.get("nspecies")) and w["nbin"] >= 5000
-    steps = args.steps if args.steps is not None else (20 if heavy else 200)
-    warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
-    ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
 
-    import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
-    dist = None
-    # test hook for single-GPU machines: HELIOS_BENCH_BACKEND=gloo runs all ranks on GPU 0 with CPU-side collectives,
-    # so that the multi-rank logic can be exercised where RCCL cannot (one GPU cannot host two RCCL ranks)
-    backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")
-    device_index = local_rank if backend == "nccl" else 0
-    coll_device = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(device_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (this process
+    has not touched a GPU and never will), relay its output -- rank 0 prints the line -- and leave with its code"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, cwd=ROOT).returncode)
 
-    from helios_amd.device import Context
 
-    seed = 20240 + 2
-    c = build_case(w, seed)
-    ctx = Context(device_index)
-    sweep = bool(w.get("sweep"))
-    rt = make_batch(ctx, c, ncol, first_column=rank * ncol, sweep=sweep)
-    # every column of a batch differs: the sweep's own parameters, or a few per cent in the start profile
-    if not sweep and (ncol > 1 or world > 1):
-        for i in range(ncol):
-            gi = rank * ncol + i
-            rt.set_temperatures(i, c.T_lay * (1.0 + 0.01 * gi))
-    rt.build_planck_table(1)
-    ctx.synchronize()
+class Ranks(object):
+    """the process group of this run (None at N = 1) and what the measurements need from it"""
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def __init__(self, dist, world, rank, coll_device):
+        self.dist, self.world, self.rank, self.coll_device = dist, world, rank, coll_device
+
+    def barrier(self, ctx):
+        import torch
+        if self.dist is not None:
+            self.dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    def gather_scalars(self, v, dtype=None):
+        import torch
+        if self.dist is None:
+            return [v]
+        t = torch.tensor([v], dtype=dtype or torch.float64, device=self.coll_device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [x.item() for x in out]
+
+
+def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
+    """the dominant kernel against the HBM roofline: algorithmic bytes per launch / HIP-event average of its launches on
+    the library's stream, in separate short passes behind the timed region (E-only iterations, one refresh on its own)"""
+    ctx = rt.ctx
+    tm = rt.traffic_model()
+    counters, counter_source = load_counters(wname)
+    it0 = start + (-start) % 10 + 1                 # right behind a refresh boundary
+    run(start, it0 - start)
+    ctx.synchronize()
+    ctx.timer_start()
+    run(it0, 9)                                     # nine iterations without a refresh
+    e_only_ms = ctx.timer_stop_ms() / 9.0
+    rt.profile(True)
+    run(it0 + 9, 1)                                 # iteration index = 0 mod 10: refresh + iteration
+    run(it0 + 10, min(profile_steps, 9))            # E-iterations under the event profiler
+    rt.profile(False)
+    flux_ms, nflux = rt.profile_read("rt_flux")
+    prof = {k: rt.profile_read(k)[0] for k in ("rt_flux", "refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
+                                               "opac_interpol", "direct_beam", "rt_nodes", "rt_totals_a", "rt_totals_b")}
+    t_only_ms = prof["refresh_total"]
+    B_E, B_T = tm["step_algorithmic"], tm["refresh_algorithmic"]      # bytes per launch, all columns
+    B = B_E + B_T / 10.0
+    mix_bound = bool(c.species) and prof["add_to_mixed_opac"] > 5.0 * flux_ms
+    roofline = None
+    if nflux and not mix_bound:
+        achieved = B_E / (flux_ms * 1e-3) / 1e9
+        traffic = counters.get("rt_flux_hbm_bytes_per_launch") if counters else None
+        if traffic is not None:
+            traffic *= ncol                         # measured with one column per launch
+        roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
+                        frac=achieved / 8000.0, traffic=traffic, traffic_source=counter_source if traffic else None,
+                        algorithmic_bytes_per_launch=B_E, actual_bytes_model_per_launch=tm["step_actual"],
+                        avg_launch_ms=flux_ms, launches_timed=nflux)
+        # what the chip streams at best (MI355X_MICROARCH.md: 6.29 TB/s float4 copy) on the bytes this kernel has to move
+        # with the reference's sweep semantics -- coefficient planes + up-flux state read and written (DESIGN.md section 4)
+        moved = traffic if traffic else tm["step_actual"]
+        roofline["frac_of_achievable"] = dict(
+            achieved=moved / (flux_ms * 1e-3) / 1e9, achievable=6290.0, unit="GB/s",
+            frac=moved / (flux_ms * 1e-3) / 1e9 / 6290.0, bytes_moved_per_launch=moved,
+            note="bytes the kernel moves / its launch time, against the 6.29 TB/s copy rate of the guide")
+    elif mix_bound:
+        # on-the-fly mixing: the refresh's species kernel is where the time goes.  Against HBM: B_T per launch;
+        # against vector issue (what actually binds it): instructions per launch from the committed PMC run
+        mix_ms = prof["add_to_mixed_opac"]
+        achieved = B_T / (mix_ms * 1e-3) / 1e9
+        traffic = counters.get("rt_mix_hbm_bytes_per_launch") if counters else None
+        roofline = dict(bound="hbm", kernel="k_rt_mix_species", achieved=achieved, peak=8000.0, unit="GB/s",
+                        frac=achieved / 8000.0, traffic=traffic * ncol if traffic else None,
+                        traffic_source=counter_source if traffic else None,
+                        algorithmic_bytes_per_launch=B_T, avg_launch_ms=mix_ms, launches_timed=1)
+        valu = counters.get("rt_mix_valu_instructions_per_launch") if counters else None
+        if valu:
+            peak = 1024 * 2.4e9 / 4.0               # SIMDs x clock / 4 cycles per wave64 instruction
+            rate = valu * ncol / (mix_ms * 1e-3)
+            roofline["valu_issue"] = dict(achieved=rate / 1e9, peak=peak / 1e9, unit="G wavefront-instructions/s",
+                                          frac=rate / peak, instructions_per_launch=valu * ncol, source=counter_source)
+    if roofline is not None:
+        whole = B / step_s / 1e9                    # SURVEY 8(d): B * iterations/s over the whole step
+        roofline["whole_step"] = dict(achieved=whole, peak=8000.0, unit="GB/s", frac=whole / 8000.0,
+                                      algorithmic_bytes_per_iteration=B)
+        roofline["e_only_ms_per_iteration"] = e_only_ms
+        roofline["t_only_ms_per_refresh"] = t_only_ms
+        roofline["kernels_ms"] = {k: v for k, v in prof.items() if v}
+    return roofline
+
+
+def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", profile_steps=20, steady_state=False):
+    """one workload on this rank's GPU: W warm-up steps, K timed steps between barriers (max over ranks), roofline
+    passes, the gather of the emission spectra.  Returns the fields of its line."""
+    import torch
+    w = WORKLOADS[wname]
+    rank, world = ranks.rank, ranks.world
+    c = build_case(w, seed)
+    sweep = bool(w.get("sweep"))
+    rt = make_batch(ctx, c, ncol, first_column=rank * ncol, sweep=sweep)
+    # every column of a run differs: the sweep's own parameters, or a few per cent in the start profile
+    T_start = [c.T_lay * (1.0 + 0.01 * (rank * ncol + i)) for i in range(ncol)]
+    if not sweep and (ncol > 1 or world > 1):
+        for i in range(ncol):
+            rt.set_temperatures(i, T_start[i])
+    rt.build_planck_table(1)
+    ctx.synchronize()
     run = rt.run
-    if args.phase == "convection":
+    if phase == "convection":
         # a profile with a super-adiabatic interior, so that every iteration adjusts a deep convective zone
         from helios_amd import phys_const as pc
         kap = 2.0 / 7.0
@@ -321,117 +421,46 @@ def main():
         run(warmup + device_warmup, 10)
         ctx.synchronize()
         device_warmup += 10
-    if dist is not None:   # every rank the same number of iterations (the slowest decides nothing here: take the max)
-        t = torch.tensor([device_warmup], dtype=torch.int64, device=coll_device)
-        allw = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(allw, t)
-        most = max(int(x.item()) for x in allw)
-        if most > device_warmup:
-            run(warmup + device_warmup, most - device_warmup)
-            device_warmup = most
+    most = int(max(ranks.gather_scalars(device_warmup, torch.int64)))   # every rank the same number of iterations
+    if most > device_warmup:
+        run(warmup + device_warmup, most - device_warmup)
+        device_warmup = most
     start = warmup + device_warmup
-    barrier()
+    ranks.barrier(ctx)
     t0 = time.perf_counter()
     ctx.timer_start()
     run(start, steps)
     ev_ms = ctx.timer_stop_ms()
-    barrier()
+    ranks.barrier(ctx)
     dt_local = time.perf_counter() - t0
-    dt = dt_local
-    rank_ms = [dt_local / steps * 1e3]
-    if dist is not None:
-        t = torch.tensor([dt_local], dtype=torch.float64, device=coll_device)
-        allt = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        rank_ms = [float(x.item()) / steps * 1e3 for x in allt]
-        dt = max(float(x.item()) for x in allt)
-
+    all_dt = ranks.gather_scalars(dt_local)
+    dt = max(all_dt)
+    rank_ms = [t / steps * 1e3 for t in all_dt]
     done = [int(rt.get("done", i)[0]) for i in range(ncol)]
 
-    # per-kernel timing with HIP events on the library's stream, in separate short passes after the timed region:
-    # E-only iterations (no refresh) and one refresh on its own
     roofline = None
-    tm = rt.traffic_model()
-    counters, counter_source = load_counters(wname)
-    if args.profile_steps > 0:
-        it0 = start + steps
-        it0 += (-it0) % 10 + 1                      # start right after a refresh boundary
-        run(start + steps, it0 - (start + steps))
-        ctx.synchronize()
-        ctx.timer_start()
-        run(it0, 9)                                 # nine iterations without a refresh
-        e_only_ms = ctx.timer_stop_ms() / 9.0
-        rt.profile(True)
-        run(it0 + 9, 1)                             # iteration index = 0 mod 10: refresh + iteration
-        run(it0 + 10, min(args.profile_steps, 9))   # E-iterations under the event profiler
-        rt.profile(False)
-        flux_ms, nflux = rt.profile_read("rt_flux")
-        prof = {k: rt.profile_read(k)[0] for k in ("refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
-                                                   "opac_interpol", "direct_beam", "rt_nodes", "rt_totals_a",
-                                                   "rt_totals_b")}
-        t_only_ms = prof["refresh_total"]
-        B_E, B_T = tm["step_algorithmic"], tm["refresh_algorithmic"]      # bytes per launch, all columns
-        B = B_E + B_T / 10.0
-        mix_bound = bool(c.species) and prof["add_to_mixed_opac"] > 5.0 * flux_ms
-        if nflux and not mix_bound:
-            achieved = B_E / (flux_ms * 1e-3) / 1e9
-            traffic = counters.get("rt_flux_hbm_bytes_per_launch") if counters else None
-            if traffic is not None:
-                traffic *= ncol                     # measured with one column per launch
-            roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
-                            frac=achieved / 8000.0, traffic=traffic, traffic_source=counter_source if traffic else None,
-                            algorithmic_bytes_per_launch=B_E, actual_bytes_model_per_launch=tm["step_actual"],
-                            avg_launch_ms=flux_ms, launches_timed=nflux)
-        elif mix_bound:
-            # on-the-fly mixing: the refresh's species kernel is where the time goes.  Against HBM: B_T per launch;
-            # against vector issue (what actually binds it): instructions per launch from the committed PMC run
-            mix_ms = prof["add_to_mixed_opac"]
-            achieved = B_T / (mix_ms * 1e-3) / 1e9
-            traffic = counters.get("rt_mix_hbm_bytes_per_launch") if counters else None
-            roofline = dict(bound="hbm", kernel="k_rt_mix_species", achieved=achieved, peak=8000.0, unit="GB/s",
-                            frac=achieved / 8000.0, traffic=traffic * ncol if traffic else None,
-                            traffic_source=counter_source if traffic else None,
-                            algorithmic_bytes_per_launch=B_T, avg_launch_ms=mix_ms, launches_timed=1)
-            valu = counters.get("rt_mix_valu_instructions_per_launch") if counters else None
-            if valu:
-                peak = 1024 * 2.4e9 / 4.0           # SIMDs x clock / 4 cycles per wave64 instruction
-                rate = valu * ncol / (mix_ms * 1e-3)
-                roofline["valu_issue"] = dict(achieved=rate / 1e9, peak=peak / 1e9, unit="G wavefront-instructions/s",
-                                              frac=rate / peak, instructions_per_launch=valu * ncol,
-                                              source=counter_source)
-        if roofline is not None:
-            whole = B / (dt / steps) / 1e9          # B * iterations/s over the whole step
-            roofline["whole_step"] = dict(achieved=whole, peak=8000.0, unit="GB/s", frac=whole / 8000.0,
-                                          algorithmic_bytes_per_iteration=B)
-            roofline["e_only_ms_per_iteration"] = e_only_ms
-            roofline["t_only_ms_per_refresh"] = t_only_ms
-            roofline["kernels_ms"] = {k: v for k, v in prof.items() if v}
+    if profile_steps > 0:
+        roofline = kernel_roofline(rt, c, wname, ncol, run, start + steps, profile_steps, dt / steps)
 
     # the path's only exchange: gather the emission spectra of all columns once, after the run
-    gather_ms = None
+    from helios_amd.parallel import gather_spectra
     spec = np.stack([rt.get("F_up_band", i)[-c.nbin:] for i in range(ncol)])
-    if dist is not None:
+    gather_ms = None
+    if ranks.dist is not None:
         tg = time.perf_counter()
-        mine = torch.from_numpy(spec).to(coll_device)
-        out = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(out, mine)
+        spec = gather_spectra(spec, ranks.dist, device=ranks.coll_device)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
-        spec = torch.cat(out).cpu().numpy()
 
     total_cols = ncol * world
-    value = steps / dt * c.nbin * c.nlayer * total_cols
-    line = {
-        "metric": "rad-conv iterations/sec x (lambda-bins x layers)",
-        "value": value, "unit": "bin*layer*iterations/s", "n_gpus": world, "steps": steps,
-        "warmup": warmup, "device_warmup_iterations": device_warmup, "ms_per_step": dt / steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+    out = {
+        "value": steps / dt * c.nbin * c.nlayer * total_cols, "unit": "bin*layer*iterations/s",
+        "steps": steps, "warmup": warmup, "device_warmup_iterations": device_warmup, "ms_per_step": dt / steps * 1e3,
         "config": {"workload": w["desc"], "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
                    "species": len(c.species) if c.species else 0,
                    "opacity_table_TP_grid": [c.ntemp, c.npress], "columns_per_gpu": ncol,
-                   "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 4, "loop": args.phase,
-                   "parallelism": "columns sharded, %d per GPU" % ncol},
+                   "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 3 * c.scat + 1,
+                   "loop": phase, "parallelism": "columns sharded, %d per GPU" % ncol},
         "iterations_per_s_per_column": steps / dt,
         "stream_event_ms_per_step": ev_ms / steps,
         "per_rank_ms_per_step": rank_ms,
@@ -441,32 +470,111 @@ def main():
         "spectrum_checksum": float(np.sum(spec)),
         "roofline": roofline,
     }
-    ref = os.path.join(ROOT, "profiles", "r02_c4_bench_64columns.json")
-    if world == 1 and wname == "c2" and ncol == 1 and os.path.exists(ref):
-        # the 1/2/4/8-GPU series is config 4 (the default at N > 1); its N = 1 member, for whoever forms an efficiency
-        with open(ref) as f:
-            one = json.loads(f.read().strip().splitlines()[-1])
-        line["scaling_series_n1"] = dict(workload=one["config"]["workload"], value=one["value"],
-                                         ms_per_step=one["ms_per_step"],
-                                         source="profiles/r02_c4_bench_64columns.json (python bench.py --workload c4)")
-    if world > 1:
-        # N = 1 runs another workload (config 2): what ONE GPU does on this workload, measured with the same command
-        # at --gpus 1 and committed under profiles/, so that a scaling efficiency can be formed from like numbers
-        if wname == "c4" and ncol == WORKLOADS["c4"]["columns_per_gpu"] and os.path.exists(ref):
-            with open(ref) as f:
-                one = json.loads(f.read().strip().splitlines()[-1])
-            line["scaling_note"] = ("the N = 1 default is config 2, the configuration the metric is quoted on; this line is "
-                                    "config 4 (17x the work per bin*layer*iteration): divide by single_gpu_same_workload")
-            line["single_gpu_same_workload"] = dict(value=one["value"], ms_per_step=one["ms_per_step"],
-                                                    source="profiles/r02_c4_bench_64columns.json (python bench.py "
-                                                           "--workload c4 on one MI355X)")
+    if steady_state and phase == "radiative":
+        # the metric over >= 200 iterations from iteration 0, i.e. with exactly one refresh per 10
+        # iterations -- the column back in its start state (temperatures, zeroed flux and time-step state), 200
+        # iterations in one go between barriers
+        n_it = 200
+        for i in range(ncol):
+            rt.set_temperatures(i, T_start[i] if not sweep else np.full(c.nlayer + 1, sweep_column(c, rank * ncol + i)["T_start"]))
+        rt.set_state(-1, "restart", np.array([1], np.int32))
+        ranks.barrier(ctx)
+        t0 = time.perf_counter()
+        run(0, n_it)
+        ranks.barrier(ctx)
+        dts = max(ranks.gather_scalars(time.perf_counter() - t0))
+        conv = [int(rt.get("done", i)[0]) for i in range(ncol)]
+        out["steady_state_200"] = dict(iterations=n_it, from_iteration=0, refreshes=n_it // 10,
+                                       ms_per_iteration=dts / n_it * 1e3,
+                                       value=n_it / dts * c.nbin * c.nlayer * total_cols,
+                                       unit="bin*layer*iterations/s", columns_converged_during_run=int(sum(conv)))
     rt.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="headline workload (default c2, the configuration the metric is quoted on, at every N)")
+    ap.add_argument("--columns-per-gpu", type=int, default=None)
+    ap.add_argument("--secondary", default="default",
+                    help="'default' (N = 1: c3,c5; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
+                         "the same run into the line's `secondary` block")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--allow-debug-knobs", action="store_true")
+    ap.add_argument("--phase", default="radiative", choices=["radiative", "convection"],
+                    help="which loop a step is taken from: radiation_loop (default, the headline number) or "
+                         "convection_loop (convective adjustment + sweeps + temperature step, all on the device)")
+    args = ap.parse_args()
+    knobs = env_knobs(args.allow_debug_knobs)
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    wname = args.workload or "c2"
+    w = WORKLOADS[wname]
+    heavy = bool(w.get("nspecies")) and w["nbin"] >= 5000
+    steps = args.steps if args.steps is not None else (20 if heavy else 200)
+    warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
+    ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
+    if args.secondary == "default":
+        secondary = (["c3", "c5"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
+    else:
+        secondary = [x for x in args.secondary.split(",") if x and x != "none"]
+    for x in secondary:
+        if x not in WORKLOADS:
+            raise SystemExit("unknown secondary workload %r" % x)
+
+    import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
+    dist = None
+    # test hook for single-GPU machines: HELIOS_BENCH_BACKEND=gloo runs all ranks on GPU 0 with CPU-side collectives,
+    # so that the multi-rank logic can be exercised where RCCL cannot (one GPU cannot host two RCCL ranks)
+    backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else 0
+    coll_device = "cuda" if backend == "nccl" else "cpu"
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    ranks = Ranks(dist, world, rank, coll_device)
+
+    from helios_amd.device import Context
+    seed = 20240 + 2
+    ctx = Context(device_index)
+    head = measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase=args.phase, profile_steps=args.profile_steps,
+                   steady_state=True)
+    line = {"metric": "rad-conv iterations/sec x (lambda-bins x layers)", "value": head.pop("value"),
+            "unit": head.pop("unit"), "n_gpus": world, "steps": head.pop("steps"), "warmup": head.pop("warmup"),
+            "device_warmup_iterations": head.pop("device_warmup_iterations"), "ms_per_step": head.pop("ms_per_step"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    line.update(head)
+    line["env_knobs"] = knobs
+    # the other configurations, measured live in this run on every rank (weak scaling like the headline)
+    sec = {}
+    for x in secondary:
+        wx = WORKLOADS[x]
+        hx_ = bool(wx.get("nspecies")) and wx["nbin"] >= 5000
+        r = measure(ctx, ranks, x, wx.get("columns_per_gpu", 1), 20 if hx_ else 100, 10, seed,
+                    profile_steps=args.profile_steps)
+        sec[x] = r
+    line["secondary"] = sec or None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(w, seed)
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

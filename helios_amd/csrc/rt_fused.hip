@@ -1273,6 +1273,24 @@ int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t
                         rt->planck_grid + (size_t)rt->d.plancktable_dim * rt->X, (size_t)rt->X * 8);
         return rc;
     }
+    if (n == "restart") {
+        // every column back to the state of a fresh batch: flux state of the sweeps (which persists between iterations,
+        // SURVEY.md Q9), time-step state, convergence flags.  Temperatures are the caller's (hx_rt_set_temperatures).
+        if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "restart expects one int32");
+        const size_t C = rt->C, Ln = rt->L, nc = (size_t)rt->X * rt->Y;
+        struct { void* p; size_t bytes; } z[] = {
+            {rt->Utile, C * rt->g.flux_elems_per_col * 8}, {rt->Dtile, rt->Dtile ? C * rt->g.flux_elems_per_col * 8 : 0},
+            {rt->U0, C * nc * 8}, {rt->T_store, C * (Ln + 1) * 8}, {rt->prefactor, C * (Ln + 1) * 8},
+            {rt->abort_flags, C * (Ln + 1) * 4}, {rt->done, C * 4}, {rt->iters_done, C * 4}, {rt->conv_count, C * 4},
+            {rt->F_smooth, C * Ln * 8}, {rt->F_smooth_sum, C * Ln * 8}};
+        for (auto& e : z)
+            if (e.p && e.bytes) {
+                hipError_t he = hipMemsetAsync(e.p, 0, e.bytes, rt->ctx->stream);
+                if (he != hipSuccess) return hx_fail(rt->ctx, -(int)he, "hipMemset failed");
+            }
+        rt->refreshed = false;
+        return 0;
+    }
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     const size_t L = rt->L;

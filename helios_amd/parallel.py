@@ -65,7 +65,7 @@ def gather_spectra(local, dist=None, device=None, columns=None):
     Column counts may differ between ranks (padding to the maximum, then trimming).  `columns`: the global indices of
     the local rows (default: ranks hold consecutive blocks in rank order); the result is in global column order."""
     local = np.ascontiguousarray(local, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local
     import torch
     world = dist.get_world_size()

@@ -402,6 +402,10 @@ int hx_rt_converged_layers(hx_rt* rt, int* out_counts);
  * "conv_layer","conv_unstable","marked_red" (int32[nlayer+1]),"done","iters_done".
  * `out` is a HOST buffer of `out_bytes`; returns HX_E_ARG if the name is unknown or the size wrong. */
 int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes);
+/* named write of host data into the batch: "T_lay", "c_p_lay", "delta_t_prefactor", "T_store", "done", "kappa_lay",
+ * "kappa_int", "conv_layer", "conv_unstable", "add_heat_dens", "dampara" (per column, col = -1: all), "planck_grid",
+ * "keep_down" (int32), and "restart" (int32): every column back to the state of a fresh batch -- the sweeps' flux state,
+ * the time-step state and the convergence flags zeroed; temperatures stay the caller's. */
 int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes);
 /* device pointer of a named internal array (column `col`) for use with the per-stage entry points */
 int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr);

@@ -33,6 +33,55 @@ def test_bench_single_rank_contract():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert str(cb["cores"]) in cb["thread_probe_iterations_per_s"] and cb["host_cores"] >= cb["cores"]
+    ss = line["steady_state_200"]
+    assert ss["iterations"] == 200 and ss["from_iteration"] == 0 and ss["refreshes"] == 20 and ss["value"] > 0
+    assert line["env_knobs"] == {} and line["secondary"] is None
+    assert "scaling_series_n1" not in line and "single_gpu_same_workload" not in line
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the process starts a child torch.distributed.run
+    with two ranks before touching a GPU and relays rank 0's line (here: both ranks on GPU 0 through the gloo hook); the
+    line is the N = 1 workload on every rank, with a secondary workload measured in the same run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HELIOS_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "10", "--workload", "c1",
+                        "--secondary", "c4small"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    one = subprocess.run([sys.executable, "bench.py", "--workload", "c1", "--steps", "20", "--warmup", "10",
+                          "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    one = _last_json(one.stdout)
+    assert line["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert line["config"]["workload"] == one["config"]["workload"]          # one workload for the whole series
+    assert line["config"]["columns_per_gpu"] == one["config"]["columns_per_gpu"] == 1
+    assert line["config"]["columns_total"] == 2 and line["spectra_gather_ms"] is not None
+    assert line["env_knobs"] == {"HELIOS_BENCH_BACKEND": "gloo"}
+    sec = line["secondary"]["c4small"]
+    assert sec["config"]["columns_total"] == 12 and sec["config"]["species"] == 7 and sec["ms_per_step"] > 0
+    assert len(sec["per_rank_ms_per_step"]) == 2 and sec["roofline"] is not None
+
+
+def test_rccl_gathers_the_spectra_with_one_rank():
+    """RCCL itself (backend "nccl") on the one GPU of this box: a process group of one rank, the spectra gather of
+    helios_amd/parallel.py through it on the device"""
+    code = ("import os, numpy as np, torch, torch.distributed as dist\n"
+            "from helios_amd.parallel import gather_spectra\n"
+            "torch.cuda.set_device(0)\n"
+            "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', world_size=1, rank=0,"
+            " device_id=torch.device('cuda', 0))\n"
+            "a = np.arange(12.0).reshape(3, 4)\n"
+            "out = gather_spectra(a, dist, device='cuda', columns=[2, 0, 1])\n"
+            "assert np.array_equal(out, a[[1, 2, 0]]), out\n"
+            "out = gather_spectra(a, dist, device='cuda')\n"
+            "assert np.array_equal(out, a)\n"
+            "print('backend', dist.get_backend())\n"
+            "dist.destroy_process_group()\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "backend nccl" in p.stdout
 
 
 def test_bench_two_ranks_share_the_columns():
@@ -62,17 +111,18 @@ def test_bench_species_workload_carries_roofline_and_cpu_baseline():
     assert cb["value"] > 0 and "species" in cb["sample"]
 
 
-def test_bench_multi_rank_default_is_the_sharded_sweep():
-    """N > 1 without --workload: config 4 (columns of the parameter sweep sharded over the ranks); here the reduced
-    shape, two ranks on one GPU through the gloo hook"""
+def test_bench_secondary_workload_under_a_launcher():
+    """the driver's launch (torch.distributed.run around bench.py) with the sharded sweep as the secondary workload: the
+    reduced config-4 shape, two ranks on one GPU through the gloo hook"""
     env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29519", "bench.py", "--gpus", "2", "--steps",
-                        "10", "--warmup", "10", "--workload", "c4small"], cwd=ROOT, env=env, capture_output=True,
-                       text=True, timeout=900)
+                        "10", "--warmup", "10", "--workload", "c1", "--secondary", "c4small"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = _last_json(p.stdout)
-    assert line["n_gpus"] == 2 and line["config"]["columns_total"] == 12 and line["config"]["species"] == 7
-    assert len(line["per_rank_ms_per_step"]) == 2 and 0 <= line["rank_imbalance"] < 1
+    sec = line["secondary"]["c4small"]
+    assert line["n_gpus"] == 2 and sec["config"]["columns_total"] == 12 and sec["config"]["species"] == 7
+    assert len(sec["per_rank_ms_per_step"]) == 2 and 0 <= sec["rank_imbalance"] < 1
     import bench
     assert bench.WORKLOADS["c4"]["columns_per_gpu"] * 8 == 512
