@@ -61,24 +61,34 @@ void choose_workgroup(int Y, int X, int max_threads, TileGeom& g) {
     }
 }
 
+// k_rt_flux<ROWS, K> instantiations whose code objects report vgpr_spill_count > 0 (K = 0 stands for k = 8)
+bool flux_variant_spills(int rows, int k) { return rows >= 15 || (rows == 14 && k != 16); }
+
 bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g) {
     // lanes per spectral point: the fewest padded nodes, with the kernels whose scans are written for a compile-time
     // lane count (k = 16, 32, 64) preferred -- measured at 10 000 bins: 50 layers 0.172 ms (k = 16, 12 % padding) against
     // 0.210 ms (k = 8, 4 %), 60 layers 0.194 against 0.256 ms
+    // Instantiations that keep part of their register image in scratch are not chosen while another lane count avoids
+    // it: k_rt_flux<15, *> spills 15-22 VGPRs, <16, *> 32-37, <14, K != 16> 2-3 (tools/code_object_notes.py;
+    // tests/test_abi.py reads the same notes), and scratch round trips inside the Gauss-group loop cost this kernel a
+    // quarter of its time in round 2.  Every column of up to 416 layers has a spill-free tiling
+    // (k = 64, 13 rows); beyond that only k = 64 with 14-16 rows exists.  Measured: profiles/r03_geometry_ab.txt.
     int best_k = 0, best_rows = 0, best_cost = 1 << 30;
     int force_k = 0;
     if (const char* e = getenv("HELIOS_RT_K")) force_k = atoi(e);  // tuning knob
-    for (int k = 8; k <= 64; k <<= 1) {
-        const int rows = (H + k - 1) / k;
-        if (rows > 16) continue;
-        if (force_k && k != force_k) continue;
-        const int cost = k * rows * (k >= 16 ? 100 : 125);
-        if (cost < best_cost) {
-            best_cost = cost;
-            best_k = k;
-            best_rows = rows;
+    for (int pass = 0; pass < 2 && !best_k; pass++)
+        for (int k = 8; k <= 64; k <<= 1) {
+            const int rows = (H + k - 1) / k;
+            if (rows > 16) continue;
+            if (force_k && k != force_k) continue;
+            if (pass == 0 && flux_variant_spills(rows, k)) continue;
+            const int cost = k * rows * (k >= 16 ? 100 : 125);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_k = k;
+                best_rows = rows;
+            }
         }
-    }
     if (!best_k) return false;
     g.k = best_k;
     g.ROWS = best_rows;
@@ -1362,6 +1372,16 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
     else if (n == "delta_col_lower") p = rt->dcol_l + c * L;
     else return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_device_ptr: unknown name '%s'", name);
     *out_dptr = p;
+    return 0;
+}
+
+int hx_rt_flux_geometry(int nlayer, int iso, int ny, int nbin, int ncol, int* out_lanes, int* out_rows) {
+    TileGeom g;
+    memset(&g, 0, sizeof(g));
+    if (nlayer < 1 || ny < 1 || nbin < 1 || ncol < 1 || !out_lanes || !out_rows) return HX_E_ARG;
+    if (!choose_geometry(iso ? nlayer : 2 * nlayer, ny, nbin, ncol, 0, 0, g)) return HX_E_ARG;
+    *out_lanes = g.k;
+    *out_rows = g.ROWS;
     return 0;
 }
 

@@ -409,6 +409,10 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
 int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes);
 /* device pointer of a named internal array (column `col`) for use with the per-stage entry points */
 int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr);
+/* the tiling hx_rt_create would choose for the flux kernel -- lanes per spectral point and half-layer rows per lane, i.e.
+ * the instantiation k_rt_flux<rows, lanes> -- for a batch of `ncol` columns of `nlayer` layers (`iso`: one segment per
+ * layer).  Host only, no device needed: tests hold the choice to the code objects' register notes. */
+int hx_rt_flux_geometry(int nlayer, int iso, int ny, int nbin, int ncol, int* out_lanes, int* out_rows);
 /* algorithmic / actual HBM byte counts of the last refresh and step (for the roofline report) */
 int hx_rt_traffic_model(hx_rt* rt, double* step_bytes_algorithmic, double* step_bytes_actual,
                         double* refresh_bytes_algorithmic, double* refresh_bytes_actual);

@@ -90,3 +90,37 @@ def test_reference_gpu_build_exports_every_launcher():
     raw = ctypes.CDLL(path)
     for n in g:
         assert hasattr(raw, n), n
+
+
+def _kernel_notes():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("code_object_notes", os.path.join(ROOT, "tools", "code_object_notes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return {k["name"]: k for k in mod.kernel_notes()}
+
+
+def test_no_selected_flux_kernel_keeps_registers_in_scratch():
+    """the tiling chosen for any column of 1 ... 416 layers (and any isothermal column of up to 512) is an instantiation
+    of k_rt_flux whose code object reports no spilled VGPRs and no scratch (read from the library's own notes, no GPU
+    needed); beyond 416 layers only k = 64 with 14-16 rows exists"""
+    import ctypes
+    from helios_amd import _lib
+    lib = _lib.lib()
+    notes = _kernel_notes()
+    flux = {n: k for n, k in notes.items() if "k_rt_flux<" in n}
+    assert len(flux) >= 4 * 16
+    seen = set()
+    k, r = ctypes.c_int(), ctypes.c_int()
+    for iso, top in ((0, 416), (1, 512)):
+        for L in range(1, top + 1):
+            assert lib.hx_rt_flux_geometry(L, iso, 20, 10000, 1, ctypes.byref(k), ctypes.byref(r)) == 0
+            seen.add((r.value, k.value if k.value >= 16 else 0))
+    for rows, K in sorted(seen):
+        n = [v for name, v in flux.items() if "k_rt_flux<%d, %d>" % (rows, K) in name]
+        assert len(n) == 1, (rows, K)
+        assert n[0]["vgpr_spill_count"] == 0 and n[0]["private_segment_fixed_size"] == 0, (rows, K, n[0])
+    # and the instantiations that do spill are known to the selection
+    spilling = {(int(name.split("<")[1].split(",")[0]), int(name.split(",")[1].split(">")[0]))
+                for name, v in flux.items() if v["vgpr_spill_count"] > 0}
+    assert spilling and not (spilling & seen)
