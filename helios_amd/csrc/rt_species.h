@@ -96,6 +96,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     __shared__ const double* s_tab[MIX_MAX_ABSORBERS];
     __shared__ double s_fac[MIX_MAX_ABSORBERS];
     __shared__ int s_info[MIX_MAX_ABSORBERS];  // species index << 1 | random-overlap flag
+    // the level's bilinear weights (pup - p, p - pdown, tup - t, t - tdown): wave-uniform fp64 values that the compiler
+    // otherwise carries in ten VGPRs through the species loop and, at the 128-register cap, parks in scratch around it --
+    // 16 bytes per lane and point written and read back (2.1 GB of the 2.5 GB WRITE_SIZE of round 2's launch)
+    __shared__ double s_blend[4];
     const int lane = threadIdx.x;
     ro::Lane ln;
     ro::init(sh, ln, lane, a.gauss_w, a.gauss_y);
@@ -111,6 +115,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     const long long p0 = (long long)blockIdx.x * chunk, p1 = min(npair, p0 + chunk);
     const size_t nc = (size_t)a.Y * a.X, st_p = nc, st_t = nc * a.npress;
     long long lev_cur = -1;
+    int tcase = 0;  // bit 0: two pressure nodes, bit 1: two temperature nodes (the four cases of :617-644)
     TPIndex tp = {};
     double* out_level = nullptr;
     size_t pl_dd = 0, pl_ud = 0, pl_du = 0, pl_uu = 0;  // table planes of the level's four (T, P) corners: wave-uniform
@@ -120,12 +125,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     // absorbers (a few dozen instructions each) does not wait for memory.
     const int grp = lane / ro::NY, y = lane - grp * ro::NY;
     const bool loader = grp < 3 && y < a.Y;
+    // (bin, level, column) of the run's first point by division, then counted up: no 64-bit division per point
+    long long cl = p0 < p1 ? p0 / a.X : 0;  // column * nlev + level
+    int x = (int)(p0 - cl * a.X) - 1;
+    int col = (int)(cl / nlev), lev = (int)(cl - (long long)col * nlev);
     for (long long pair = p0; pair < p1; pair++) {
-        const long long cl = pair / a.X;  // column * nlev + level
-        const int x = (int)(pair - cl * a.X);
+        if (++x == a.X) {
+            x = 0;
+            cl++;
+            if (++lev == (int)nlev) {
+                lev = 0;
+                col++;
+            }
+        }
         if (cl != lev_cur) {  // wave-uniform: a new level (or column)
             lev_cur = cl;
-            const int col = (int)(cl / nlev), lev = (int)(cl - (long long)col * nlev);
             const bool lay = lev < a.L;
             const int i = lay ? lev : lev - a.L;
             skip = a.done[col] != 0;
@@ -137,7 +151,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
             pl_du = st_p * tp.pdown + st_t * tp.tup;
             pl_uu = st_p * tp.pup + st_t * tp.tup;
             ro::sync();
-            if (lane < nabs) s_fac[lane] = fac[s_info[lane] >> 1];
+            int ls = lane;
+            asm volatile("" : "+v"(ls));  // addresses derived from the lane id are rebuilt here, once per level, instead of
+                                          // occupying a register (at the cap: a scratch slot) through the whole kernel
+            if (ls < nabs) s_fac[ls] = fac[s_info[ls] >> 1];
+            if (lane == 0) {
+                s_blend[0] = tp.pup - tp.p; s_blend[1] = tp.p - tp.pdown;
+                s_blend[2] = tp.tup - tp.t; s_blend[3] = tp.t - tp.tdown;
+            }
+            tcase = (tp.pdown != tp.pup ? 1 : 0) | (tp.tdown != tp.tup ? 2 : 0);
             ro::sync();
         }
         if (skip) continue;
@@ -149,7 +171,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
         }
         double mixv = 0.0;  // nullify_opac_scat_arrays (host_functions.py:1050-1056)
         for (int kb = 0; kb < nabs; kb += 3) {
-            const double raw_mine = blend_tp(c_dd, c_ud, c_du, c_uu, tp, true);
+            // blend_tp(..., species = true) with the level's weights re-read from LDS (same products in the same order)
+            asm volatile("" ::: "memory");  // the weights are not to be carried in registers across the mixes
+            double raw_mine = c_dd;
+            if (tcase == 3)
+                raw_mine = c_dd * s_blend[0] * s_blend[2] + c_ud * s_blend[1] * s_blend[2] + c_du * s_blend[0] * s_blend[3] +
+                           c_uu * s_blend[1] * s_blend[3];
+            else if (tcase == 1) raw_mine = c_dd * s_blend[0] + c_ud * s_blend[1];
+            else if (tcase == 2) raw_mine = c_du * s_blend[3] + c_dd * s_blend[2];
             if (loader && kb + 3 + grp < nabs) {
                 const double* tab = s_tab[kb + 3 + grp];
                 c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];

@@ -45,7 +45,8 @@ def _block_case(c, x0, nb, species_slices=None):
     b.opac_interwave = np.ascontiguousarray(c.opac_interwave[x0:x0 + nb + 1])
     for k in ("opac_wave", "opac_deltawave", "surf_albedo", "starflux"):
         b[k] = np.ascontiguousarray(np.asarray(c[k])[x0:x0 + nb])
-    b.opac_k = _slice_table(c.opac_k, c, x0, nb)
+    if not c.get("species"):       # with species the premixed table is never read (bench.build_case keeps a stub)
+        b.opac_k = _slice_table(c.opac_k, c, x0, nb)
     b.opac_scat_cross = np.ascontiguousarray(
         np.asarray(c.opac_scat_cross).reshape(c.ntemp, c.npress, c.nbin)[:, :, x0:x0 + nb]).reshape(-1)
     for nm, n in (("lay", c.nlayer), ("int", c.nlayer + 1)):
@@ -221,6 +222,83 @@ def test_config4_batch_of_sweep_columns_equals_single_runs(ctx):
             np.testing.assert_allclose(batch[i][k], single[k], rtol=1e-12, atol=0, err_msg="column %d: %s" % (gi, k))
 
 
+def test_config4_sixteen_full_size_columns_in_one_batch_vs_oracle(ctx, port):
+    """config 4 at its size: 16 columns of the 8 x 8 x 8 sweep (different gravity, orbital distance, internal flux and
+    start profile), 10 000 bins x 100 layers each, 20 species mixed on the fly, in ONE batch -- the first refresh and
+    flux solve of three of the columns (first, one from the middle, last) against the CPU oracle on sampled bins
+    (mixed opacities of every Gauss point and level, scattering, spectral and band fluxes)"""
+    import bench
+    from helios_amd.rt import batch_from_case
+    c = bench.build_case(bench.WORKLOADS["c4"], 20242)
+    picks = [0, 7, 63, 64, 100, 137, 200, 255, 256, 321, 383, 384, 448, 470, 504, 511]
+    xs, nb = _blocks(c.nbin)
+    cols = [bench.sweep_column(c, gi) for gi in picks]
+    rt = batch_from_case(ctx, c, ncol=len(cols), nspecies=len(c.species), columns=cols)
+    try:
+        slices = _upload_species(rt, c, xs, nb)
+        for i, cp in enumerate(cols):
+            rt.set_column_profile(i, c.p_lay, c.p_int, np.full(c.nlayer + 1, cp["T_start"]) * (1.0 + 0.002 * i),
+                                  c.surf_albedo, c.starflux)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        grid = rt.get("planck_grid")
+        checked = [0, 9, 15]
+        got = {i: {k: rt.get(k, i) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int",
+                                             "F_up_band", "F_down_band", "F_up_wg")} for i in checked}
+        spectra = [rt.get("F_up_band", i)[-c.nbin:] for i in range(len(cols))]
+    finally:
+        rt.close()
+    for i in checked:
+        cp = cols[i]
+        ci = cases.Case(c)
+        ci.g, ci.a, ci.F_intern = cp["g"], cp["a"], cp["F_intern"]
+        ci.T_lay = np.full(c.nlayer + 1, cp["T_start"]) * (1.0 + 0.002 * i)
+        for x0 in xs[:2] + xs[-1:]:
+            b = _block_case(ci, x0, nb, slices)
+            s = _oracle_block(port, b, grid, ci, x0, nb, cases.refresh_onthefly)
+            _compare_block(got[i], s, ci, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg"),
+                           ("scat_cross_lay", "scat_cross_int", "F_up_band", "F_down_band"))
+    for i in range(1, len(cols)):                     # sixteen different columns, none a copy of its neighbour
+        assert np.abs(spectra[i] / spectra[i - 1] - 1.0).max() > 1e-6
+
+
+def test_config5_on_the_fly_full_size_sampled_bins_vs_oracle(ctx, port):
+    """BASELINE config 5 as named: 30 000 bins x 200 layers, 20 species mixed on the fly (random overlap), two cloud
+    decks, g0 = 0.3 with the I2S correction, direct beam, surface albedo -- the first refresh and flux solve against the
+    CPU oracle on sampled bins: mixed opacities of every Gauss point and level, scattering, total g0, spectral and band
+    fluxes incl. the direct beam.  (The convection loop on this shape runs in the premixed test below.)"""
+    import bench
+    from helios_amd.rt import batch_from_case
+    c = bench.build_case(bench.WORKLOADS["c5"], 20245)
+    assert c.nbin == 30000 and c.nlayer == 200 and c.dir_beam == 1 and c.clouds == 1 and c.scat_corr == 1
+    c.T_lay = 700.0 + 900.0 * (np.log10(np.append(c.p_lay, c.p_lay[0])) + 1.0) / 10.0
+    xs, nb = _blocks(c.nbin)
+    rt = batch_from_case(ctx, c, ncol=1, nspecies=len(c.species))
+    try:
+        slices = _upload_species(rt, c, xs, nb)
+        rt.keep_down_fluxes(True)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        got = {k: rt.get(k) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int", "F_up_band",
+                                      "F_down_band", "F_dir_band", "F_up_wg", "F_down_wg", "g_0_tot_lay", "g_0_tot_int")}
+        grid = rt.get("planck_grid")
+        dg = ctx.diag()
+    finally:
+        rt.close()
+    for x0 in xs:
+        b = _block_case(c, x0, nb, slices)
+        s = _oracle_block(port, b, grid, c, x0, nb, cases.refresh_onthefly)
+        _compare_block(got, s, c, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg", "F_down_wg"),
+                       ("scat_cross_lay", "scat_cross_int", "g_0_tot_lay", "g_0_tot_int", "F_up_band", "F_down_band",
+                        "F_dir_band"))
+    Y, X, L = c.ny, c.nbin, c.nlayer
+    for k, nlev in (("opac_wg_lay", L), ("opac_wg_int", L + 1)):
+        a = got[k][:nlev * X * Y].reshape(nlev, X, Y)
+        assert np.all(np.isfinite(a)) and a.min() > 0 and np.all(np.diff(a, axis=2) >= 0)
+    assert got["F_up_band"].min() >= 0 and got["F_dir_band"].min() >= 0 and got["F_dir_band"].max() > 0
+    assert dg["ro_rebin_skipped"] == 0
+
+
 def test_config5_full_size_clouds_beam_i2s_albedo_and_convection(ctx, port):
     """30 000 bins x 200 layers, two cloud decks, g0, I2S correction, surface albedo, direct beam: the first refresh and
     flux solve of 64 bins against the oracle; then the convection loop (adjustment + sweeps + temperature step on the
@@ -228,7 +306,7 @@ def test_config5_full_size_clouds_beam_i2s_albedo_and_convection(ctx, port):
     import bench
     from helios_amd import phys_const as pc
     from helios_amd.rt import batch_from_case
-    c = bench.build_case(bench.WORKLOADS["c5"], 20245)
+    c = bench.build_case(bench.WORKLOADS["c5premixed"], 20245)
     c.dir_beam = 1
     c.T_lay = 700.0 + 900.0 * (np.log10(np.append(c.p_lay, c.p_lay[0])) + 1.0) / 10.0
     xs, nb = _blocks(c.nbin)
@@ -336,7 +414,7 @@ def test_config5_full_size_all_bins_vs_the_reference_on_the_gpu(ctx):
     """30 000 bins x 200 layers, two cloud decks, g0, I2S correction, surface albedo and the direct beam: the same
     comparison with the reference's kernels on this GPU, every bin"""
     import bench
-    c0 = bench.build_case(bench.WORKLOADS["c5"], 20245)
+    c0 = bench.build_case(bench.WORKLOADS["c5premixed"], 20245)
     c0.dir_beam = 1
     c0.T_lay = 700.0 + 900.0 * (np.log10(np.append(c0.p_lay, c0.p_lay[0])) + 1.0) / 10.0
     _premixed_column_vs_reference(ctx, c0)
