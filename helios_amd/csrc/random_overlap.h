@@ -37,6 +37,12 @@ constexpr int NY = 20;
 constexpr int N = NY * NY;   // 400 pair sums
 constexpr int SLOTS = 8;     // per lane: 512 slots
 constexpr int LDS_N = 512;   // by fill position (<= 511) or by padded rank (399 + 49)
+// LDS images of the run layout: the sum of cell (i, j) of a tableau without a crossing lives at index 21 i + j -- a row
+// pitch of 21 instead of the reference's 20 spreads the sixteen lanes of a store over all banks (with pitch 20 they hit
+// four bank pairs: same-box A/B +7 % on the whole mixing kernel).  21 i + j ascends with the fill position 20 i + j, so it
+// serves as the tie-break of equal quantised sums just as well.  Index PAD holds (inf, 0) for every padding slot.
+constexpr int ROW_PITCH = 21;
+constexpr int PAD = 511;
 
 struct Shared {
     double outer[NY], inner[NY], hw[NY], gy[NY];  // outer: the curve that is stronger at y = 0 (outer fill loop)
@@ -44,13 +50,35 @@ struct Shared {
 };
 
 struct Lane {
-    unsigned c[6];         // c[t] = 0 where lane bit t is clear (lower partner of an exchange over that bit), else ~0
-    unsigned pk20[SLOTS];  // fill position e = 64 r + lane as LDS byte offsets 8 (e / 20) | 8 (e % 20) << 16
+    unsigned c[3];         // c[t] = 0 where lane bit t is clear (lower partner of an exchange over that bit), else ~0;
+                           // bits 3-5 (6 of the 35 exchanges) are extracted where they are used: three registers fewer
+    // Tableau coordinates of the network position p = 8 lane + s (the "run layout", see run_cell): byte offsets
+    // 8 i | 8 j << 8 of outer[i], inner[j], the padded fill position 21 i + j of the no-crossing order << 16 (pads: PAD),
+    // bit 31 set for a pad
+    unsigned cell[SLOTS];
 };
 
 struct Counters {
     unsigned skipped = 0, passes = 0;
 };
+
+// The run layout.  K[i][j] = outer[i] + inner[j] of two ascending curves ascends along every row and every column, so
+// the 400 sums can be dealt out to the network as 28 runs of 16 positions that are ALREADY ascending -- and then the first
+// ten steps of the 45-step bitonic network (which only sort inside blocks of 16) have nothing to do:
+//     runs  0-19: row i = run, columns 0-15            runs 20-23: column 16 + (run - 20), rows 0-15
+//     runs 24-27: row 16 + (run - 24), columns 16-19, then 12 pads      runs 28-31: pads
+// (400 sums cannot be cut into fewer than 20 ascending chains -- the anti-diagonal is an antichain -- so runs of 32 are
+// out of reach.)  Keys inside a run ascend too: equal quantised sums are ordered by fill position, and both fill orders
+// of the reference (:3332-3365) ascend along rows and along columns.  Position p = 8 lane + s: run = lane / 2.
+__device__ __forceinline__ unsigned run_cell(int lane, int s) {
+    const int run = lane >> 1, idx = 8 * (lane & 1) + s;
+    int i = -1, j = -1;
+    if (run < 20) { i = run; j = idx; }
+    else if (run < 24) { i = idx; j = 16 + (run - 20); }
+    else if (run < 28 && idx < 4) { i = 16 + (run - 24); j = 16 + idx; }
+    if (i < 0) return 0x80000000u | (unsigned)PAD << 16;  // pads share one LDS cell holding (inf, 0)
+    return (unsigned)(8 * i) | (unsigned)(8 * j) << 8 | (unsigned)(ROW_PITCH * i + j) << 16;
+}
 
 __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const double* gauss_weight, const double* gauss_y) {
     if (lane < NY) {
@@ -58,11 +86,12 @@ __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const doubl
         sh.gy[lane] = gauss_y[lane];
     }
 #pragma unroll
-    for (int t = 0; t < 6; t++) ln.c[t] = (lane >> t) & 1 ? 0xFFFFFFFFu : 0u;
+    for (int t = 0; t < 3; t++) ln.c[t] = (lane >> t) & 1 ? 0xFFFFFFFFu : 0u;
 #pragma unroll
-    for (int r = 0; r < SLOTS; r++) {
-        const unsigned e = 64 * r + lane, q = e / 20;
-        ln.pk20[r] = 8 * q | (8 * (e - 20 * q)) << 16;
+    for (int r = 0; r < SLOTS; r++) ln.cell[r] = run_cell(lane, r);
+    if (lane == 0) {
+        sh.A[PAD] = __builtin_inf();
+        sh.B[PAD] = 0.0;
     }
 }
 
@@ -131,11 +160,14 @@ __device__ __forceinline__ void cross_step(Keys& v, int lane, const Lane& ln) {
     constexpr int TOP = MIRROR ? (M + 1) / 2 : M;
     constexpr int T = TOP == 1 ? 0 : TOP == 2 ? 1 : TOP == 4 ? 2 : TOP == 8 ? 3 : TOP == 16 ? 4 : 5;
     const int addr = (lane ^ M) << 2;
+    unsigned c;
+    if constexpr (T < 3) c = ln.c[T];
+    else c = (unsigned)__builtin_amdgcn_sbfe(lane, T, 1);  // v_bfe_i32: 0 or ~0
     Keys n;
 #pragma unroll
     for (int s = 0; s < SLOTS; s++) {
         const int ps = MIRROR ? SLOTS - 1 - s : s;
-        n.k[s] = med3(v.k[s], xor_lane<M>(addr, v.k[ps]), ln.c[T]);
+        n.k[s] = med3(v.k[s], xor_lane<M>(addr, v.k[ps]), c);
     }
     v = n;
 }
@@ -147,6 +179,22 @@ __device__ __forceinline__ void sort512(Keys& v, int lane, const Lane& ln) {
     lane_mirror<8>(v); lane_step<2>(v); lane_step<1>(v);
 #define RO_LANE_TAIL lane_step<4>(v); lane_step<2>(v); lane_step<1>(v);
     cross_step<1, true>(v, lane, ln); RO_LANE_TAIL
+    cross_step<3, true>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
+    cross_step<7, true>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
+    RO_LANE_TAIL
+    cross_step<15, true>(v, lane, ln); cross_step<4, false>(v, lane, ln); cross_step<2, false>(v, lane, ln);
+    cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
+    cross_step<31, true>(v, lane, ln); cross_step<8, false>(v, lane, ln); cross_step<4, false>(v, lane, ln);
+    cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
+    cross_step<63, true>(v, lane, ln); cross_step<16, false>(v, lane, ln); cross_step<8, false>(v, lane, ln);
+    cross_step<4, false>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
+    RO_LANE_TAIL
+#undef RO_LANE_TAIL
+}
+
+// the same network entered behind its tenth step: every block of 16 positions (two lanes) is already ascending
+__device__ __forceinline__ void sort512_from_runs16(Keys& v, int lane, const Lane& ln) {
+#define RO_LANE_TAIL lane_step<4>(v); lane_step<2>(v); lane_step<1>(v);
     cross_step<3, true>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
     cross_step<7, true>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
     RO_LANE_TAIL
@@ -201,6 +249,8 @@ __device__ __forceinline__ void sync() {
 // point and receive the mixed value (kernels.cu:3293-3396, ro_method == 1, s > 0, ny == 20).  All 64 lanes must call.
 template <bool MONOTONE, bool CROSSING>
 __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys& v, int yx, int hmin, int sh_bits) {
+    asm volatile("" : "+v"(lane));  // rare path (a curve that is not ascending): its per-slot addresses are derived here,
+                                    // not kept in fourteen registers through the whole kernel
     const int nfirst = NY * yx;
     const int inv_yx = (1048576 + yx - 1) / yx;
     const char* outer = (const char*)sh.outer;
@@ -212,7 +262,7 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
         double K = __builtin_inf(), g = 0.0;
         unsigned key = 0xFFFFFE00u | (unsigned)e;
         if (r < 6 || (r == 6 && lane < N - 6 * 64)) {  // e < 400: every lane for r < 6, 16 lanes for r = 6, none for r = 7
-            int aq = ln.pk20[r] & 0xFFFF, ar = ln.pk20[r] >> 16;  // byte offsets of outer[e / 20], inner[e % 20]
+            int aq = 8 * (e / 20), ar = 8 * (e % 20);  // byte offsets of outer[e / 20], inner[e % 20]
             if (CROSSING) {  // the curves cross: two fill regions (:3332-3365)
                 const bool first = e < nfirst;
                 // e / yx and e / 20 for e < 512 as multiply-shift (exact: e * d < 2^20 / d for d <= 20)
@@ -237,6 +287,40 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
     }
 }
 
+// fill for two ascending curves: the sums in the run layout (no index arithmetic: the cell of a slot is fixed), their fill
+// positions e of the reference's order -- e0 without a crossing, j < yx ? j + yx i : i + 20 j with one (:3332-3365 with the
+// stronger curve on the outer loop) -- as the low key bits and as the address of the LDS images.  HI: sh_bits >= 32.
+template <bool CROSSING, bool HI>
+__device__ __forceinline__ void fill_runs(Shared& sh, const Lane& ln, Keys& v, int yx, int hmin, int sh_bits) {
+    const char* outer = (const char*)sh.outer;
+    const char* inner = (const char*)sh.inner;
+    const char* hw = (const char*)sh.hw;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        unsigned cell = ln.cell[r];
+        asm volatile("" : "+v"(cell));  // unpack here, per problem: hoisted out of the problem loop the four fields of the
+                                        // eight cells would occupy 32 registers instead of 8
+        const int ai = cell & 0xFF, aj = (cell >> 8) & 0xFF;
+        int e = (cell >> 16) & 0x1FF;   // index of the LDS images and tie-break of the key
+        const double K = *(const double*)(outer + ai) + *(const double*)(inner + aj);
+        const double g = *(const double*)(hw + ai) * *(const double*)(hw + aj);
+        if (CROSSING) {
+            const int i8 = ai, j8 = aj;  // 8 i, 8 j
+            const int e1 = (j8 + __umul24(yx, i8)) >> 3, e2 = (i8 + 20 * j8) >> 3;
+            e = (int)cell < 0 ? e : (j8 < 8 * yx ? e1 : e2);
+        }
+        const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
+        const unsigned q23 = HI ? dh >> (sh_bits - 32) : __builtin_amdgcn_alignbit(dh, (unsigned)__double2loint(K), sh_bits);
+        v.k[r] = (int)cell < 0 ? 0xFFFFFFFFu : q23 << 9 | (unsigned)e;
+        if ((int)cell >= 0) {
+            sh.A[e] = K;
+            sh.B[e] = g;
+        }
+        // two groups of four slots: all eight sets of operands in flight at once cost 64 registers at the kernel's peak
+        if (r == SLOTS / 2 - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, double my_mix, double my_add, Counters& cnt) {
     // corners of the tableau, wave-uniform
     const double m0 = __shfl(my_mix, 0), a0 = __shfl(my_add, 0), m19 = __shfl(my_mix, NY - 1), a19 = __shfl(my_add, NY - 1);
@@ -250,16 +334,21 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     }
     sync();
     // last crossing of the two curves (:3321-3329); are both k-distributions (ascending)?
-    bool cross = false, down = false;
+    // ... and do the rows of the tableau overlap?  If row i ends below the start of row i + 1 for every i, the sums are
+    // ascending in fill order (without a crossing: e = 20 i + j) and nothing has to be sorted
+    bool cross = false, down = false, over = false;
     if (lane >= 1 && lane < NY) {
         const double po = sh.outer[lane - 1], pi = sh.inner[lane - 1];
         const double pm = mix_first ? po : pi, pa = mix_first ? pi : po;
         cross = (my_mix > my_add) != (pm > pa);
         down = my_mix < pm || my_add < pa;
+        const double mo = mix_first ? my_mix : my_add;  // outer[lane]
+        over = po + (mix_first ? a19 : m19) > mo + (mix_first ? a0 : m0);
     }
     const unsigned long long cmask = __ballot(cross);
     const int yx = cmask ? 63 - __clzll((long long)cmask) : NY;
     const bool monotone = __ballot(down) == 0;
+    const bool rows_apart = __ballot(over) == 0;
     double kmin = m0 + a0, kmax = m19 + a19;
     if (!monotone) {  // the extreme sums are not at the corners of the tableau
         double mn1 = sh.outer[0], mx1 = mn1, mn2 = sh.inner[0], mx2 = mn2;
@@ -279,29 +368,33 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     const int bl = dmax ? 64 - __clzll((long long)dmax) : 0;
     const int sh_bits = bl > 23 ? bl - 23 : 0;
     Keys v;
-    if (yx == NY) {
-        if (monotone) fill<true, false>(sh, ln, lane, v, yx, hmin, sh_bits);
-        else fill<false, false>(sh, ln, lane, v, yx, hmin, sh_bits);
-    } else {
-        if (monotone) fill<true, true>(sh, ln, lane, v, yx, hmin, sh_bits);
+    bool presorted = false;
+    if (monotone) {
+        if (yx == NY) {
+            if (sh_bits >= 32) fill_runs<false, true>(sh, ln, v, yx, hmin, sh_bits);
+            else fill_runs<false, false>(sh, ln, v, yx, hmin, sh_bits);
+            presorted = rows_apart;
+        } else {
+            if (sh_bits >= 32) fill_runs<true, true>(sh, ln, v, yx, hmin, sh_bits);
+            else fill_runs<true, false>(sh, ln, v, yx, hmin, sh_bits);
+        }
+        if (!presorted) {
+            int lv = lane;
+            asm volatile("" : "+v"(lv));  // what the network derives from the lane id (exchange addresses, bits 3-5) is
+                                          // rebuilt per problem and does not sit in registers between the problems
+            sort512_from_runs16(v, lv, ln);
+        }
+    } else {  // a curve that is not a k-distribution: positions in fill order, the whole network
+        if (yx == NY) fill<false, false>(sh, ln, lane, v, yx, hmin, sh_bits);
         else fill<false, true>(sh, ln, lane, v, yx, hmin, sh_bits);
+        sort512(v, lane, ln);
     }
     sync();
-    // already ascending in fill order?
-    bool unsorted = false;
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
-        const int e = 64 * r + lane;
-        if (r < 6 || lane < N - 1 - 6 * 64) unsorted = unsorted || sh.A[e] > sh.A[e + 1];
-    }
     int src[SLOTS];  // byte offset of the fill position of the element at rank 8 lane + r
-    if (__ballot(unsorted) == 0) {
 #pragma unroll
-        for (int r = 0; r < SLOTS; r++) src[r] = 8 * (SLOTS * lane + r);
-    } else {
-        sort512(v, lane, ln);
-#pragma unroll
-        for (int r = 0; r < SLOTS; r++) src[r] = (v.k[r] & 511) << 3;
+    for (int r = 0; r < SLOTS; r++) {
+        const int w = SLOTS * lane + r;  // rank; presorted: the sum at fill position w, LDS index w + w / 20
+        src[r] = presorted ? (w < N ? 8 * (w + (int)(__umul24(w, 52429) >> 20)) : 8 * PAD) : (int)(v.k[r] & 511) << 3;
     }
     double K[SLOTS], g[SLOTS];
 #pragma unroll
