@@ -45,7 +45,10 @@ constexpr int ROW_PITCH = 21;
 constexpr int PAD = 511;
 
 struct Shared {
-    double outer[NY], inner[NY], hw[NY], gy[NY];  // outer: the curve that is stronger at y = 0 (outer fill loop)
+    // outer: the curve that is stronger at y = 0 (outer fill loop).  Entry NY of outer / inner / hw is a constant
+    // (inf, 0, 0): what the padding slots of the run layout read, so that their sum is inf and their weight 0 without a
+    // branch or a select
+    double outer[NY + 1], inner[NY + 1], hw[NY + 1], gy[NY];
     double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded rank: sorted sum / abscissa
 };
 
@@ -76,7 +79,7 @@ __device__ __forceinline__ unsigned run_cell(int lane, int s) {
     if (run < 20) { i = run; j = idx; }
     else if (run < 24) { i = idx; j = 16 + (run - 20); }
     else if (run < 28 && idx < 4) { i = 16 + (run - 24); j = 16 + idx; }
-    if (i < 0) return 0x80000000u | (unsigned)PAD << 16;  // pads share one LDS cell holding (inf, 0)
+    if (i < 0) return 0x80000000u | (unsigned)PAD << 16 | (unsigned)(8 * NY) << 8 | (unsigned)(8 * NY);  // pads: the constant entries
     return (unsigned)(8 * i) | (unsigned)(8 * j) << 8 | (unsigned)(ROW_PITCH * i + j) << 16;
 }
 
@@ -90,8 +93,8 @@ __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const doubl
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) ln.cell[r] = run_cell(lane, r);
     if (lane == 0) {
-        sh.A[PAD] = __builtin_inf();
-        sh.B[PAD] = 0.0;
+        sh.A[PAD] = sh.outer[NY] = __builtin_inf();
+        sh.B[PAD] = sh.inner[NY] = sh.hw[NY] = 0.0;
     }
 }
 
@@ -311,13 +314,9 @@ __device__ __forceinline__ void fill_runs(Shared& sh, const Lane& ln, Keys& v, i
         }
         const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
         const unsigned q23 = HI ? dh >> (sh_bits - 32) : __builtin_amdgcn_alignbit(dh, (unsigned)__double2loint(K), sh_bits);
-        v.k[r] = (int)cell < 0 ? 0xFFFFFFFFu : q23 << 9 | (unsigned)e;
-        if ((int)cell >= 0) {
-            sh.A[e] = K;
-            sh.B[e] = g;
-        }
-        // two groups of four slots: all eight sets of operands in flight at once cost 64 registers at the kernel's peak
-        if (r == SLOTS / 2 - 1) __builtin_amdgcn_sched_barrier(0);
+        v.k[r] = (q23 << 9 | (unsigned)e) | (unsigned)((int)cell >> 31);  // pads: all ones
+        sh.A[e] = K;   // pads: (inf, 0) into their common cell
+        sh.B[e] = g;
     }
 }
 
