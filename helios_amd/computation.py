@@ -550,7 +550,7 @@ class Compute(object):
             if (it - 1) % 100 == 0:
                 T_surf = rt.get("T_lay")[L]                      # computation.py:946-952
                 condition2 = T_surf < quant.plancktable_dim * quant.plancktable_step - 2
-                if not condition2:
+                if not condition2 and quant.iso == 0:            # (isothermal layers cannot be adjusted: see convection_loop)
                     quant.convection = 1
             self._coupling_output(quant, it, write, read)
             if it in quant.crit_relaxation_numbers:
@@ -650,7 +650,7 @@ class Compute(object):
                 if quant.iter_value % 100 == 0:
                     quant.T_lay = quant.dev_T_lay.get()
                     condition2 = quant.T_lay[L] < quant.plancktable_dim * quant.plancktable_step - 2
-                    if not condition2:
+                    if not condition2 and quant.iso == 0:
                         quant.convection = 1
                 quant.iter_value = np.int32(quant.iter_value + 1)
                 self._coupling_output(quant, int(quant.iter_value), write, read)

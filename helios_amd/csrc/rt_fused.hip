@@ -659,7 +659,9 @@ static int upload_species_table(hx_rt* rt) {
     for (int s = 0; s < S; s++) {
         const Species& sp = rt->species[s];
         sd[s] = SpeciesDev{sp.pretab, sp.scat_cross, sp.weight, sp.absorbing ? 1 : 0, sp.scattering ? 1 : 0,
-                           sp.is_h2o ? 1 : 0, (rt->f.kcoeff_mixing_ro && !sp.is_cia) ? 1 : 0,  // computation.py:1343
+                           // random overlap unless CIA (computation.py:1343) or one Gauss point per bin (opacity sampling:
+                           // condition_for_correlated_k includes ny == 1, kernels.cu:3302)
+                           sp.is_h2o ? 1 : 0, (rt->f.kcoeff_mixing_ro && !sp.is_cia && rt->Y != 1) ? 1 : 0,
                            sp.in_mu, 0};
         if (sp.absorbing) abs.push_back(s);
     }
@@ -719,7 +721,8 @@ int hx_rt_refresh(hx_rt* rt) {
     if (rt->d.nspecies > 0) {  // computation.py:1343: random overlap is written for 20 Gauss points
         bool any_ro = false;
         for (const Species& sp : rt->species) any_ro = any_ro || (sp.absorbing && rt->f.kcoeff_mixing_ro && !sp.is_cia);
-        if (Y != ro::NY && any_ro) return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 (got %d)", Y);
+        if (Y != ro::NY && Y != 1 && any_ro)  // ny == 1 mixes correlated-k in the reference too (kernels.cu:3302)
+            return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 or 1 (got %d)", Y);
         HX_REQUIRE(ctx, Y <= ro::NY, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 20 Gauss points");
         int nabs = 0;
         for (const Species& sp : rt->species) nabs += sp.absorbing ? 1 : 0;

@@ -328,6 +328,12 @@ class Read(object):
             quant.no_atmo_mode = i32(1)
             quant.p_toa, quant.p_boa = 1e-3, 2e-3
             quant.scat, quant.convection, quant.nlayer = i32(0), i32(0), i32(2)
+        if quant.iso == 1 and quant.convection == 1 and quant.singlewalk == 0:
+            # the reference skips the stability test with isothermal layers and then sums a conv_unstable that was never
+            # built (computation.py:1004-1009, quantities.py:134: `sum(None)` raises TypeError after the whole radiative
+            # loop has run): say what is wrong before any GPU work instead
+            raise IOError("ERROR: convective adjustment needs non-isothermal layers (the reference cannot run this "
+                          "combination either); set 'isothermal layers = no' or 'convective adjustment = no'")
         quant.ninterface = i32(quant.nlayer + 1)
         print("\n### Welcome! This run has the name: " + str(quant.name) + ". ###")
 

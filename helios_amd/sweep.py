@@ -85,7 +85,8 @@ def _prepare_column(base_argv, overrides, shared):
 
 def _batch_signature(q):
     return (int(q.nbin), int(q.ny), int(q.nlayer), int(q.scat), int(q.dir_beam), int(q.clouds), int(q.scat_corr),
-            int(q.smooth), int(q.convection), str(q.opacity_mixing), float(q.g_0), float(q.epsi), str(q.planet_type))
+            int(q.smooth), int(q.convection), str(q.opacity_mixing), float(q.g_0), float(q.epsi), str(q.planet_type),
+            int(q.iso), int(q.singlewalk))
 
 
 def _radiation_loop(computer, quants, rt):
@@ -96,6 +97,17 @@ def _radiation_loop(computer, quants, rt):
     done = np.zeros(ncol, bool)
     iters = np.zeros(ncol, np.int64)
     fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in q0.species_list)
+    if q0.singlewalk == 1:
+        # post-processing run type (computation.py:983-984, Compute.radiation_loop): ONE pass over the given T-P profiles --
+        # refresh, 1000*scat+1 sweeps inside one launch of the flux kernel, quadrature -- and no temperature step
+        if q0.opacity_mixing == "on-the-fly":
+            for q in quants:
+                computer._push_vmr(q)
+        rt.step(0, step_temperature=False)
+        computer.report_diagnostics(q0)
+        for q in quants:
+            q.iter_value = np.int32(0)
+        return iters
     it = 0
     while not done.all():
         if q0.opacity_mixing == "on-the-fly" and it % 10 == 0 and (it == 0 or fastchem):
@@ -117,7 +129,8 @@ def _radiation_loop(computer, quants, rt):
             for c in np.nonzero(~done)[0]:
                 q = quants[c]
                 if not rt.get("T_lay", c)[int(q.nlayer)] < q.plancktable_dim * q.plancktable_step - 2:
-                    q.convection = 1
+                    if q.iso == 0:
+                        q.convection = 1
                     done[c] = True
                     iters[c] = it
                     rt.set_state(int(c), "done", np.ones(1, np.int32))
@@ -248,6 +261,9 @@ def _finish_column(computer, q, reader, writer):
         setattr(q, name, None)
 
 
+_SWEEP_SEQUENCE = 0      # number of run_sweep calls with a shared work list in this process
+
+
 def _run_columns(base_argv, overrides_list, cols, computer, writer, shared, columns, timing, write_output):
     """prepare the columns `cols`, run them as device batches (one per batch signature) to the end of both loops, write
     their files and append them to `columns`"""
@@ -263,7 +279,8 @@ def _run_columns(base_argv, overrides_list, cols, computer, writer, shared, colu
     groups = {}
     for q, reader in fresh:
         if not computer._fused_supported(q):
-            raise IOError("sweeps run on the fused path: iterative run type, non-isothermal layers, flux iteration method")
+            raise IOError("sweeps run on the fused device path: flux calculation method 'iteration', at most 512 layers "
+                          "(1024 isothermal ones); run this configuration column by column with helios.py")
         groups.setdefault(_batch_signature(q), []).append((q, reader))
     for members in groups.values():
         quants = [q for q, _ in members]
@@ -313,7 +330,12 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
     if mode.startswith("dynamic"):
         from .parallel import WorkList
         chunk = int(mode.split(":")[1]) if ":" in mode else max(1, len(overrides_list) // (8 * world))
-        work = WorkList(len(overrides_list), chunk, dist)
+        # one counter per sweep: every rank calls run_sweep the same number of times, and a restarted worker group
+        # (torchrun --max-restarts) may find the previous attempt's keys still in the agent's store
+        global _SWEEP_SEQUENCE
+        _SWEEP_SEQUENCE += 1
+        key = "%s/restart%s/sweep%d" % (WorkList.KEY, os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _SWEEP_SEQUENCE)
+        work = WorkList(len(overrides_list), chunk, dist, key=key)
         claims = iter(work.claim, [])
         mine_cols = work.claimed
     else:
@@ -341,6 +363,9 @@ def run_sweep(base_argv, overrides_list, dist=None, coll_device="cpu", write_out
     X = int(columns[0][0].nbin) if columns else 0
     local = np.array([np.asarray(q.F_up_band)[-X:] for q, _ in columns]).reshape(len(columns), X)
     spectra = gather_spectra(local, dist, coll_device, columns=mine_cols)
+    if spectra.shape[0] != len(overrides_list):
+        raise RuntimeError("sweep: %d columns were run, %d were asked for (partition '%s')"
+                           % (spectra.shape[0], len(overrides_list), mode))
     return [q for q, _ in columns], spectra
 
 

@@ -17,13 +17,19 @@ def ctx():
     return Context(0)
 
 
-@pytest.mark.parametrize("cfg", [dict(nbin=9, nlayer=8), dict(nbin=14, nlayer=21, dir_beam=1, albedo=0.1)])
+@pytest.mark.parametrize("cfg", [dict(nbin=9, nlayer=8), dict(nbin=14, nlayer=21, dir_beam=1, albedo=0.1),
+                                 dict(nbin=11, nlayer=8, ny=1)])
 def test_fused_onthefly_vs_oracle(ctx, port, cfg):
+    """the species loop of the fused refresh against the oracle's; ny = 1 (opacity sampling) with `kcoeff_mixing = RO`:
+    the reference mixes correlated-k then (condition_for_correlated_k includes ny == 1, kernels.cu:3302), and so does
+    the fused path instead of refusing the table"""
     c0 = cases.add_species(cases.make_case(**cfg), nspecies=4)
     for n_iter, rtol in ((1, 1e-9), (11, 1e-7)):
         f, grid = fh.run_fused(ctx, c0, n_iter, with_planck_grid=True)
         o = fh.run_oracle(port, c0, n_iter, planck_grid=grid, refresh=cases.refresh_onthefly)
         fh.compare(f, o, c0, rtol=rtol)
+    if c0.ny == 1:
+        return
     # the mix really went through random overlap: differs from the correlated-k mix
     o_ck = fh.run_oracle(port, c0, 1, planck_grid=grid,
                          refresh=lambda i, c, s: cases.refresh_onthefly(i, c, s, ro=0))
@@ -424,6 +430,29 @@ def test_sweep_batch_equals_individual_runs(tmp_path):
             b = open(os.path.join(out, "single", "s%d" % k, "s%d_tp.dat" % k)).read()
             assert a == b
             k += 1
+
+
+def test_sweep_of_post_processing_runs_is_one_pass_per_column(tmp_path):
+    """`-run_type post-processing` in a sweep (singlewalk = 1, isothermal layers): the batch takes ONE pass without a
+    temperature step -- every column keeps the T-P profile it was given and ends where its own single post-processing run
+    ends (an earlier version iterated the fixed profile 'to convergence' with 1001 sweeps per iteration)"""
+    import sweep
+    wd = str(tmp_path)
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "24 6 5 7",
+            "-number_of_layers", "30", "-maximum_number_of_iterations", "20000", "-radiative_equilibrium_criterion", "1e-5",
+            "-convective_adjustment", "no"]
+    it = _run_driver(base + ["-output_directory", wd + "/", "-name", "run"], True)
+    pp_args = base + ["-run_type", "post-processing", "-path_to_temperature_file", os.path.join(wd, "run", "run_tp.dat")]
+    cols, spectra = sweep.main(["-sweep", "f_factor=0.25,0.6"] + pp_args + ["-output_directory", wd + "/batch/", "-name", "pp"])
+    assert len(cols) == 2 and spectra.shape == (2, 24)
+    for k, f in enumerate(("0.25", "0.6")):
+        single = _run_driver(pp_args + ["-output_directory", wd + "/single/", "-name", "s%d" % k, "-f_factor", f], True)
+        q = cols[k]
+        assert int(q.singlewalk) == 1 and int(q.iso) == 1 and int(q.iter_value) == 0 == int(single.iter_value)
+        np.testing.assert_allclose(q.T_lay, it.T_lay, rtol=1e-5)            # the given profile, untouched (6 digits in the file)
+        np.testing.assert_allclose(q.T_lay, single.T_lay, rtol=1e-14)
+        np.testing.assert_allclose(spectra[k], single.F_up_band[-24:], rtol=1e-12)
+    assert np.abs(spectra[0] / spectra[1] - 1.0).max() > 1e-3
 
 
 def test_sweep_with_convection_and_two_ranks(tmp_path):

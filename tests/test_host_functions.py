@@ -45,6 +45,26 @@ def test_automatic_layer_count_and_param_parsing(tmp_path):
     assert q.crit_relaxation_numbers == [10000, 20000] and q.plancktable_dim == 8000
 
 
+def test_isothermal_layers_with_convective_adjustment_are_refused_when_the_input_is_read(tmp_path):
+    """the reference fails with a TypeError after the whole radiative loop (computation.py:1004-1009); here the
+    combination is refused at set-up, before any GPU work -- but not for the post-processing run type, which is isothermal
+    by definition and never enters the convection loop"""
+    import pytest
+    p = tmp_path / "param.dat"
+    p.write_text("name = abc [x]\n")
+    for flags, ok in ((["-isothermal_layers", "yes", "-convective_adjustment", "yes"], False),
+                      (["-isothermal_layers", "yes", "-convective_adjustment", "no"], True),
+                      (["-run_type", "post-processing", "-convective_adjustment", "yes"], True)):
+        r, q = Read(), Q()
+        q.no_atmo_mode = 0
+        if ok:
+            r.read_param_file_and_command_line(q, None, ["-parameter_file", str(p)] + flags)
+            assert q.iso == 1
+        else:
+            with pytest.raises(IOError, match="non-isothermal"):
+                r.read_param_file_and_command_line(q, None, ["-parameter_file", str(p)] + flags)
+
+
 def test_height_z_gas_and_rocky():
     q = Q()
     q.nlayer = 6

@@ -90,6 +90,13 @@ def _worklist_worker(rank, world, port, ncol, chunk, q):
     cols = work.claimed
     local = np.array([[c * 100.0 + k for k in range(5)] for c in cols]).reshape(len(cols), 5)
     full = gather_spectra(local, dist, columns=cols)
+    # a second sweep in the same process group draws from its own counter (its own key), not from the exhausted one
+    again = WorkList(ncol, chunk, dist, key=WorkList.KEY + "/sweep2")
+    second = [c for cols2 in iter(again.claim, []) for c in cols2]
+    stale = WorkList(ncol, chunk, dist)          # the first key once more: nothing left to claim
+    every = [None, None]
+    dist.all_gather_object(every, (second, stale.claim()))
+    assert sorted(every[0][0] + every[1][0]) == list(range(ncol)) and every[0][1] == every[1][1] == []
     q.put((rank, cols, full))
     dist.destroy_process_group()
 
