@@ -23,6 +23,7 @@ def run_helios(argv=None):
     writer = write_mod.Write()
 
     reader.read_param_file_and_command_line(keeper, reader.cloud, argv)
+    reader.check_run_configuration(keeper)
     if keeper.opacity_mixing in ("premixed", "synthetic"):
         reader.load_premixed_opacity_table(keeper)
     elif keeper.opacity_mixing == "on-the-fly":

@@ -150,6 +150,18 @@ class Read(object):
         self.synthetic_spec = None
         self.cloud = Cloud()
 
+    @staticmethod
+    def check_run_configuration(quant):
+        """set-up time checks of combinations the reference only trips over deep into a run.  Called by run_helios and by
+        the sweep driver right after the input has been read, before any GPU work (the reader itself parses what the
+        reference's reader parses, tests/golden/reader)"""
+        if quant.iso == 1 and quant.convection == 1 and quant.singlewalk == 0:
+            # the reference skips the stability test with isothermal layers and then sums a conv_unstable that was never
+            # built (computation.py:1004-1009, quantities.py:134: `sum(None)` raises TypeError after the whole radiative
+            # loop has run)
+            raise IOError("ERROR: convective adjustment needs non-isothermal layers (the reference cannot run this "
+                          "combination either); set 'isothermal layers = no' or 'convective adjustment = no'")
+
     # ---------------------------------------------------------------------------------------------
     @staticmethod
     def _parse_param_file(path):
@@ -328,12 +340,6 @@ class Read(object):
             quant.no_atmo_mode = i32(1)
             quant.p_toa, quant.p_boa = 1e-3, 2e-3
             quant.scat, quant.convection, quant.nlayer = i32(0), i32(0), i32(2)
-        if quant.iso == 1 and quant.convection == 1 and quant.singlewalk == 0:
-            # the reference skips the stability test with isothermal layers and then sums a conv_unstable that was never
-            # built (computation.py:1004-1009, quantities.py:134: `sum(None)` raises TypeError after the whole radiative
-            # loop has run): say what is wrong before any GPU work instead
-            raise IOError("ERROR: convective adjustment needs non-isothermal layers (the reference cannot run this "
-                          "combination either); set 'isothermal layers = no' or 'convective adjustment = no'")
         quant.ninterface = i32(quant.nlayer + 1)
         print("\n### Welcome! This run has the name: " + str(quant.name) + ". ###")
 

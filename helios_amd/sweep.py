@@ -47,6 +47,7 @@ def _prepare_column(base_argv, overrides, shared):
     for k, v in overrides.items():
         argv += ["-" + k, str(v)]
     reader.read_param_file_and_command_line(keeper, reader.cloud, argv)
+    reader.check_run_configuration(keeper)
     if "tables" not in shared:
         if keeper.opacity_mixing in ("premixed", "synthetic"):
             reader.load_premixed_opacity_table(keeper)

@@ -47,7 +47,7 @@ def test_automatic_layer_count_and_param_parsing(tmp_path):
 
 def test_isothermal_layers_with_convective_adjustment_are_refused_when_the_input_is_read(tmp_path):
     """the reference fails with a TypeError after the whole radiative loop (computation.py:1004-1009); here the
-    combination is refused at set-up, before any GPU work -- but not for the post-processing run type, which is isothermal
+    combination is refused at set-up (Read.check_run_configuration, called by run_helios and the sweep driver), before any GPU work -- but not for the post-processing run type, which is isothermal
     by definition and never enters the convection loop"""
     import pytest
     p = tmp_path / "param.dat"
@@ -57,12 +57,13 @@ def test_isothermal_layers_with_convective_adjustment_are_refused_when_the_input
                       (["-run_type", "post-processing", "-convective_adjustment", "yes"], True)):
         r, q = Read(), Q()
         q.no_atmo_mode = 0
+        r.read_param_file_and_command_line(q, None, ["-parameter_file", str(p)] + flags)   # parses, as the reference's reader
+        assert q.iso == 1
         if ok:
-            r.read_param_file_and_command_line(q, None, ["-parameter_file", str(p)] + flags)
-            assert q.iso == 1
+            r.check_run_configuration(q)
         else:
             with pytest.raises(IOError, match="non-isothermal"):
-                r.read_param_file_and_command_line(q, None, ["-parameter_file", str(p)] + flags)
+                r.check_run_configuration(q)
 
 
 def test_height_z_gas_and_rocky():
