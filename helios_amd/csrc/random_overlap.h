@@ -44,21 +44,34 @@ constexpr int LDS_N = 512;   // by fill position (<= 511) or by padded rank (399
 constexpr int ROW_PITCH = 21;
 constexpr int PAD = 511;
 
+constexpr int NTAB_O = 21, NTAB_I = 28;  // table entries per curve: 20 Gauss points, then constants for the padding slots
+
+struct Pair {
+    double v, hw;  // a curve's coefficient at a Gauss point and the half weight of that point, read with one 16-byte load
+};
+
 struct Shared {
-    // outer: the curve that is stronger at y = 0 (outer fill loop).  Entry NY of outer / inner / hw is a constant
-    // (inf, 0, 0): what the padding slots of the run layout read, so that their sum is inf and their weight 0 without a
-    // branch or a select
-    double outer[NY + 1], inner[NY + 1], hw[NY + 1], gy[NY];
+    // op: the curve that is stronger at y = 0 (outer fill loop), ip: the other one.  The entries from NY on are constants,
+    // (inf, 0): what the padding slots of the run layout read, so that their sum is inf and their weight 0 without a
+    // branch or a select (inf + inf = inf, 0 * 0 = 0)
+    Pair op[NTAB_O], ip[NTAB_I];
+    double gy[NY];
     double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded rank: sorted sum / abscissa
 };
 
 struct Lane {
     unsigned c[3];         // c[t] = 0 where lane bit t is clear (lower partner of an exchange over that bit), else ~0;
                            // bits 3-5 (6 of the 35 exchanges) are extracted where they are used: three registers fewer
-    // Tableau coordinates of the network position p = 8 lane + s (the "run layout", see run_cell): byte offsets
-    // 8 i | 8 j << 8 of outer[i], inner[j], the padded fill position 21 i + j of the no-crossing order << 16 (pads: PAD),
-    // bit 31 set for a pad
-    unsigned cell[SLOTS];
+    // The run layout (see run_lane): a lane's eight network positions are eight consecutive cells of ONE row or ONE
+    // column of the tableau, so one operand of its sums is the same for all slots and the other steps by one table entry.
+    unsigned fix, var;     // LDS byte offsets (from the start of Shared) of the fixed entry and of slot 0's varying entry
+    unsigned e0step;       // padded fill position 21 i + j of slot 0 | its step per slot (1 along a row, 21 down a column) << 16
+    unsigned ij;           // i | j << 8 of slot 0 | (1 << 16 if i steps, 1 << 24 if j steps): the crossing case's fill positions
+    unsigned padlo, padhi; // all ones where the slots 0-3 / 4-7 are padding
+    // the presorted tableau read in rank order (rank w = 8 lane + r is cell (w / 20, w % 20)): offsets of op[w0 / 20] and
+    // ip[w0 % 20] for w0 = 8 lane, and the first slot that belongs to the next row
+    unsigned pa, pb;
+    int wrap;
 };
 
 struct Counters {
@@ -73,28 +86,53 @@ struct Counters {
 // (400 sums cannot be cut into fewer than 20 ascending chains -- the anti-diagonal is an antichain -- so runs of 32 are
 // out of reach.)  Keys inside a run ascend too: equal quantised sums are ordered by fill position, and both fill orders
 // of the reference (:3332-3365) ascend along rows and along columns.  Position p = 8 lane + s: run = lane / 2.
-__device__ __forceinline__ unsigned run_cell(int lane, int s) {
-    const int run = lane >> 1, idx = 8 * (lane & 1) + s;
-    int i = -1, j = -1;
-    if (run < 20) { i = run; j = idx; }
-    else if (run < 24) { i = idx; j = 16 + (run - 20); }
-    else if (run < 28 && idx < 4) { i = 16 + (run - 24); j = 16 + idx; }
-    if (i < 0) return 0x80000000u | (unsigned)PAD << 16 | (unsigned)(8 * NY) << 8 | (unsigned)(8 * NY);  // pads: the constant entries
-    return (unsigned)(8 * i) | (unsigned)(8 * j) << 8 | (unsigned)(ROW_PITCH * i + j) << 16;
+__device__ __forceinline__ void run_lane(Lane& ln, int lane) {
+    const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
+    const int run = lane >> 1, idx0 = 8 * (lane & 1);
+    int i = NY, j = NY, di = 0, dj = 0;   // default: padding everywhere (constant entries)
+    ln.padlo = ln.padhi = 0xFFFFFFFFu;
+    if (run < 20) { i = run; j = idx0; dj = 1; ln.padlo = ln.padhi = 0u; }                       // row i, columns idx0 ...
+    else if (run < 24) { i = idx0; j = 16 + (run - 20); di = 1; ln.padlo = ln.padhi = 0u; }       // column j, rows idx0 ...
+    else if (run < 28 && idx0 == 0) { i = 16 + (run - 24); j = 16; dj = 1; ln.padlo = 0u; }       // corner row: 4 cells + pads
+    if (di) {  // the column's entry is the fixed operand
+        ln.fix = IP + PS * j;
+        ln.var = OP + PS * i;
+    } else {
+        ln.fix = OP + PS * i;
+        ln.var = IP + PS * j;
+    }
+    ln.e0step = (unsigned)(ROW_PITCH * i + j) | (unsigned)(di ? ROW_PITCH : 1) << 16;
+    ln.ij = (unsigned)i | (unsigned)j << 8 | (unsigned)di << 16 | (unsigned)dj << 24;
+    const int w0 = 8 * lane;
+    if (w0 < N) {
+        ln.pa = OP + PS * (w0 / NY);
+        ln.pb = IP + PS * (w0 % NY);
+        ln.wrap = NY - w0 % NY;   // slots r >= wrap: next row, column r - wrap
+    } else {
+        ln.pa = OP + PS * NY;
+        ln.pb = IP + PS * NY;
+        ln.wrap = SLOTS;
+    }
 }
 
 __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const double* gauss_weight, const double* gauss_y) {
     if (lane < NY) {
-        sh.hw[lane] = 0.5 * gauss_weight[lane];
+        sh.op[lane].hw = sh.ip[lane].hw = 0.5 * gauss_weight[lane];
         sh.gy[lane] = gauss_y[lane];
+    } else if (lane < NTAB_I) {
+        sh.ip[lane].v = __builtin_inf();
+        sh.ip[lane].hw = 0.0;
+        if (lane < NTAB_O) {
+            sh.op[lane].v = __builtin_inf();
+            sh.op[lane].hw = 0.0;
+        }
     }
 #pragma unroll
     for (int t = 0; t < 3; t++) ln.c[t] = (lane >> t) & 1 ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-    for (int r = 0; r < SLOTS; r++) ln.cell[r] = run_cell(lane, r);
+    run_lane(ln, lane);
     if (lane == 0) {
-        sh.A[PAD] = sh.outer[NY] = __builtin_inf();
-        sh.B[PAD] = sh.inner[NY] = sh.hw[NY] = 0.0;
+        sh.A[PAD] = __builtin_inf();
+        sh.B[PAD] = 0.0;
     }
 }
 
@@ -256,27 +294,27 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
                                     // not kept in fourteen registers through the whole kernel
     const int nfirst = NY * yx;
     const int inv_yx = (1048576 + yx - 1) / yx;
-    const char* outer = (const char*)sh.outer;
-    const char* inner = (const char*)sh.inner;
-    const char* hw = (const char*)sh.hw;
+    const char* outer = (const char*)sh.op;
+    const char* inner = (const char*)sh.ip;
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
         const int e = 64 * r + lane;
         double K = __builtin_inf(), g = 0.0;
         unsigned key = 0xFFFFFE00u | (unsigned)e;
         if (r < 6 || (r == 6 && lane < N - 6 * 64)) {  // e < 400: every lane for r < 6, 16 lanes for r = 6, none for r = 7
-            int aq = 8 * (e / 20), ar = 8 * (e % 20);  // byte offsets of outer[e / 20], inner[e % 20]
+            int aq = 16 * (e / 20), ar = 16 * (e % 20);  // byte offsets of op[e / 20], ip[e % 20]
             if (CROSSING) {  // the curves cross: two fill regions (:3332-3365)
                 const bool first = e < nfirst;
                 // e / yx and e / 20 for e < 512 as multiply-shift (exact: e * d < 2^20 / d for d <= 20)
                 const int q = (int)(__umul24(e, first ? inv_yx : 52429) >> 20);
                 const int rem = e - __umul24(q, first ? yx : NY);
                 // second part: the curves have changed places, the other one is on the outer loop
-                aq = 8 * (first ? q : rem);
-                ar = 8 * (first ? rem : q);
+                aq = 16 * (first ? q : rem);
+                ar = 16 * (first ? rem : q);
             }
-            K = *(const double*)(outer + aq) + *(const double*)(inner + ar);
-            g = *(const double*)(hw + aq) * *(const double*)(hw + ar);
+            const Pair po = *(const Pair*)(outer + aq), pi = *(const Pair*)(inner + ar);
+            K = po.v + pi.v;
+            g = po.hw * pi.hw;
             int dh = __double2hiint(K) - hmin;
             if (!MONOTONE) dh = max(dh, 0);
             unsigned q23 = sh_bits >= 32 ? (unsigned)dh >> (sh_bits - 32)
@@ -295,28 +333,30 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
 // stronger curve on the outer loop) -- as the low key bits and as the address of the LDS images.  HI: sh_bits >= 32.
 template <bool CROSSING, bool HI>
 __device__ __forceinline__ void fill_runs(Shared& sh, const Lane& ln, Keys& v, int yx, int hmin, int sh_bits) {
-    const char* outer = (const char*)sh.outer;
-    const char* inner = (const char*)sh.inner;
-    const char* hw = (const char*)sh.hw;
+    const char* base = (const char*)&sh;
+    // (the barriers: what is derived from the lane's constants -- eight addresses, eight fill positions -- is derived
+    // here, per problem; hoisted out of the problem loop it would sit in two dozen registers)
+    unsigned fix = ln.fix, var = ln.var, e0step = ln.e0step;
+    asm volatile("" : "+v"(fix), "+v"(var), "+v"(e0step));
+    const Pair F = *(const Pair*)(base + fix);
+    const unsigned e0 = e0step & 0xFFFF, estep = e0step >> 16;
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
-        unsigned cell = ln.cell[r];
-        asm volatile("" : "+v"(cell));  // unpack here, per problem: hoisted out of the problem loop the four fields of the
-                                        // eight cells would occupy 32 registers instead of 8
-        const int ai = cell & 0xFF, aj = (cell >> 8) & 0xFF;
-        int e = (cell >> 16) & 0x1FF;   // index of the LDS images and tie-break of the key
-        const double K = *(const double*)(outer + ai) + *(const double*)(inner + aj);
-        const double g = *(const double*)(hw + ai) * *(const double*)(hw + aj);
+        const Pair V = *(const Pair*)(base + var + (unsigned)sizeof(Pair) * r);
+        const double K = F.v + V.v;      // pads: inf
+        const double g = F.hw * V.hw;    // pads: 0
+        unsigned e = e0 + estep * r;     // index of the LDS images and tie-break of the key
         if (CROSSING) {
-            const int i8 = ai, j8 = aj;  // 8 i, 8 j
-            const int e1 = (j8 + __umul24(yx, i8)) >> 3, e2 = (i8 + 20 * j8) >> 3;
-            e = (int)cell < 0 ? e : (j8 < 8 * yx ? e1 : e2);
+            const unsigned i = (ln.ij & 0xFF) + ((ln.ij >> 16) & 1) * r, j = ((ln.ij >> 8) & 0xFF) + (ln.ij >> 24) * r;
+            e = (int)j < yx ? j + __umul24(yx, i) : i + 20 * j;
         }
+        const unsigned pad = r < SLOTS / 2 ? ln.padlo : ln.padhi;
         const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
         const unsigned q23 = HI ? dh >> (sh_bits - 32) : __builtin_amdgcn_alignbit(dh, (unsigned)__double2loint(K), sh_bits);
-        v.k[r] = (q23 << 9 | (unsigned)e) | (unsigned)((int)cell >> 31);  // pads: all ones
-        sh.A[e] = K;   // pads: (inf, 0) into their common cell
-        sh.B[e] = g;
+        v.k[r] = (q23 << 9 | e) | pad;                       // pads: all ones
+        const unsigned at = ((e << 3) | pad) & (8 * PAD);   // pads: their common cell, which holds (inf, 0) anyway
+        *(double*)((char*)sh.A + at) = K;
+        *(double*)((char*)sh.B + at) = g;
     }
 }
 
@@ -328,8 +368,8 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     const bool mix_first = m0 > a0;
     sync();  // the previous problem's readers are done with sh
     if (lane < NY) {
-        sh.outer[lane] = mix_first ? my_mix : my_add;
-        sh.inner[lane] = mix_first ? my_add : my_mix;
+        sh.op[lane].v = mix_first ? my_mix : my_add;
+        sh.ip[lane].v = mix_first ? my_add : my_mix;
     }
     sync();
     // last crossing of the two curves (:3321-3329); are both k-distributions (ascending)?
@@ -337,7 +377,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     // ascending in fill order (without a crossing: e = 20 i + j) and nothing has to be sorted
     bool cross = false, down = false, over = false;
     if (lane >= 1 && lane < NY) {
-        const double po = sh.outer[lane - 1], pi = sh.inner[lane - 1];
+        const double po = sh.op[lane - 1].v, pi = sh.ip[lane - 1].v;
         const double pm = mix_first ? po : pi, pa = mix_first ? pi : po;
         cross = (my_mix > my_add) != (pm > pa);
         down = my_mix < pm || my_add < pa;
@@ -350,11 +390,11 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     const bool rows_apart = __ballot(over) == 0;
     double kmin = m0 + a0, kmax = m19 + a19;
     if (!monotone) {  // the extreme sums are not at the corners of the tableau
-        double mn1 = sh.outer[0], mx1 = mn1, mn2 = sh.inner[0], mx2 = mn2;
+        double mn1 = sh.op[0].v, mx1 = mn1, mn2 = sh.ip[0].v, mx2 = mn2;
 #pragma unroll 1
         for (int j = 1; j < NY; j++) {
-            mn1 = fmin(mn1, sh.outer[j]); mx1 = fmax(mx1, sh.outer[j]);
-            mn2 = fmin(mn2, sh.inner[j]); mx2 = fmax(mx2, sh.inner[j]);
+            mn1 = fmin(mn1, sh.op[j].v); mx1 = fmax(mx1, sh.op[j].v);
+            mn2 = fmin(mn2, sh.ip[j].v); mx2 = fmax(mx2, sh.ip[j].v);
         }
         kmin = mn1 + mn2;
         kmax = mx1 + mx2;
@@ -366,40 +406,48 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(kmax));
     const int bl = dmax ? 64 - __clzll((long long)dmax) : 0;
     const int sh_bits = bl > 23 ? bl - 23 : 0;
-    Keys v;
-    bool presorted = false;
-    if (monotone) {
-        if (yx == NY) {
-            if (sh_bits >= 32) fill_runs<false, true>(sh, ln, v, yx, hmin, sh_bits);
-            else fill_runs<false, false>(sh, ln, v, yx, hmin, sh_bits);
-            presorted = rows_apart;
-        } else {
-            if (sh_bits >= 32) fill_runs<true, true>(sh, ln, v, yx, hmin, sh_bits);
-            else fill_runs<true, false>(sh, ln, v, yx, hmin, sh_bits);
+    double K[SLOTS], g[SLOTS];
+    if (monotone && yx == NY && rows_apart) {
+        // nothing to sort: rank w = 8 lane + r is cell (w / 20, w % 20) -- the sums and weights straight from the curves,
+        // no keys, no LDS images
+        const char* base = (const char*)&sh;
+        unsigned pa = ln.pa, pb = ln.pb;
+        int wrap = ln.wrap;
+        asm volatile("" : "+v"(pa), "+v"(pb), "+v"(wrap));
+#pragma unroll
+        for (int r = 0; r < SLOTS; r++) {
+            const bool next_row = r >= wrap;
+            const Pair po = *(const Pair*)(base + pa + (next_row ? (unsigned)sizeof(Pair) : 0u));
+            const Pair pi = *(const Pair*)(base + pb + (unsigned)sizeof(Pair) * r - (next_row ? (unsigned)sizeof(Pair) * NY : 0u));
+            K[r] = po.v + pi.v;
+            g[r] = po.hw * pi.hw;
         }
-        if (!presorted) {
+    } else {
+        Keys v;
+        if (monotone) {
+            if (yx == NY) {
+                if (sh_bits >= 32) fill_runs<false, true>(sh, ln, v, yx, hmin, sh_bits);
+                else fill_runs<false, false>(sh, ln, v, yx, hmin, sh_bits);
+            } else {
+                if (sh_bits >= 32) fill_runs<true, true>(sh, ln, v, yx, hmin, sh_bits);
+                else fill_runs<true, false>(sh, ln, v, yx, hmin, sh_bits);
+            }
             int lv = lane;
             asm volatile("" : "+v"(lv));  // what the network derives from the lane id (exchange addresses, bits 3-5) is
                                           // rebuilt per problem and does not sit in registers between the problems
             sort512_from_runs16(v, lv, ln);
+        } else {  // a curve that is not a k-distribution: positions in fill order, the whole network
+            if (yx == NY) fill<false, false>(sh, ln, lane, v, yx, hmin, sh_bits);
+            else fill<false, true>(sh, ln, lane, v, yx, hmin, sh_bits);
+            sort512(v, lane, ln);
         }
-    } else {  // a curve that is not a k-distribution: positions in fill order, the whole network
-        if (yx == NY) fill<false, false>(sh, ln, lane, v, yx, hmin, sh_bits);
-        else fill<false, true>(sh, ln, lane, v, yx, hmin, sh_bits);
-        sort512(v, lane, ln);
-    }
-    sync();
-    int src[SLOTS];  // byte offset of the fill position of the element at rank 8 lane + r
+        sync();
 #pragma unroll
-    for (int r = 0; r < SLOTS; r++) {
-        const int w = SLOTS * lane + r;  // rank; presorted: the sum at fill position w, LDS index w + w / 20
-        src[r] = presorted ? (w < N ? 8 * (w + (int)(__umul24(w, 52429) >> 20)) : 8 * PAD) : (int)(v.k[r] & 511) << 3;
-    }
-    double K[SLOTS], g[SLOTS];
-#pragma unroll
-    for (int r = 0; r < SLOTS; r++) {
-        K[r] = *(const double*)((const char*)sh.A + src[r]);
-        g[r] = *(const double*)((const char*)sh.B + src[r]);
+        for (int r = 0; r < SLOTS; r++) {
+            const int src = (int)(v.k[r] & 511) << 3;  // byte offset of the LDS images' entry of the element at rank 8 lane + r
+            K[r] = *(const double*)((const char*)sh.A + src);
+            g[r] = *(const double*)((const char*)sh.B + src);
+        }
     }
     // exact finish: any inversion left by the quantisation?
     const int next = (lane < 63 ? lane + 1 : lane) << 2, prev = (lane > 0 ? lane - 1 : lane) << 2;

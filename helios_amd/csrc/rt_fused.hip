@@ -726,7 +726,7 @@ int hx_rt_refresh(hx_rt* rt) {
         HX_REQUIRE(ctx, Y <= ro::NY, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 20 Gauss points");
         int nabs = 0;
         for (const Species& sp : rt->species) nabs += sp.absorbing ? 1 : 0;
-        HX_REQUIRE(ctx, nabs <= MIX_MAX_ABSORBERS, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 64 absorbers");
+        HX_REQUIRE(ctx, nabs <= MIX_MAX_ABSORBERS, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 48 absorbers");
     }
     KArgs a = make_args(rt);
     {   // interface temperatures (and node Planck values) of the CURRENT layer temperatures

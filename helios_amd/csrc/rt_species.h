@@ -85,7 +85,8 @@ __global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, cons
     mmm_lay[(size_t)col * I + i] = num / tot * HX_AMU;
 }
 
-constexpr int MIX_MAX_ABSORBERS = 64;  // LDS images of the species list: 1.25 KB next to ro::Shared, 16 wavefronts per CU
+constexpr int MIX_MAX_ABSORBERS = 48;  // LDS images of the species list: 1 KB next to ro::Shared; together <= 10 KB, so that
+                                       // 16 wavefronts share a CU's 160 KB
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_rt_mix_species(MixArgs a) {
     __shared__ ro::Shared sh;
@@ -165,8 +166,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
         if (skip) continue;
         const unsigned off = (unsigned)(a.Y * x + y);  // inside a table plane: the same for all corners of all species
         double c_dd = 0.0, c_ud = 0.0, c_du = 0.0, c_uu = 0.0;
+        int gl = grp;
+        asm volatile("" : "+v"(gl));  // the LDS address of this lane's table pointer is rebuilt per point (no register, no scratch slot)
         if (loader && grp < nabs) {
-            const double* tab = s_tab[grp];
+            const double* tab = s_tab[gl];
             c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];
         }
         double mixv = 0.0;  // nullify_opac_scat_arrays (host_functions.py:1050-1056)

@@ -312,7 +312,12 @@ def loopconv_fixture(name, hostref=False):
     data = {"meta": json.dumps(m), "planck_grid": s.planck_grid.copy(), "kappa": np.array(kappa),
             "radiative_first": np.array(int(radiative_first))}
     for k, v in c0.items():
-        data["in." + k] = np.asarray(v)
+        if k != "species":
+            data["in." + k] = np.asarray(v)
+    for i, sp in enumerate(c0.get("species") or []):     # the species list as plain arrays
+        for k, v in sp.items():
+            if v is not None:
+                data["species.%d.%s" % (i, k)] = np.asarray(v)
     with contextlib.redirect_stdout(io.StringIO()):       # check_for_radiative_eq prints every 100th iteration
         n_rad, n, snaps, q = ld.rad_conv_run(ref, hs, c, s, kappa, radiative_first)
     data["rad_iter_count"] = np.array(n_rad)
@@ -387,7 +392,7 @@ if __name__ == "__main__":
             loopconv_fixture(name, hostref=True)
     elif not only or "loopconv" in only:
         import loop_driver as ld
-        for name in ld.CONV_NAMES:
+        for name in (a.loop_names.split(",") if a.loop_names else ld.CONV_NAMES):
             loopconv_fixture(name)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("wrote fixtures to %s, %.1f KB total" % (OUT, tot / 1024.0))

@@ -93,12 +93,16 @@ def loop_case(name):
     elif name == "onthefly":
         # opacities mixed on the fly at every refresh: 4 absorbers (one CIA pair), water-vapour and H2 scattering
         kw.update(nbin=5)
+    elif name == "c5physics_onthefly":
+        # BASELINE config 5's ingredients together in one small column: absorbers mixed on the fly with random overlap,
+        # two cloud decks, g0 with the I2S correction, direct beam, reflecting surface
+        kw.update(nbin=5, clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0)
     else:
         raise KeyError(name)
     c = cases.make_case(**kw)
     if name == "noscat_relax":
         c.rad_convergence_limit = 1e-9
-    if name == "onthefly":
+    if name in ("onthefly", "c5physics_onthefly"):
         cases.add_species(c, nspecies=4)
     return c, relax
 
@@ -107,7 +111,7 @@ def loop_refresh(c):
     return cases.refresh_onthefly if c.get("species") else cases.refresh_premixed
 
 
-LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s", "onthefly")
+LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s", "onthefly", "c5physics_onthefly")
 SNAP_AT = (1, 10, 11, 50)
 
 
@@ -225,7 +229,7 @@ def convection_loop(impl, hs, c, s, kappa, snap_at=(), max_nr_iterations=20000, 
     return int(q.iter_value), snaps, q
 
 
-CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "surface_jump", "detached")
+CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "surface_jump", "detached", "c5physics_onthefly")
 CONV_SIZE = dict(nbin=6, nlayer=16, ntemp=6, npress=5, plancktable_dim=800, plancktable_step=10)
 
 
@@ -252,12 +256,16 @@ def conv_case(name):
         limit = 1e-7
     elif name == "clouds_g0_i2s":
         kw.update(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0, T_intern=350.0)
+    elif name == "c5physics_onthefly":   # config 5 in small: on-the-fly mixing + clouds + beam + albedo + I2S, then convection
+        kw.update(nbin=5, clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0, T_intern=350.0)
     elif name == "detached":
         kw.update(nlayer=20, dir_beam=1, albedo=0.2, T_intern=300.0)
         kappa, radiative_first = 0.25, False
     else:
         raise KeyError(name)
     c = cases.make_case(**kw)
+    if name == "c5physics_onthefly":
+        cases.add_species(c, nspecies=4)
     c.rad_convergence_limit = limit
     c.c_p_lay = np.full(c.nlayer, pc.R_UNIV / kappa)              # read.py:1178-1180
     if name == "detached":
@@ -275,7 +283,7 @@ def rad_conv_run(impl, hs, c, s, kappa, radiative_first):
     """radiation loop (when the case has one), then the convection loop from the state it leaves"""
     n_rad, reason = 0, "not run"
     if radiative_first:
-        n_rad, _snaps, reason = radiation_loop(impl, c, s)
-    n, snaps, q = convection_loop(impl, hs, c, s, kappa, snap_at=CONV_SNAP_AT)
+        n_rad, _snaps, reason = radiation_loop(impl, c, s, refresh=loop_refresh(c))
+    n, snaps, q = convection_loop(impl, hs, c, s, kappa, snap_at=CONV_SNAP_AT, refresh=loop_refresh(c))
     q.rad_reason = reason
     return n_rad, n, snaps, q

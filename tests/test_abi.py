@@ -124,3 +124,14 @@ def test_no_selected_flux_kernel_keeps_registers_in_scratch():
     spilling = {(int(name.split("<")[1].split(",")[0]), int(name.split(",")[1].split(">")[0]))
                 for name, v in flux.items() if v["vgpr_spill_count"] > 0}
     assert spilling and not (spilling & seen)
+
+
+def test_only_the_unselected_flux_tilings_use_scratch():
+    """every other kernel of the library -- the species loop with random overlap, the coefficient kernel, all per-stage
+    kernels -- runs without a private segment (k_rt_mix_species kept 7 VGPRs in scratch in round 2: 2.1 GB of stores per
+    launch); the mixing kernel also has to leave room for 16 wavefronts per CU (128 VGPRs, 10 KB of LDS)"""
+    notes = _kernel_notes()
+    with_scratch = sorted(n for n, k in notes.items() if k["private_segment_fixed_size"] > 0 or k["vgpr_spill_count"] > 0)
+    assert with_scratch and all("k_rt_flux<" in n for n in with_scratch), with_scratch
+    mix = [k for n, k in notes.items() if "k_rt_mix_species" in n]
+    assert len(mix) == 1 and mix[0]["vgpr_count"] <= 128 and mix[0]["group_segment_fixed_size"] <= 10240

@@ -55,7 +55,7 @@ def test_oracle_convection_loop_golden(port, name, capsys):
 
 def test_convection_loop_fixtures_cover_the_verdict_list():
     for name in ld.CONV_NAMES:
-        z = np.load(gc.os.path.join(gc.GOLDEN, "loopconv_%s.npz" % name))
+        z = np.load(gc.os.path.join(gc.GOLDEN, "loopconv_%s.npz" % name), allow_pickle=False)
         for at in ("start", "it1", "it10", "it11", "it50", "it400", "end"):
             for k in ("T_lay", "F_net", "F_up_band_TOA", "conv_layer", "marked_red"):
                 assert "%s.%s" % (at, k) in z.files
