@@ -231,6 +231,13 @@ def convection_loop(impl, hs, c, s, kappa, snap_at=(), max_nr_iterations=20000, 
 
 CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "surface_jump", "detached", "c5physics_onthefly")
 CONV_SIZE = dict(nbin=6, nlayer=16, ntemp=6, npress=5, plancktable_dim=800, plancktable_step=10)
+# Columns whose convection loop takes a marginal time-step decision (`|T - T_store| < adapt/2 |dT|`, kernels.cu:2869-2876)
+# between iterations 50 and 400: last-bit differences decide it, the trajectories part for a few hundred iterations and
+# meet again at the same equilibrium.  The REFERENCE ITSELF is not reproducible there: its gfx950 build leaves the loop of
+# `c5physics_onthefly` after 1281 iterations, its host build (no FMA contraction) after 7861, this repo's oracle and library
+# after 1241 -- end states within 6e-10 of each other.  For these the tests hold everything through iteration 50 and the end
+# state, not the count.
+CONV_COUNT_SENSITIVE = ("c5physics_onthefly",)
 
 
 def conv_case(name):
