@@ -259,8 +259,11 @@ __device__ __forceinline__ int padded(int w) { return w + (w >> 3); }
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_or_zero(double x) {  // the DPP-selected lane's value, 0.0 where there is none
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+    // a lane without a source inside its row reads 0 through bound_ctrl (no register to clear beforehand); only the
+    // row-masked broadcasts need a zeroed destination for the rows they leave out
+    constexpr bool BC = ROW_MASK == 0xF;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, BC);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, BC);
     return __hiloint2double(hi, lo);
 }
 
@@ -486,7 +489,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         const int w = SLOTS * lane + r;
         if (w < N) {
             sh.A[9 * lane + r] = K[r];  // = padded(w)
-            sh.B[9 * lane + r] = run + 0.5 * g[r];
+            sh.B[9 * lane + r] = fma(0.5, g[r], run);  // = run + 0.5 g bit for bit (0.5 g is exact): one instruction
         }
         run += g[r];
     }
@@ -496,12 +499,14 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     double yq = 0.0;
     if (lane < NY) {
         yq = sh.gy[lane];
-        int lo = 1, hi = N;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (sh.B[padded(mid)] > yq) hi = mid; else lo = mid + 1;
+        // lower bound over w = 1 ... 399 with lengths known at compile time: ten dependent LDS reads, no loop control
+        int base = 1;
+#pragma unroll
+        for (int len = N - 1; len > 1; len -= len / 2) {
+            const int probe = base + len / 2 - 1;
+            base = sh.B[padded(probe)] > yq ? base : probe + 1;
         }
-        w = lo;
+        w = base + (sh.B[padded(base)] > yq ? 0 : 1);
     }
     // a Gauss point that falls into the interval of its predecessor takes the next one (the reference's walk advances w
     // before it looks at the next point, and reports a malfunction, :3383-3387): w'_q = max over j <= q of (w_j + q - j)
