@@ -30,6 +30,9 @@
 #ifndef RO_SWIZZLE_XOR4
 #define RO_SWIZZLE_XOR4 0
 #endif
+#ifndef RO_DPP_MINMAX4
+#define RO_DPP_MINMAX4 1   // same-box A/B at config 3: 43.6 -> 43.05 ms per refresh
+#endif
 
 namespace ro {
 
@@ -149,23 +152,29 @@ __device__ __forceinline__ unsigned med3(unsigned a, unsigned b, unsigned c) {
     return r;
 }
 
-// the value lane^M holds: DPP moves where one or two of them express the permutation, the LDS crossbar for M = 16, 31, 63
+// the value lane^M holds: DPP moves where one or two of them express the permutation, the LDS crossbar for M = 16, 31, 63.
+// RO_SWIZZLE_MASK (bit M set: exchange with lane^M through ds_swizzle instead of DPP) moves vector instructions over to
+// the LDS pipe -- the kernel is bound by vector issue (VALU active 90 % of the time, the LDS unit 30 %), the exchanges
+// then wait for the crossbar; which mix wins is measured
+// Measured at config 3 (43.6 ms with none): lane^4 through the crossbar 46.1 ms, lane^4 and ^8 47.1, ^4 ^7 ^8 ^15 48.8 --
+// the DPP forms stay.  The exchanges that go through the crossbar anyway (lane^16, lane^31) take ds_swizzle instead of
+// ds_bpermute (no address register): 43.1 ms.
+#ifndef RO_SWIZZLE_MASK
+#define RO_SWIZZLE_MASK ((1u << 16) | (1u << 31) | (RO_SWIZZLE_XOR4 ? (1u << 4) : 0u))
+#endif
 template <int M>
 __device__ __forceinline__ unsigned xor_lane(int addr, unsigned x) {
     const int v = (int)x;
-    if constexpr (M == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    if constexpr (M < 32 && ((RO_SWIZZLE_MASK >> M) & 1u))
+        return __builtin_amdgcn_ds_swizzle(v, (M << 10) | 0x1F);  // bit mode: and 0x1f, or 0, xor M (inside each half of the wavefront)
+    else if constexpr (M == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
     else if constexpr (M == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
     else if constexpr (M == 3) return __builtin_amdgcn_mov_dpp(v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
     else if constexpr (M == 7) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror
     else if constexpr (M == 15) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); // row_mirror
     else if constexpr (M == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
-    else if constexpr (M == 4) {
-        // no single DPP pattern: 7 ^ 3 as two moves.  One ds_swizzle (bit mode: and 0x1f, or 0, xor 4) on the LDS crossbar
-        // instead saves 48 vector instructions per problem but was measured slower on the same box (2.06-2.10 vs
-        // 2.015 ms per 1.01 M problems): the exchange steps wait for the crossbar's latency
-        if (RO_SWIZZLE_XOR4) return __builtin_amdgcn_ds_swizzle(v, 0x101F);
+    else if constexpr (M == 4)   // no single DPP pattern: 7 ^ 3 as two moves
         return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
-    }
     else return __builtin_amdgcn_ds_bpermute(addr, v);
 }
 
@@ -200,6 +209,28 @@ template <int M, bool MIRROR>
 __device__ __forceinline__ void cross_step(Keys& v, int lane, const Lane& ln) {
     constexpr int TOP = MIRROR ? (M + 1) / 2 : M;
     constexpr int T = TOP == 1 ? 0 : TOP == 2 ? 1 : TOP == 4 ? 2 : TOP == 8 ? 3 : TOP == 16 ? 4 : 5;
+#if RO_DPP_MINMAX4
+    if constexpr (M == 4 && !MIRROR) {
+        // lane^4 has no single DPP pattern, but its two halves have: the lanes with bit 2 clear sit in the DPP banks 0 and 2
+        // and find their partner four lanes up (row_shl:4), the others in banks 1 and 3 four lanes down (row_shr:4).  The
+        // min / max themselves take the DPP operand, each writing only its banks: two instructions per slot, no med3.
+        // (s_nop: a DPP operand must not be read within two cycles of the instruction that wrote it)
+        Keys n;
+        asm volatile("s_nop 1\n\t"
+                     "v_min_u32_dpp %0, %8, %8 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %0, %8, %8 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %1, %9, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %1, %9, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %2, %10, %10 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %2, %10, %10 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %3, %11, %11 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %3, %11, %11 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %4, %12, %12 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %4, %12, %12 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %5, %13, %13 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %5, %13, %13 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %6, %14, %14 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %6, %14, %14 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                     "v_min_u32_dpp %7, %15, %15 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_max_u32_dpp %7, %15, %15 row_shr:4 row_mask:0xf bank_mask:0xa"
+                     : "=&v"(n.k[0]), "=&v"(n.k[1]), "=&v"(n.k[2]), "=&v"(n.k[3]), "=&v"(n.k[4]), "=&v"(n.k[5]), "=&v"(n.k[6]), "=&v"(n.k[7])
+                     : "v"(v.k[0]), "v"(v.k[1]), "v"(v.k[2]), "v"(v.k[3]), "v"(v.k[4]), "v"(v.k[5]), "v"(v.k[6]), "v"(v.k[7]));
+        v = n;
+        return;
+    }
+#endif
     const int addr = (lane ^ M) << 2;
     unsigned c;
     if constexpr (T < 3) c = ln.c[T];
