@@ -223,6 +223,50 @@ def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
             np.testing.assert_array_equal(got[k], z[k], err_msg="%s vs %s" % (k, kind))
 
 
+def test_random_overlap_every_crossing_index_vs_oracle(hip, port):
+    """two ascending curves that cross exactly once, behind Gauss point yx - 1, for every yx = 1 ... 19, with either curve
+    the stronger one at y = 0, over a narrow range (key shift < 32 bits) and over 14 decades (shift >= 32 bits), and curves
+    that cross several times (the LAST crossing decides the fill order, kernels.cu:3321-3329): all four fill variants of
+    the run layout against the oracle's adjacent-swap sort; plus tableaux whose rows just touch (presorted or not by one
+    ulp)"""
+    from helios_amd import phys_const as pc
+    from helios_amd import synthetic as syn
+    ny = 20
+    gy, gw = syn.gauss_points(ny)
+    rng = np.random.default_rng(77)
+    rows = []
+    for decades in (1.5, 14.0):
+        for yx in range(1, ny):
+            for first in (0, 1):
+                a = np.sort(10.0 ** rng.uniform(-3.0, -3.0 + decades, ny))
+                # b below a before yx, above it from yx on (or the other way round)
+                b = np.where(np.arange(ny) < yx, a * rng.uniform(0.55, 0.95, ny), a * rng.uniform(1.05, 1.8, ny))
+                b = np.maximum.accumulate(b)
+                rows.append((a, b) if first else (b, a))
+        for _ in range(24):          # several crossings
+            a = np.sort(10.0 ** rng.uniform(-3.0, -3.0 + decades, ny))
+            b = np.maximum.accumulate(a * np.where(rng.uniform(size=ny) < 0.5, 0.8, 1.25))
+            rows.append((a, b))
+    # rows that touch: outer[i] + inner[19] == outer[i + 1] + inner[0] exactly, and one ulp above
+    inner = np.linspace(1.0, 2.0, ny)
+    outer = 4.0 + np.arange(ny) * 1.0
+    rows.append((outer, inner))
+    rows.append((outer, inner * (1.0 + np.where(np.arange(ny) == ny - 1, 2.3e-16, 0.0))))
+    rows.append((outer * 64.0, inner))       # far apart: presorted
+    nbin, nlev = len(rows), 1
+    mix0 = np.array([r[0] for r in rows])
+    spec = np.array([r[1] for r in rows]) / (1e-3 * 18.0 / 2.3)       # add = vmr * mass / mu * spec
+    out = []
+    for impl in (hip, port):
+        mix = np.ascontiguousarray(mix0.reshape(-1)).copy()
+        impl.add_to_mixed_opac(np.full(nlev, 1e-3), np.ascontiguousarray(spec.reshape(-1)), mix, np.full(nlev, 2.3 * pc.AMU),
+                               gw, gy, 18.0 * pc.AMU, 1, 1, ny, nbin, nlev)
+        out.append(mix.reshape(nbin, ny))
+    assert np.all(np.isfinite(out[0])) and np.abs(out[1] - mix0).max() > 0
+    for k in range(nbin):
+        np.testing.assert_allclose(out[0][k], out[1][k], rtol=2e-11, err_msg="problem %d" % k)
+
+
 def test_diagnostics_record(hip, port):
     """what the reference's kernels report through device printf is counted in the context's hx_diag record:
     energy-budget factor (kernels.cu:455), negative fluxes and limited G functions under debug = 1 (:1458, :227),
