@@ -36,6 +36,8 @@ WORKLOADS = {
     # name: (nbin, nlayer, ny, ntemp, npress)
     "c2": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20,
                desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
+    "c2beam": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, dir_beam=1, albedo=0.1,
+                   desc="config 2's shape with the direct beam and a reflecting surface (five coefficient planes)"),
     "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20,
                desc="BASELINE config 1 shape: 300 bins x 50 layers, premixed"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,

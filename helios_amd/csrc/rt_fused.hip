@@ -82,7 +82,12 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
             if (rows > 16) continue;
             if (force_k && k != force_k) continue;
             if (pass == 0 && flux_variant_spills(rows, k)) continue;
-            const int cost = k * rows * (k >= 16 ? 100 : 125);
+            int cost = k * rows * (k >= 16 ? 100 : 125);
+            // With the direct beam a tile has two more planes.  All seven register images (alpha, beta, u', v', U, dd, du)
+            // are in flight at once only while rows <= 10; beyond that the beam planes are a second, dependent request
+            // per tile (256 VGPRs).  Same-box A/B, k_rt_flux per launch: 10 000 x 100 with beam 0.617 ms (k = 16, 13 rows)
+            // -> 0.493 ms (k = 32, 7 rows); 30 000 x 200 with beam and I2S 3.92 ms (k = 32, 13 rows) -> 3.23 ms (k = 64, 7).
+            if (dir_beam && rows > 10) cost += cost * 3 / 10;
             if (cost < best_cost) {
                 best_cost = cost;
                 best_k = k;
@@ -1378,11 +1383,11 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
     return 0;
 }
 
-int hx_rt_flux_geometry(int nlayer, int iso, int ny, int nbin, int ncol, int* out_lanes, int* out_rows) {
+int hx_rt_flux_geometry(int nlayer, int iso, int dir_beam, int ny, int nbin, int ncol, int* out_lanes, int* out_rows) {
     TileGeom g;
     memset(&g, 0, sizeof(g));
     if (nlayer < 1 || ny < 1 || nbin < 1 || ncol < 1 || !out_lanes || !out_rows) return HX_E_ARG;
-    if (!choose_geometry(iso ? nlayer : 2 * nlayer, ny, nbin, ncol, 0, 0, g)) return HX_E_ARG;
+    if (!choose_geometry(iso ? nlayer : 2 * nlayer, ny, nbin, ncol, dir_beam, 0, g)) return HX_E_ARG;
     *out_lanes = g.k;
     *out_rows = g.ROWS;
     return 0;

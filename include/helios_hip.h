@@ -411,8 +411,9 @@ int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t
 int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr);
 /* the tiling hx_rt_create would choose for the flux kernel -- lanes per spectral point and half-layer rows per lane, i.e.
  * the instantiation k_rt_flux<rows, lanes> -- for a batch of `ncol` columns of `nlayer` layers (`iso`: one segment per
- * layer).  Host only, no device needed: tests hold the choice to the code objects' register notes. */
-int hx_rt_flux_geometry(int nlayer, int iso, int ny, int nbin, int ncol, int* out_lanes, int* out_rows);
+ * layer; `dir_beam`: the direct beam adds two planes per tile and favours fewer rows per lane).  Host only, no device
+ * needed: tests hold the choice to the code objects' register notes. */
+int hx_rt_flux_geometry(int nlayer, int iso, int dir_beam, int ny, int nbin, int ncol, int* out_lanes, int* out_rows);
 /* algorithmic / actual HBM byte counts of the last refresh and step (for the roofline report) */
 int hx_rt_traffic_model(hx_rt* rt, double* step_bytes_algorithmic, double* step_bytes_actual,
                         double* refresh_bytes_algorithmic, double* refresh_bytes_actual);

@@ -113,9 +113,12 @@ def test_no_selected_flux_kernel_keeps_registers_in_scratch():
     seen = set()
     k, r = ctypes.c_int(), ctypes.c_int()
     for iso, top in ((0, 416), (1, 512)):
-        for L in range(1, top + 1):
-            assert lib.hx_rt_flux_geometry(L, iso, 20, 10000, 1, ctypes.byref(k), ctypes.byref(r)) == 0
-            seen.add((r.value, k.value if k.value >= 16 else 0))
+        for beam in (0, 1):
+            for L in range(1, top + 1):
+                assert lib.hx_rt_flux_geometry(L, iso, beam, 20, 10000, 1, ctypes.byref(k), ctypes.byref(r)) == 0
+                seen.add((r.value, k.value if k.value >= 16 else 0))
+                if beam and (2 - iso) * L <= 640:      # with the beam: at most 10 rows per lane wherever 64 lanes allow it
+                    assert r.value <= 10, (L, iso, k.value, r.value)
     for rows, K in sorted(seen):
         n = [v for name, v in flux.items() if "k_rt_flux<%d, %d>" % (rows, K) in name]
         assert len(n) == 1, (rows, K)
