@@ -376,7 +376,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     if (const char* e = getenv("HELIOS_RT_CLOUD_LDS")) rt->cloud_lds = atoi(e) != 0;  // 0: k_rt_coef's fallback path (tests)
     // tiles per workgroup of k_rt_coef: 16 spectral points staged side by side (128-byte runs of the k-table) -- 4 tiles
     // at k = 16, 8 at k = 32 (config 5, same box: 2 tiles 6.4 ms, 4 tiles 4.5 ms, 8 tiles 3.4 ms per refresh)
-    rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));
+    rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));    // (16 tiles per workgroup at k = 64: measured, no faster)
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
@@ -788,7 +788,7 @@ int hx_rt_refresh(hx_rt* rt) {
                                            rt->z_lay, rt->colpar, rt->done, C, rt->f.dir_beam,
                                            rt->f.geom_zenith_corr, I, X, Y);
         if (rc) return rc;
-        k_rt_fdir_band<<<dim3(hx_cdiv(X, 256), I, C), 256, 0, ctx->stream>>>(rt->F_dir_wg, rt->F_dir_band_n,
+        k_rt_fdir_band<<<dim3(hx_cdiv(X, 32), hx_cdiv(I, 32), C), 256, 0, ctx->stream>>>(rt->F_dir_wg, rt->F_dir_band_n,
                                                                            rt->gauss_w, X, Y, I, rt->done);
         HX_LAUNCH_CHECK(ctx);
     }
