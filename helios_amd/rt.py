@@ -245,7 +245,8 @@ def batch_from_case(ctx, c, ncol=1, nspecies=0, columns=None):
     per-column parameters given in `columns` (a list of ncol dicts overriding g, a, F_intern, ...)."""
     flags = dict(scat=int(c.scat), dir_beam=int(c.dir_beam), clouds=int(c.clouds),
                  scat_corr=int(c.scat_corr), geom_zenith_corr=int(c.geom_zenith_corr),
-                 smooth=int(c.smooth), real_star=int(c.real_star), planet_type_gas=1,
+                 smooth=int(c.smooth), real_star=int(c.real_star),
+                 planet_type_gas=0 if c.get("planet_type", "gas") == "rocky" else 1,
                  kcoeff_mixing_ro=1, iso=int(c.get("iso", 0)), singlewalk=int(c.get("singlewalk", 0)),
                  epsi=float(c.epsi), epsi2=float(c.epsi2), g_0=float(c.g_0),
                  i2s_transition=float(c.i2s_transition), w_0_limit=float(c.w_0_limit),

@@ -193,7 +193,7 @@ def refresh_transmission(impl, c, s):
             s.scat_trigger, c.g_0, c.epsi, c.epsi2, c.mu_star, c.w_0_limit, c.w_0_scat_limit,
             c.scat, X, Y, L, c.clouds, c.scat_corr, c.i2s_transition)
     impl.calc_delta_z(c.T_lay, c.p_int, s.meanmolmass_lay, s.delta_z_lay, c.g, L)
-    calculate_height_z(c, s)
+    calculate_height_z(c, s, c.get("planet_type", "gas"))
     if c.iso == 1:
         impl.fdir_iso(s.F_dir_wg, s.planckband_lay, s.delta_tau_wg, c.z_lay, c.mu_star, c.R_planet,
                       c.R_star, c.a, c.dir_beam, c.geom_zenith_corr, I, X, Y)

@@ -54,6 +54,25 @@ def test_fused_vs_oracle(ctx, port, name):
         fh.compare(f, o, c0, rtol=rtol)
 
 
+def test_fused_rocky_planet_heights_and_zenith_correction(ctx, port):
+    """planet type "rocky": the layer heights are integrated from the surface instead of the 10-bar level
+    (host_functions.py:673-698), and with the geometric zenith-angle correction they enter the direct beam
+    (kernels.cu:1349) -- the fused refresh (k_rt_height on the device) against the oracle with the host's integration"""
+    c0 = cases.make_case(nbin=11, nlayer=30, dir_beam=1, geom_zenith_corr=1, zenith_deg=82.0, albedo=0.1)
+    c0.planet_type = "rocky"
+    c0.R_planet = 0.1 * c0.R_planet          # a small planet: the correction is strong
+    gas = c0.copy()
+    gas.planet_type = "gas"
+    for n_iter, rtol in ((1, 1e-9), (12, 1e-7)):
+        f, grid = fh.run_fused(ctx, c0, n_iter, with_planck_grid=True)
+        o = fh.run_oracle(port, c0, n_iter, planck_grid=grid)
+        fh.compare(f, o, c0, rtol=rtol)
+    fr, fg = fh.run_fused(ctx, c0, 1), fh.run_fused(ctx, gas, 1)
+    assert fr["z_lay"][0] > 0 and fg["z_lay"][0] < 0           # heights above the surface / around the 10-bar level
+    top = fg["F_dir_band"] > 1e-30 * fg["F_dir_band"].max()
+    assert np.abs(fr["F_dir_band"][top] / fg["F_dir_band"][top] - 1.0).max() > 1e-6       # and the beam sees the difference
+
+
 @pytest.mark.parametrize("name", ["default", "dirbeam", "clouds_g0", "L100", "L50", "L200", "L400", "L200_i2s"])
 def test_fused_vs_oracle_single_wavefront_workgroups(ctx, port, name, monkeypatch):
     """small spectral grids default to 5-wavefront workgroups (all Gauss points of a bin at once); the shape large
