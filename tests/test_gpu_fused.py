@@ -54,6 +54,43 @@ def test_fused_vs_oracle(ctx, port, name):
         fh.compare(f, o, c0, rtol=rtol)
 
 
+@pytest.mark.parametrize("option", ["real_star", "foreplay", "no_atmo", "smooth", "species_correlated_k"])
+def test_fused_run_options_vs_oracle(ctx, port, option):
+    """options of the iteration that the other cases leave at their defaults: a stellar spectrum read from file
+    (`real_star`: planck_interpol_layer takes the star's row from `starflux`, kernels.cu:945-951), temperature steps only
+    from iteration `foreplay` on (computation.py:906), the "no atmosphere" mode of rad_temp_iter (:2739-2745), the
+    temperature smoothing flux (:2656-2670), and on-the-fly absorbers mixed correlated-k throughout
+    (`kcoeff_mixing = correlated-k`, computation.py:1343-1348)"""
+    c0 = cases.make_case(nbin=10, nlayer=14, dir_beam=1, albedo=0.1)
+    refresh = None
+    if option == "real_star":
+        c0.real_star = 1
+        c0.starflux = 3e5 * (1.0 + 0.5 * np.sin(np.arange(c0.nbin)))
+    elif option == "foreplay":
+        c0.foreplay = 5
+    elif option == "no_atmo":
+        c0.no_atmo = 1
+    elif option == "smooth":
+        c0.smooth = 1
+    else:
+        cases.add_species(c0, nspecies=4)
+        c0.kcoeff_mixing = "correlated-k"
+        refresh = lambda i, c, s: cases.refresh_onthefly(i, c, s, ro=0)        # noqa: E731
+    for n_iter, rtol in ((1, 1e-9), (12, 1e-7)):
+        f, grid = fh.run_fused(ctx, c0, n_iter, with_planck_grid=True)
+        oc = c0.copy()
+        if option == "real_star":    # the oracle is handed the device's Planck table; the energy correction of the star's
+            # own spectrum (corr_inc_energy scales `starflux` in place, kernels.cu:434-466) is still its to do
+            port.corr_inc_energy(np.array(grid), oc.starflux, oc.opac_deltawave, 1, oc.nbin, oc.T_star, oc.plancktable_dim)
+            assert np.abs(oc.starflux / c0.starflux - 1.0).min() > 0.1
+        o = fh.run_oracle(port, oc, n_iter, planck_grid=grid, refresh=refresh)
+        fh.compare(f, o, c0, rtol=rtol)
+    if option == "foreplay":         # five iterations without a temperature step
+        np.testing.assert_array_equal(fh.run_fused(ctx, c0, 5)["T_lay"], c0.T_lay)
+    if option == "no_atmo":
+        assert np.all(f["T_lay"][:-1] == 1.001)
+
+
 def test_fused_rocky_planet_heights_and_zenith_correction(ctx, port):
     """planet type "rocky": the layer heights are integrated from the surface instead of the 10-bar level
     (host_functions.py:673-698), and with the geometric zenith-angle correction they enter the direct beam
