@@ -409,8 +409,10 @@ class Compute(object):
 
     def _fused_supported(self, quant):
         # isothermal layers halve the segments per layer: 1024 of them fit the register-resident sweeps
+        # ... and the species loop of the fused refresh holds 48 absorbers (its LDS budget, csrc/rt_species.h)
+        nabs = sum(1 for sp in (getattr(quant, "species_list", None) or []) if getattr(sp, "absorbing", "no") == "yes")
         return (self.use_fused and quant.flux_calc_method == "iteration"
-                and _i(quant.nlayer) <= (1024 if quant.iso == 1 else 512))
+                and _i(quant.nlayer) <= (1024 if quant.iso == 1 else 512) and nabs <= 48)
 
     @staticmethod
     def _rt_flags(q):
