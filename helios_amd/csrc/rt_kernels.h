@@ -521,6 +521,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     const hx_rt_column cp = a.colpar[col];
     double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64;
     const double nmu = -cp.mu_star;
+    const bool plain = a.clouds != 1 && a.scat_corr != 1 && a.g_0 == 0.0 && a.dir_beam != 1;
     for (int r = 0; r < ROWS; r++) {
         const int h = j * ROWS + r;
         double alpha = 1.0, beta = 0.0, up = 0.0, vp = 0.0, dd = 0.0, du = 0.0;
@@ -547,9 +548,11 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             const double mu = sh_mu[h], dcol = sh_dc[h];
             const double w0 = single_scat_albedo(ray + csc, kap * mu + cab, a.w_0_limit);
             const double dtau_gas = dcol * (kap + ray / mu);
-            const double dtau = dtau_gas + dcol * (cab + csc) / mu;
-            const Slab s = slab_coeffs(w0, dtau, g0, a.epsi, a.epsi2, cp.mu_star, a.scat_corr, a.i2s,
-                                       a.dir_beam == 1);
+            // `plain` (wave-uniform): no clouds, no I2S correction, g0 = 0, no beam -- the cloud term is an exact zero and
+            // E (1 - w0 g0) an exact one: the general formulas minus their no-ops, same bits (two_stream.h)
+            const double dtau = plain ? dtau_gas : dtau_gas + dcol * (cab + csc) / mu;
+            const Slab s = plain ? slab_coeffs_plain(w0, dtau, a.epsi)
+                                 : slab_coeffs(w0, dtau, g0, a.epsi, a.epsi2, cp.mu_star, a.scat_corr, a.i2s, a.dir_beam == 1);
             if (a.diag != nullptr && a.dir_beam == 1) {  // G_limiter's warning (kernels.cu:217-231) as a count
                 const int nlim = (fabs(s.Gp) >= 1e8 ? 1 : 0) + (fabs(s.Gm) >= 1e8 ? 1 : 0);
                 if (nlim) atomicAdd(a.diag + HX_DIAG_G_LIMITED, (unsigned long long)nlim);
@@ -562,7 +565,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             if (a.iso || dtau < a.dtau_limit) {  // isothermal source: B (N + M - P) (kernels.cu:1442, :1640-1643)
                 u = v = (s.N + s.M - s.P) / 2.0;
             } else {
-                const double qq = a.epsi / (s.E * (1.0 - w0 * g0)) * (s.P - s.M + s.N) / dtau;
+                const double qq = (plain ? a.epsi : a.epsi / (s.E * (1.0 - w0 * g0))) * (s.P - s.M + s.N) / dtau;
                 u = (s.M + s.N) + qq;
                 v = -s.P - qq;
             }

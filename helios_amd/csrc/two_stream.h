@@ -55,6 +55,26 @@ __device__ __forceinline__ Slab slab_coeffs(double w0, double dtau, double g0, d
     return s;
 }
 
+// slab_coeffs for E = 1 and g0 = 0 (no I2S correction, isotropic scattering, no clouds -- BASELINE config 2), without G+-:
+// the same operations in the same order minus those that are exact no-ops there -- E * omg = 1.0, so both divisions by it
+// return their numerator and the two square roots have the same argument (1 - w0).  Bit-identical to slab_coeffs(w0,
+// dtau, 0.0, ..., scat_corr = 0, need_G = false); saves a square root and a division of the eight per half-layer.
+__device__ __forceinline__ Slab slab_coeffs_plain(double w0, double dtau, double epsi) {
+    Slab s;
+    s.w0 = w0;
+    s.E = 1.0;
+    const double r = sqrt(1.0 - w0);                 // = sqrt(E * omg * (E - w0)) = sqrt((E - w0) / (E * omg))
+    s.trans = exp(-1.0 / epsi * r * dtau);           // :144
+    const double zm = 0.5 * (1.0 - r), zp = 0.5 * (1.0 + r);
+    const double t2 = s.trans * s.trans;
+    s.M = (zm * zm) * t2 - (zp * zp);
+    s.N = zp * zm * (1.0 - t2);
+    s.P = ((zm * zm) - (zp * zp)) * s.trans;
+    s.Gp = 0.0;
+    s.Gm = 0.0;
+    return s;
+}
+
 __device__ __forceinline__ double single_scat_albedo(double scat, double absorb, double limit) {
     return dmin(scat / (scat + absorb), limit);  // :249-256
 }
