@@ -411,7 +411,8 @@ class Compute(object):
         # isothermal layers halve the segments per layer: 1024 of them fit the register-resident sweeps
         # ... and the species loop of the fused refresh holds 48 absorbers (its LDS budget, csrc/rt_species.h)
         nabs = sum(1 for sp in (getattr(quant, "species_list", None) or []) if getattr(sp, "absorbing", "no") == "yes")
-        return (self.use_fused and quant.flux_calc_method == "iteration"
+        # (`flux calculation method = matrix` runs in the same device-resident loop: hx_rt_flags.matrix)
+        return (self.use_fused and quant.flux_calc_method in ("iteration", "matrix")
                 and _i(quant.nlayer) <= (1024 if quant.iso == 1 else 512) and nabs <= 48)
 
     @staticmethod
@@ -420,7 +421,7 @@ class Compute(object):
                     geom_zenith_corr=_i(q.geom_zenith_corr), smooth=_i(q.smooth), real_star=_i(q.real_star),
                     planet_type_gas=1 if q.planet_type == "gas" else 0,
                     kcoeff_mixing_ro=0 if q.kcoeff_mixing == "correlated-k" else 1, iso=_i(q.iso),
-                    singlewalk=_i(q.singlewalk), epsi=_f(q.epsi),
+                    singlewalk=_i(q.singlewalk), matrix=1 if q.flux_calc_method == "matrix" else 0, epsi=_f(q.epsi),
                     epsi2=_f(q.epsi2), g_0=_f(q.g_0), i2s_transition=_f(q.i2s_transition),
                     w_0_limit=_f(q.w_0_limit), w_0_scat_limit=_f(q.w_0_scat_limit),
                     delta_tau_limit=_f(q.delta_tau_limit), debug=_i(q.debug or 0))

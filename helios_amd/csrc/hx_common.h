@@ -70,6 +70,28 @@ extern "C" int hx_internal_fdir_noniso(hx_context* ctx, double* F_dir_wg, double
                                        double mu_star, double R_planet, double R_star, double a,
                                        int dir_beam, int geom_zenith_corr, int ninterface, int nbin,
                                        int ny);
+// the matrix solver of the per-stage path with the fused loop's per-column "done" flag (stage_matrix.hip)
+extern "C" int hx_internal_fband_matrix_iso(
+    hx_context* ctx, const int* skip, double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
+    const double* planckband_lay, const double* w_0, const double* M_term, const double* N_term, const double* P_term,
+    const double* G_plus, const double* G_minus, const double* g_0_tot_lay, double* alpha, double* beta,
+    double* source_term_down, double* source_term_up, double* c_prime, double* d_prime, const int* scat_trigger,
+    const double* trans_wg, const double* surf_albedo, double g_0, int singlewalk, double Rstar, double a,
+    int numinterfaces, int nbin, double f_factor, double mu_star, int ny, double epsi, int dir_beam, int clouds,
+    int scat_corr, int debug, double i2s_transition);
+extern "C" int hx_internal_fband_matrix_noniso(
+    hx_context* ctx, const int* skip, double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg,
+    const double* F_dir_wg, const double* Fc_dir_wg, const double* planckband_lay, const double* planckband_int,
+    const double* w_0_upper, const double* w_0_lower, const double* delta_tau_wg_upper,
+    const double* delta_tau_wg_lower, const double* delta_tau_all_clouds_upper,
+    const double* delta_tau_all_clouds_lower, const double* M_upper, const double* M_lower, const double* N_upper,
+    const double* N_lower, const double* P_upper, const double* P_lower, const double* G_plus_upper,
+    const double* G_plus_lower, const double* G_minus_upper, const double* G_minus_lower, const double* g_0_tot_lay,
+    const double* g_0_tot_int, double* alpha, double* beta, double* source_term_down, double* source_term_up,
+    double* c_prime, double* d_prime, const int* scat_trigger, const double* trans_wg_upper,
+    const double* trans_wg_lower, const double* surf_albedo, double g_0, int singlewalk, double Rstar, double a,
+    int numinterfaces, int nbin, double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit,
+    int dir_beam, int clouds, int scat_corr, int debug, double i2s_transition);
 extern "C" int hx_internal_fdir_noniso_batch(hx_context* ctx, double* F_dir_wg, double* Fc_dir_wg, const double* star,
                                              const double* delta_tau_wg_upper, const double* delta_tau_wg_lower,
                                              const double* z_lay, const hx_rt_column* colpar, const int* done,

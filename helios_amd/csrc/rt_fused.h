@@ -33,6 +33,23 @@ struct Species {
     bool absorbing = false, scattering = false;
 };
 
+// `flux calculation method = matrix` (hx_rt_flags.matrix): the reference's per-half-layer arrays in the reference's
+// layouts, filled by the per-stage kernels of calc_trans_* (every refresh) and read by the per-stage matrix solver
+// (every iteration), both launched from the device-resident loop.  Per column unless noted; with isothermal layers the
+// `_u` members are the reference's single arrays.
+struct MatrixArrays {
+    double *trans_u = nullptr, *trans_l = nullptr, *M_u = nullptr, *M_l = nullptr, *N_u = nullptr, *N_l = nullptr,
+           *P_u = nullptr, *P_l = nullptr, *Gp_u = nullptr, *Gp_l = nullptr, *Gm_u = nullptr, *Gm_l = nullptr,
+           *w0_u = nullptr, *w0_l = nullptr;                                         // ny*nbin*nlayer
+    double *dtc_u = nullptr, *dtc_l = nullptr;                                       // nbin*nlayer (cloud optical depths)
+    double* dcol_iso = nullptr;                                                      // nlayer (delta_colmass, isothermal layers)
+    int* trigger = nullptr;                                                          // ny*nbin
+    double *F_down = nullptr, *F_up = nullptr, *Fc_down = nullptr, *Fc_up = nullptr;  // ny*nbin*ninterface
+    double *pb_lay = nullptr, *pb_int = nullptr;                                     // nbin*(nlayer+2), nbin*ninterface
+    // work arrays of the elimination, shared by the columns (solved one after the other on one stream)
+    double *alpha = nullptr, *beta = nullptr, *s_down = nullptr, *s_up = nullptr, *c_prime = nullptr, *d_prime = nullptr;
+};
+
 struct ProfileEntry {
     std::string name;
     hipEvent_t e0, e1;
@@ -111,6 +128,9 @@ struct hx_rt {
     int entr_ntemp = 0, entr_npress = 0;
     double* add_heat_dens = nullptr;   // L: additional heating density [erg cm^-3 s^-1]; flux = density * layer height
     bool has_heating = false;
+
+    bool matrix = false;           // hx_rt_flags.matrix
+    hx::MatrixArrays mx;
 
     // profiling
     bool profiling = false;

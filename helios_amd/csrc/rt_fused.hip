@@ -411,14 +411,32 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
         RT_ALLOC(rt->sc_spec_lay, X * I); RT_ALLOC(rt->sc_spec_int, X * I);
     }
     RT_ALLOC(rt->delta_z, C * L); RT_ALLOC(rt->z_lay, C * L);
-    if (flags->dir_beam) {
+    rt->matrix = flags->matrix != 0;
+    if (flags->dir_beam || rt->matrix) {   // (the matrix solver reads the beam arrays unconditionally: zeros without a beam)
         RT_ALLOC(rt->dtau_u, C * nc * L); RT_ALLOC(rt->dtau_l, C * nc * L);
         RT_ALLOC(rt->F_dir_wg, C * nc * I); RT_ALLOC(rt->Fc_dir_wg, C * nc * I);
     }
     RT_ALLOC(rt->F_dir_band_n, C * X * I);
     RT_ALLOC(rt->Bn, C * X * (rt->H + 3));
-    RT_ALLOC(rt->coef, C * rt->g.coef_elems_per_col);
-    RT_ALLOC(rt->Utile, C * rt->g.flux_elems_per_col);
+    if (rt->matrix) {
+        // `flux calculation method = matrix`: the reference's per-half-layer arrays instead of the coefficient tiles
+        // and the persistent up-flux state (a direct solve has none)
+        MatrixArrays& m = rt->mx;
+        const size_t wgL = C * nc * L, halves = flags->iso ? 1 : 2;
+        for (double** q : {&m.trans_u, &m.M_u, &m.N_u, &m.P_u, &m.Gp_u, &m.Gm_u, &m.w0_u}) RT_ALLOC(*q, wgL);
+        if (!flags->iso)
+            for (double** q : {&m.trans_l, &m.M_l, &m.N_l, &m.P_l, &m.Gp_l, &m.Gm_l, &m.w0_l}) RT_ALLOC(*q, wgL);
+        RT_ALLOC(m.dtc_u, C * X * L); RT_ALLOC(m.dtc_l, C * X * L); RT_ALLOC(m.dcol_iso, C * L);
+        RT_ALLOC(m.trigger, C * nc);
+        RT_ALLOC(m.F_down, C * nc * I); RT_ALLOC(m.F_up, C * nc * I);
+        RT_ALLOC(m.Fc_down, C * nc * I); RT_ALLOC(m.Fc_up, C * nc * I);
+        RT_ALLOC(m.pb_lay, C * X * (L + 2)); RT_ALLOC(m.pb_int, C * X * I);
+        for (double** q : {&m.alpha, &m.beta, &m.s_down, &m.s_up}) RT_ALLOC(*q, nc * L * halves);
+        RT_ALLOC(m.c_prime, nc * (halves * 2 * I)); RT_ALLOC(m.d_prime, nc * (halves * 2 * I));
+    } else {
+        RT_ALLOC(rt->coef, C * rt->g.coef_elems_per_col);
+        RT_ALLOC(rt->Utile, C * rt->g.flux_elems_per_col);
+    }
     RT_ALLOC(rt->U0, C * nc); RT_ALLOC(rt->boaK, C * nc); RT_ALLOC(rt->Fdir0, C * nc);
     RT_ALLOC(rt->F_down_band_n, C * X * I); RT_ALLOC(rt->F_up_band_n, C * X * I);
     RT_ALLOC(rt->tot_part, C * rt->nchunk * 2 * I);
@@ -540,6 +558,10 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
         rc |= h2d(rt, rt->p_int + c * I, p_int, I * 8);
         rc |= h2d(rt, rt->dcol_u + c * L, du.data(), L * 8);
         rc |= h2d(rt, rt->dcol_l + c * L, dl.data(), L * 8);
+        if (rt->matrix) {  // whole layers (host_functions.py:733), calc_trans_iso's delta_colmass
+            for (size_t i = 0; i < L; i++) du[i] = (p_int[i] - p_int[i + 1]) / g;
+            rc |= h2d(rt, rt->mx.dcol_iso + c * L, du.data(), L * 8);
+        }
         rc |= h2d(rt, rt->T_lay + c * (L + 1), T_lay, (L + 1) * 8);
         if (surf_albedo) rc |= h2d(rt, rt->surf_albedo + c * X, surf_albedo, X * 8);
         if (starflux) rc |= h2d(rt, rt->starflux + c * X, starflux, X * 8);
@@ -715,6 +737,86 @@ static int refresh_species(hx_rt* rt) {
     return 0;
 }
 
+// ---- `flux calculation method = matrix` ------------------------------------------------------------------------------
+// The per-stage kernels of calc_trans_* and fband_matrix_* (the ones the goldens pin), launched column by column from the
+// device-resident loop on the arrays of rt->mx.  A column whose loop has ended recomputes its coefficients from unchanged
+// inputs (same values) and skips the solve (`done`), so its fluxes stay those of its last iteration.
+static int matrix_calc_trans(hx_rt* rt) {
+    ProfScope ps(rt, "matrix_calc_trans");
+    hx_context* ctx = rt->ctx;
+    const hx_rt_flags& f = rt->f;
+    const MatrixArrays& m = rt->mx;
+    const size_t X = rt->X, L = rt->L, I = rt->I, nc = X * rt->Y, wgL = nc * L, wgI = nc * I, bI = X * I, bL = X * L;
+    HX_HIP(ctx, hipMemsetAsync(m.trigger, 0, (size_t)rt->C * nc * sizeof(int), ctx->stream));  // computation.py:368
+    for (size_t c = 0; c < (size_t)rt->C; c++) {
+        const double mu_star = rt->cols[c].mu_star;
+        int rc;
+        if (f.iso)
+            rc = hx_calc_trans_iso(ctx, m.trans_u + c * wgL, rt->dtau_u + c * wgL, m.M_u + c * wgL, m.N_u + c * wgL,
+                                   m.P_u + c * wgL, m.Gp_u + c * wgL, m.Gm_u + c * wgL, m.dcol_iso + c * L,
+                                   rt->opac_wg_lay + c * wgI, rt->mmm_lay + c * I, rt->scat_cross_lay + c * bI,
+                                   rt->cl_abs_lay + c * bI, rt->cl_sc_lay + c * bI, m.dtc_u + c * bL, m.w0_u + c * wgL,
+                                   rt->g0_tot_lay + c * bI, m.trigger + c * nc, f.g_0, f.epsi, f.epsi2, mu_star,
+                                   f.w_0_limit, f.w_0_scat_limit, f.scat, rt->X, rt->Y, rt->L, f.clouds, f.scat_corr, 0,
+                                   f.i2s_transition);
+        else
+            rc = hx_calc_trans_noniso(
+                ctx, m.trans_u + c * wgL, m.trans_l + c * wgL, rt->dtau_u + c * wgL, rt->dtau_l + c * wgL, m.M_u + c * wgL,
+                m.M_l + c * wgL, m.N_u + c * wgL, m.N_l + c * wgL, m.P_u + c * wgL, m.P_l + c * wgL, m.Gp_u + c * wgL,
+                m.Gp_l + c * wgL, m.Gm_u + c * wgL, m.Gm_l + c * wgL, rt->dcol_u + c * L, rt->dcol_l + c * L,
+                rt->opac_wg_lay + c * wgI, rt->opac_wg_int + c * wgI, rt->mmm_lay + c * I, rt->mmm_int + c * I,
+                rt->scat_cross_lay + c * bI, rt->scat_cross_int + c * bI, rt->cl_abs_lay + c * bI, rt->cl_abs_int + c * bI,
+                rt->cl_sc_lay + c * bI, rt->cl_sc_int + c * bI, m.dtc_u + c * bL, m.dtc_l + c * bL, m.w0_u + c * wgL,
+                m.w0_l + c * wgL, rt->g0_tot_lay + c * bI, rt->g0_tot_int + c * bI, m.trigger + c * nc, f.g_0, f.epsi,
+                f.epsi2, mu_star, f.w_0_limit, f.w_0_scat_limit, f.scat, rt->X, rt->Y, rt->L, f.clouds, f.scat_corr, 0,
+                f.i2s_transition);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int matrix_solve(hx_rt* rt) {
+    ProfScope ps(rt, "matrix_solve");
+    hx_context* ctx = rt->ctx;
+    const hx_rt_flags& f = rt->f;
+    const MatrixArrays& m = rt->mx;
+    const size_t X = rt->X, L = rt->L, I = rt->I, nc = X * rt->Y, wgL = nc * L, wgI = nc * I, bI = X * I, bL = X * L;
+    {   // the node values in the reference's layouts
+        const long long n = (long long)X * (L + 2 + I);
+        k_rt_matrix_planck<<<dim3(hx_cdiv(n, 256), rt->C), 256, 0, ctx->stream>>>(rt->Bn, m.pb_lay, m.pb_int, rt->X, rt->L,
+                                                                               rt->H, f.iso, rt->done);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    for (size_t c = 0; c < (size_t)rt->C; c++) {
+        const hx_rt_column& cp = rt->cols[c];
+        const double* pbl = m.pb_lay + c * X * (L + 2);
+        int rc;
+        if (f.iso)
+            rc = hx_internal_fband_matrix_iso(
+                ctx, rt->done + c, m.F_down + c * wgI, m.F_up + c * wgI, rt->F_dir_wg + c * wgI, pbl, m.w0_u + c * wgL,
+                m.M_u + c * wgL, m.N_u + c * wgL, m.P_u + c * wgL, m.Gp_u + c * wgL, m.Gm_u + c * wgL,
+                rt->g0_tot_lay + c * bI, m.alpha, m.beta, m.s_down, m.s_up, m.c_prime, m.d_prime, m.trigger + c * nc,
+                m.trans_u + c * wgL, rt->surf_albedo + c * X, f.g_0, f.singlewalk, cp.R_star, cp.a, rt->I, rt->X,
+                cp.f_factor, cp.mu_star, rt->Y, f.epsi, f.dir_beam, f.clouds, f.scat_corr, f.debug, f.i2s_transition);
+        else
+            rc = hx_internal_fband_matrix_noniso(
+                ctx, rt->done + c, m.F_down + c * wgI, m.F_up + c * wgI, m.Fc_down + c * wgI, m.Fc_up + c * wgI,
+                rt->F_dir_wg + c * wgI, rt->Fc_dir_wg + c * wgI, pbl, m.pb_int + c * bI, m.w0_u + c * wgL, m.w0_l + c * wgL,
+                rt->dtau_u + c * wgL, rt->dtau_l + c * wgL, m.dtc_u + c * bL, m.dtc_l + c * bL, m.M_u + c * wgL,
+                m.M_l + c * wgL, m.N_u + c * wgL, m.N_l + c * wgL, m.P_u + c * wgL, m.P_l + c * wgL, m.Gp_u + c * wgL,
+                m.Gp_l + c * wgL, m.Gm_u + c * wgL, m.Gm_l + c * wgL, rt->g0_tot_lay + c * bI, rt->g0_tot_int + c * bI,
+                m.alpha, m.beta, m.s_down, m.s_up, m.c_prime, m.d_prime, m.trigger + c * nc, m.trans_u + c * wgL,
+                m.trans_l + c * wgL, rt->surf_albedo + c * X, f.g_0, f.singlewalk, cp.R_star, cp.a, rt->I, rt->X,
+                cp.f_factor, cp.mu_star, rt->Y, f.epsi, f.delta_tau_limit, f.dir_beam, f.clouds, f.scat_corr, f.debug,
+                f.i2s_transition);
+        if (rc) return rc;
+    }
+    k_rt_matrix_bands<<<dim3(hx_cdiv(rt->X, 64), rt->I, rt->C), 64, 0, ctx->stream>>>(
+        m.F_down, m.F_up, rt->F_down_band_n, rt->F_up_band_n, rt->gauss_w, rt->X, rt->Y, rt->I, rt->done);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 int hx_rt_refresh(hx_rt* rt) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     hx_context* ctx = rt->ctx;
@@ -745,7 +847,7 @@ int hx_rt_refresh(hx_rt* rt) {
     // inside the kernels and keeps the state of its last real refresh.  No host round trip.
     // premixed table without the beam: the k-table look-up is fused into k_rt_coef (the beam needs the
     // materialised opacities for its optical depths); HELIOS_RT_FUSED_LOOKUP=0 switches it off
-    bool fused_lookup = rt->d.nspecies == 0 && !rt->f.dir_beam;
+    bool fused_lookup = rt->d.nspecies == 0 && !rt->f.dir_beam && !rt->matrix;
     if (const char* e = getenv("HELIOS_RT_FUSED_LOOKUP")) fused_lookup = fused_lookup && atoi(e) != 0;
     rt->opac_stale = fused_lookup;
     if (rt->d.nspecies == 0) {
@@ -780,10 +882,16 @@ int hx_rt_refresh(hx_rt* rt) {
                                                 rt->F_add_heat_sum, L, rt->done);
         HX_LAUNCH_CHECK(ctx);
     }
+    if (rt->matrix) {
+        rc = matrix_calc_trans(rt);
+        if (rc) return rc;
+    }
     if (rt->f.dir_beam) {
         ProfScope ps(rt, "direct_beam");
-        k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, C), 256, 0, ctx->stream>>>(a);
-        HX_LAUNCH_CHECK(ctx);
+        if (!rt->matrix) {  // (calc_trans_* has just written the same optical depths)
+            k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, C), 256, 0, ctx->stream>>>(a);
+            HX_LAUNCH_CHECK(ctx);
+        }
         rc = hx_internal_fdir_noniso_batch(ctx, rt->F_dir_wg, rt->f.iso ? nullptr : rt->Fc_dir_wg, rt->Bstar, rt->dtau_u, rt->dtau_l,
                                            rt->z_lay, rt->colpar, rt->done, C, rt->f.dir_beam,
                                            rt->f.geom_zenith_corr, I, X, Y);
@@ -792,7 +900,7 @@ int hx_rt_refresh(hx_rt* rt) {
                                                                            rt->gauss_w, X, Y, I, rt->done);
         HX_LAUNCH_CHECK(ctx);
     }
-    {
+    if (!rt->matrix) {
         ProfScope ps(rt, "rt_coef");
         k_rt_half_bands<<<dim3(hx_cdiv(X, 32), hx_cdiv(rt->H, 32), C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
@@ -815,6 +923,17 @@ static int count_negative_fluxes(hx_rt* rt) {
     return rc;
 }
 
+// the spectral fluxes of one iteration: the register-resident sweeps, or one tridiagonal solve per spectral point
+static int spectral_fluxes(hx_rt* rt, const KArgs& a) {
+    if (rt->matrix) return matrix_solve(rt);
+    {
+        ProfScope ps(rt, "rt_flux");
+        DISPATCH_ROWS(launch_flux, rt, a);
+        HX_LAUNCH_CHECK(rt->ctx);
+    }
+    return rt->f.debug == 1 ? count_negative_fluxes(rt) : 0;
+}
+
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
     hx_context* ctx = rt->ctx;
     KArgs a = make_args(rt);
@@ -825,12 +944,7 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         HX_LAUNCH_CHECK(ctx);
     }
     {
-        ProfScope ps(rt, "rt_flux");
-        DISPATCH_ROWS(launch_flux, rt, a);
-        HX_LAUNCH_CHECK(ctx);
-    }
-    if (rt->f.debug == 1) {
-        int rc = count_negative_fluxes(rt);
+        int rc = spectral_fluxes(rt, a);
         if (rc) return rc;
     }
     {
@@ -1020,12 +1134,7 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
         HX_LAUNCH_CHECK(ctx);
     }
     {
-        ProfScope ps(rt, "rt_flux");
-        DISPATCH_ROWS(launch_flux, rt, a);
-        HX_LAUNCH_CHECK(ctx);
-    }
-    if (rt->f.debug == 1) {
-        int rc = count_negative_fluxes(rt);
+        int rc = spectral_fluxes(rt, a);
         if (rc) return rc;
     }
     {
@@ -1240,6 +1349,16 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
             }
         }
         return 0;
+    }
+    if (rt->matrix && (n == "F_up_wg" || n == "F_down_wg" || n == "Fc_up_wg" || n == "Fc_down_wg")) {
+        // the solver's own arrays, already in the reference's layout (centre fluxes: nlayer slabs, the rest stays zero)
+        const MatrixArrays& m = rt->mx;
+        if (out_bytes != nc * I * 8) return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: wrong buffer size");
+        const bool centre = n[1] == 'c';
+        const double* src = n == "F_up_wg" ? m.F_up : n == "F_down_wg" ? m.F_down : n == "Fc_up_wg" ? m.Fc_up : m.Fc_down;
+        memset(out, 0, out_bytes);
+        if (centre && rt->f.iso) return 0;
+        return hx_d2h(rt->ctx, out, src + c * nc * I, nc * (centre ? L : I) * 8);
     }
     if (n == "F_up_wg") return get_flux_wg(rt, col, rt->Utile, rt->U0, true, true, out, out_bytes);
     if (n == "Fc_up_wg") return get_flux_wg(rt, col, rt->Utile, nullptr, true, false, out, out_bytes);

@@ -863,6 +863,48 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     }
 }
 
+// ---- `flux calculation method = matrix`: glue between the node arrays of the loop and the per-stage solver -------------
+// Planck values of the nodes, Bn[x][H+3], in the reference's layouts: planckband_lay[i + x (L+2)] (layers, then the stellar
+// row and the surface) and planckband_int[i + x I].  grid (chunks, C).
+__global__ void __launch_bounds__(256) k_rt_matrix_planck(const double* __restrict__ Bn, double* __restrict__ pb_lay,
+                                                          double* __restrict__ pb_int, int X, int L, int H, int iso,
+                                                          const int* __restrict__ done) {
+    const int col = blockIdx.y;
+    if (done[col]) return;
+    const int NN = H + 3, I = L + 1, per = L + 2 + I;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)X * per) return;
+    const int x = (int)(t / per), s = (int)(t - (long long)x * per);
+    const double* B = Bn + ((size_t)col * X + x) * NN;
+    if (s < L + 2) {
+        const int n = s < L ? (iso ? s : 2 * s + 1) : H + 1 + (s - L);
+        pb_lay[((size_t)col * X + x) * (L + 2) + s] = B[n];
+    } else {  // isothermal layers: the reference computes no interface values (computation.py:315-329)
+        const int i = s - (L + 2);
+        pb_int[((size_t)col * X + x) * I + i] = iso ? 0.0 : B[2 * i];
+    }
+}
+
+// Gauss quadrature of the solver's interface fluxes (kernels.cu:2474-2476) into the band arrays of the loop, [x][i].
+// grid (ceil(X / 64), I, C)
+__global__ void __launch_bounds__(64) k_rt_matrix_bands(const double* __restrict__ F_down_wg, const double* __restrict__ F_up_wg,
+                                                        double* __restrict__ F_down_band_n, double* __restrict__ F_up_band_n,
+                                                        const double* __restrict__ gauss_w, int X, int Y, int I,
+                                                        const int* __restrict__ done) {
+    const int col = blockIdx.z, i = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (done[col] || x >= X) return;
+    const size_t nc = (size_t)X * Y, base = (size_t)col * nc * I + nc * i + (size_t)Y * x;
+    double d = 0.0, u = 0.0;
+    for (int y = 0; y < Y; y++) {
+        const double w = 0.5 * gauss_w[y];
+        u += w * F_up_wg[base + y];
+        d += w * F_down_wg[base + y];
+    }
+    const size_t b = ((size_t)col * X + x) * I + i;
+    F_up_band_n[b] = u;
+    F_down_band_n[b] = d;
+}
+
 // ---- per iteration: wavelength totals, level 1 ---------------------------------------------------
 // grid (nchunk, C), 256 threads.  Thread t owns the (dir, i) slots t, t+256, ... (< 2I) and walks the
 // bins of its chunk; consecutive threads read consecutive addresses of the [x][i] band arrays.

@@ -53,10 +53,10 @@ k_fband_matrix_iso(double* __restrict__ F_down, double* __restrict__ F_up,
                    const int* __restrict__ scat_trigger, const double* __restrict__ trans,
                    const double* __restrict__ surf_albedo, double g_0, double Rstar, double a, int ni,
                    int nbin, double f_factor, double mu_star, int ny, double epsi, int dir_beam,
-                   int clouds, int scat_corr, double i2s) {
+                   int clouds, int scat_corr, double i2s, const int* __restrict__ skip) {
     const size_t nc = (size_t)ny * nbin;
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nc) return;
+    if (c >= nc || (skip && *skip)) return;
     const int x = (int)(c / ny), nl = ni - 1;
     const double* B = planckband_lay + (size_t)x * (ni + 1);
     const double A = surf_albedo[x];
@@ -132,10 +132,10 @@ k_fband_matrix_noniso(double* __restrict__ F_down, double* __restrict__ F_up,
                       const int* __restrict__ scat_trigger, const double* __restrict__ surf_albedo,
                       double g_0, double Rstar, double a, int ni, int nbin, double f_factor,
                       double mu_star, int ny, double epsi, double dtau_limit, int dir_beam, int clouds,
-                      int scat_corr, double i2s) {
+                      int scat_corr, double i2s, const int* __restrict__ skip) {
     const size_t nc = (size_t)ny * nbin;
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nc) return;
+    if (c >= nc || (skip && *skip)) return;
     const int x = (int)(c / ny), nl = ni - 1;
     const double* Bl = planckband_lay + (size_t)x * (ni + 1);
     const double* Bi = planckband_int + (size_t)x * ni;
@@ -241,7 +241,8 @@ k_fband_matrix_noniso(double* __restrict__ F_down, double* __restrict__ F_up,
 
 extern "C" {
 
-int hx_fband_matrix_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
+// `skip`: device flag of the fused loop (a column whose loop has ended keeps its fluxes), or null
+int hx_internal_fband_matrix_iso(hx_context* ctx, const int* skip, double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
                         const double* planckband_lay, const double* w_0, const double* M_term,
                         const double* N_term, const double* P_term, const double* G_plus,
                         const double* G_minus, const double* g_0_tot_lay, double* alpha, double* beta,
@@ -256,7 +257,7 @@ int hx_fband_matrix_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, con
         F_down_wg, F_up_wg, F_dir_wg, planckband_lay, w_0, M_term, N_term, P_term, G_plus, G_minus,
         g_0_tot_lay, alpha, beta, source_term_down, source_term_up, c_prime, d_prime, scat_trigger,
         trans_wg, surf_albedo, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
-        dir_beam, clouds, scat_corr, i2s_transition);
+        dir_beam, clouds, scat_corr, i2s_transition, skip);
     HX_LAUNCH_CHECK(ctx);
     if (debug == 1) {  // kernels.cu:1990, :2018 (the solution vector of :2268 lands in these arrays)
         const size_t n = (size_t)ny * nbin * numinterfaces;
@@ -267,8 +268,8 @@ int hx_fband_matrix_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, con
     return 0;
 }
 
-int hx_fband_matrix_noniso(
-    hx_context* ctx, double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg,
+int hx_internal_fband_matrix_noniso(
+    hx_context* ctx, const int* skip, double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg,
     const double* F_dir_wg, const double* Fc_dir_wg, const double* planckband_lay,
     const double* planckband_int, const double* w_0_upper, const double* w_0_lower,
     const double* delta_tau_wg_upper, const double* delta_tau_wg_lower,
@@ -291,7 +292,7 @@ int hx_fband_matrix_noniso(
     k_fband_matrix_noniso<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
         F_down_wg, F_up_wg, Fc_down_wg, Fc_up_wg, F_dir_wg, Fc_dir_wg, planckband_lay, planckband_int,
         q, scat_trigger, surf_albedo, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
-        delta_tau_limit, dir_beam, clouds, scat_corr, i2s_transition);
+        delta_tau_limit, dir_beam, clouds, scat_corr, i2s_transition, skip);
     HX_LAUNCH_CHECK(ctx);
     if (debug == 1) {  // kernels.cu:2268, :2329, :2351, :2397, :2418
         const size_t nc = (size_t)ny * nbin;
@@ -302,6 +303,47 @@ int hx_fband_matrix_noniso(
         if (rc) return rc;
     }
     return 0;
+}
+
+int hx_fband_matrix_iso(hx_context* ctx, double* F_down_wg, double* F_up_wg, const double* F_dir_wg,
+                        const double* planckband_lay, const double* w_0, const double* M_term,
+                        const double* N_term, const double* P_term, const double* G_plus,
+                        const double* G_minus, const double* g_0_tot_lay, double* alpha, double* beta,
+                        double* source_term_down, double* source_term_up, double* c_prime,
+                        double* d_prime, const int* scat_trigger, const double* trans_wg,
+                        const double* surf_albedo, double g_0, int singlewalk, double Rstar, double a,
+                        int numinterfaces, int nbin, double f_factor, double mu_star, int ny,
+                        double epsi, int dir_beam, int clouds, int scat_corr, int debug,
+                        double i2s_transition) {
+    return hx_internal_fband_matrix_iso(ctx, nullptr, F_down_wg, F_up_wg, F_dir_wg, planckband_lay, w_0, M_term, N_term,
+                                        P_term, G_plus, G_minus, g_0_tot_lay, alpha, beta, source_term_down,
+                                        source_term_up, c_prime, d_prime, scat_trigger, trans_wg, surf_albedo, g_0,
+                                        singlewalk, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
+                                        dir_beam, clouds, scat_corr, debug, i2s_transition);
+}
+
+int hx_fband_matrix_noniso(
+    hx_context* ctx, double* F_down_wg, double* F_up_wg, double* Fc_down_wg, double* Fc_up_wg,
+    const double* F_dir_wg, const double* Fc_dir_wg, const double* planckband_lay,
+    const double* planckband_int, const double* w_0_upper, const double* w_0_lower,
+    const double* delta_tau_wg_upper, const double* delta_tau_wg_lower,
+    const double* delta_tau_all_clouds_upper, const double* delta_tau_all_clouds_lower,
+    const double* M_upper, const double* M_lower, const double* N_upper, const double* N_lower,
+    const double* P_upper, const double* P_lower, const double* G_plus_upper,
+    const double* G_plus_lower, const double* G_minus_upper, const double* G_minus_lower,
+    const double* g_0_tot_lay, const double* g_0_tot_int, double* alpha, double* beta,
+    double* source_term_down, double* source_term_up, double* c_prime, double* d_prime,
+    const int* scat_trigger, const double* trans_wg_upper, const double* trans_wg_lower,
+    const double* surf_albedo, double g_0, int singlewalk, double Rstar, double a, int numinterfaces,
+    int nbin, double f_factor, double mu_star, int ny, double epsi, double delta_tau_limit,
+    int dir_beam, int clouds, int scat_corr, int debug, double i2s_transition) {
+    return hx_internal_fband_matrix_noniso(
+        ctx, nullptr, F_down_wg, F_up_wg, Fc_down_wg, Fc_up_wg, F_dir_wg, Fc_dir_wg, planckband_lay, planckband_int,
+        w_0_upper, w_0_lower, delta_tau_wg_upper, delta_tau_wg_lower, delta_tau_all_clouds_upper,
+        delta_tau_all_clouds_lower, M_upper, M_lower, N_upper, N_lower, P_upper, P_lower, G_plus_upper, G_plus_lower,
+        G_minus_upper, G_minus_lower, g_0_tot_lay, g_0_tot_int, alpha, beta, source_term_down, source_term_up, c_prime,
+        d_prime, scat_trigger, trans_wg_upper, trans_wg_lower, surf_albedo, g_0, singlewalk, Rstar, a, numinterfaces,
+        nbin, f_factor, mu_star, ny, epsi, delta_tau_limit, dir_beam, clouds, scat_corr, debug, i2s_transition);
 }
 
 }  // extern "C"

@@ -25,7 +25,7 @@ class RtFlags(ctypes.Structure):
                 ("smooth", ctypes.c_int32), ("real_star", ctypes.c_int32),
                 ("planet_type_gas", ctypes.c_int32), ("kcoeff_mixing_ro", ctypes.c_int32),
                 ("debug", ctypes.c_int32), ("iso", ctypes.c_int32), ("singlewalk", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 4),
+                ("matrix", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
                 ("epsi", ctypes.c_double), ("epsi2", ctypes.c_double), ("g_0", ctypes.c_double),
                 ("i2s_transition", ctypes.c_double), ("w_0_limit", ctypes.c_double),
                 ("w_0_scat_limit", ctypes.c_double), ("delta_tau_limit", ctypes.c_double),
@@ -247,7 +247,8 @@ def batch_from_case(ctx, c, ncol=1, nspecies=0, columns=None):
                  scat_corr=int(c.scat_corr), geom_zenith_corr=int(c.geom_zenith_corr),
                  smooth=int(c.smooth), real_star=int(c.real_star),
                  planet_type_gas=0 if c.get("planet_type", "gas") == "rocky" else 1,
-                 kcoeff_mixing_ro=0 if c.get("kcoeff_mixing", "RO") == "correlated-k" else 1, iso=int(c.get("iso", 0)), singlewalk=int(c.get("singlewalk", 0)),
+                 kcoeff_mixing_ro=0 if c.get("kcoeff_mixing", "RO") == "correlated-k" else 1, iso=int(c.get("iso", 0)),
+                 singlewalk=int(c.get("singlewalk", 0)), matrix=1 if c.get("flux_calc_method", "iteration") == "matrix" else 0,
                  epsi=float(c.epsi), epsi2=float(c.epsi2), g_0=float(c.g_0),
                  i2s_transition=float(c.i2s_transition), w_0_limit=float(c.w_0_limit),
                  w_0_scat_limit=float(c.w_0_scat_limit), delta_tau_limit=float(c.delta_tau_limit))

@@ -326,7 +326,11 @@ typedef struct hx_rt_flags {
     int32_t iso;                  /* 1 = isothermal layers (fband_iso / calc_trans_iso / fdir_iso), read.py:888-935 */
     int32_t singlewalk;           /* 1 = post-processing run type: 1000*scat+1 sweeps, no temperature iteration
                                      (computation.py:531-537) */
-    int32_t reserved[4];
+    int32_t matrix;               /* 1 = `flux calculation method = matrix`: one tridiagonal solve per spectral point and
+                                     iteration (fband_matrix_*, computation.py:625-710) instead of the sweeps.  The batch
+                                     then holds the reference's per-half-layer arrays (calc_trans_*' outputs, ~20 arrays of
+                                     ny*nbin*nlayer doubles per column) in place of the compact coefficient tiles */
+    int32_t reserved[3];
     double epsi, epsi2, g_0, i2s_transition, w_0_limit, w_0_scat_limit, delta_tau_limit;
     double reserved_d[9];
 } hx_rt_flags;

@@ -214,8 +214,12 @@ def interpolate_temperatures_and_planck(impl, c, s):
 
 
 def flux_sweeps(impl, c, s, nsweep=None):
-    """source/computation.py:528-623: 3*scat+1 sweeps"""
+    """source/computation.py:528-623: 3*scat+1 sweeps -- or, with `flux calculation method = matrix`
+    (:882-883, :1088-1089), the tridiagonal solve"""
     X, Y, I = c.nbin, c.ny, c.ninterface
+    if c.get("flux_calc_method", "iteration") == "matrix":
+        s.matrix_work = flux_matrix(impl, c, s, s.get("matrix_work"))
+        return
     if nsweep is None:
         nsweep = 3 * c.scat + 1
     for _ in range(nsweep):

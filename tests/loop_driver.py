@@ -97,9 +97,22 @@ def loop_case(name):
         # BASELINE config 5's ingredients together in one small column: absorbers mixed on the fly with random overlap,
         # two cloud decks, g0 with the I2S correction, direct beam, reflecting surface
         kw.update(nbin=5, clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0)
+    elif name == "matrix":
+        # `flux calculation method = matrix` (computation.py:882-883): one tridiagonal solve per spectral point instead
+        # of the sweeps.  (The reader keeps the surface albedo >= 1e-8 "for matrix method to work", read.py:1261.)
+        kw.update(albedo=0.1)
+    elif name == "matrix_c5physics":
+        kw.update(clouds=1, g_0=0.3, scat_corr=1, dir_beam=1, albedo=0.2, T_star=3500.0)
+    elif name == "matrix_noscat":
+        # no scattering: every spectral point takes the solver's pure-absorption branch (kernels.cu:2286-2421)
+        kw.update(scat=0, albedo=0.1)
+    elif name == "matrix_iso":
+        kw.update(iso=1, albedo=0.1, dir_beam=1)
     else:
         raise KeyError(name)
     c = cases.make_case(**kw)
+    if name.startswith("matrix"):
+        c.flux_calc_method = "matrix"
     if name == "noscat_relax":
         c.rad_convergence_limit = 1e-9
     if name in ("onthefly", "c5physics_onthefly"):
@@ -111,7 +124,8 @@ def loop_refresh(c):
     return cases.refresh_onthefly if c.get("species") else cases.refresh_premixed
 
 
-LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s", "onthefly", "c5physics_onthefly")
+LOOP_NAMES = ("default", "dirbeam_albedo", "noscat_relax", "clouds_g0_i2s", "onthefly", "c5physics_onthefly",
+              "matrix", "matrix_c5physics", "matrix_noscat", "matrix_iso")
 SNAP_AT = (1, 10, 11, 50)
 
 
@@ -229,7 +243,7 @@ def convection_loop(impl, hs, c, s, kappa, snap_at=(), max_nr_iterations=20000, 
     return int(q.iter_value), snaps, q
 
 
-CONV_NAMES = ("deep", "beam_albedo", "clouds_g0_i2s", "surface_jump", "detached", "c5physics_onthefly")
+CONV_NAMES = ("deep", "deep_matrix", "beam_albedo", "clouds_g0_i2s", "surface_jump", "detached", "c5physics_onthefly")
 CONV_SIZE = dict(nbin=6, nlayer=16, ntemp=6, npress=5, plancktable_dim=800, plancktable_step=10)
 # Columns whose convection loop takes a marginal time-step decision (`|T - T_store| < adapt/2 |dT|`, kernels.cu:2869-2876)
 # between iterations 50 and 400: last-bit differences decide it, the trajectories part for a few hundred iterations and
@@ -256,6 +270,8 @@ def conv_case(name):
     limit = 1e-8
     if name in ("deep", "deep_hostref"):
         kw.update(T_intern=250.0)
+    elif name == "deep_matrix":       # both loops with `flux calculation method = matrix`
+        kw.update(T_intern=250.0, albedo=0.1)
     elif name == "surface_jump":
         kw.update(T_intern=450.0)
     elif name == "beam_albedo":
@@ -274,6 +290,8 @@ def conv_case(name):
     if name == "c5physics_onthefly":
         cases.add_species(c, nspecies=4)
     c.rad_convergence_limit = limit
+    if name == "deep_matrix":
+        c.flux_calc_method = "matrix"
     c.c_p_lay = np.full(c.nlayer, pc.R_UNIV / kappa)              # read.py:1178-1180
     if name == "detached":
         p = c.p_lay

@@ -23,7 +23,7 @@ def store_from_case(ctx, c, crit_relaxation_numbers=(), max_nr_iterations=20000,
     q.convection = i32(convection)
     q.opacity_mixing = "premixed"
     q.kcoeff_mixing = "correlated-k"
-    q.flux_calc_method = "iteration"
+    q.flux_calc_method = c.get("flux_calc_method", "iteration")
     q.planet_type = "gas"
     q.name = name
     q.debug = i32(0)

@@ -119,15 +119,16 @@ def test_run_helios_with_convection(tmp_path):
 
 
 def test_run_helios_matrix_method(tmp_path):
-    """`flux calculation method = matrix` (per-stage path): same equilibrium as the iterative sweeps, whose
-    persistent up-flux state converges to the solution of the same linear system"""
+    """`flux calculation method = matrix` through run_helios (the device-resident loop with hx_rt_flags.matrix): same
+    equilibrium as the iterative sweeps, whose persistent up-flux state converges to the solution of the same linear
+    system"""
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
             "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "mat",
             "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-4",
             "-convective_adjustment", "no", "-surface_albedo", "0.1"]
     a = _run_driver(argv + ["-flux_calculation_method", "matrix"], True)
     b = _run_driver(argv, True)
-    assert np.all(np.isfinite(a.T_lay)) and int(a.iter_value) > 3
+    assert np.all(np.isfinite(a.T_lay)) and int(a.iter_value) > 3 and a.rt is not None
     # both stop at the same flux criterion from different sides; the thin top layer and the surface are the
     # loosest-constrained temperatures (observed: 0.5 % there, 1e-5 in the bulk)
     np.testing.assert_allclose(a.T_lay, b.T_lay, rtol=1e-2)

@@ -200,17 +200,24 @@ def test_fused_loop_golden(ctx, name):
     gc.check_loop(run, name)
 
 
-@pytest.mark.parametrize("name", [n for n in ld.LOOP_NAMES if "onthefly" not in n])
-def test_compute_radiation_loop_golden(ctx, name, capsys):
+@pytest.mark.parametrize("name,use_fused", [(n, True) for n in ld.LOOP_NAMES if "onthefly" not in n]
+                         + [(n, False) for n in ld.LOOP_NAMES if n.startswith("matrix")])
+def test_compute_radiation_loop_golden(ctx, name, use_fused, capsys):
     """the product's driver, Compute.radiation_loop on a Store, against the reference-kernel loop: iteration
-    count, T-P profile, net flux and TOA emission spectrum"""
+    count, T-P profile, net flux and TOA emission spectrum.  `flux calculation method = matrix`: in the device-resident
+    loop and stage by stage"""
     from helios_amd.computation import Compute
     from store_helpers import store_from_case
     c, z = gc.load_chain(name, prefix="loop_")
     relax = tuple(int(r) for r in z["crit_relaxation_numbers"])
     q = store_from_case(ctx, c, relax)
     comp = Compute(ctx)
+    comp.use_fused = use_fused
+    if not use_fused:                           # the order of run_helios (helios.py:82-85)
+        comp.construct_planck_table(q)
+        comp.correct_incident_energy(q)
     comp.radiation_loop(q)
+    assert (q.rt is not None) == use_fused
     assert int(q.iter_value) == int(z["iter_count"])
     X, I = c.nbin, c.ninterface
     np.testing.assert_allclose(q.dev_T_lay.get(), z["end.T_lay"], rtol=1e-6)
@@ -353,7 +360,12 @@ def test_fused_convection_loop_golden(ctx, name):
                 assert it < 20000
         finally:
             rt.close()
-    gc.check_loopconv(run, name)
+    # `deep_matrix`: the tridiagonal solve amplifies the last-bit differences it is fed about a hundred times more than
+    # the sweeps do (measured against the fixture: 3e-8 after 10 iterations, 1.3e-6 after 50 -- the surface still moves by
+    # 20 K per iteration there -- and < 1e-8 again after 400 and at the end; `deep`, the same column with the sweeps: 1e-8
+    # after 50), so its transient snapshots get 5e-6; counts and layer flags stay exact
+    tol = 5e-6 if "matrix" in name else 1e-6
+    gc.check_loopconv(run, name, rtol_T=tol, rtol_flux=tol)
 
 
 @pytest.mark.parametrize("use_fused", [True, False])
