@@ -47,7 +47,8 @@ struct MatrixArrays {
     double *F_down = nullptr, *F_up = nullptr, *Fc_down = nullptr, *Fc_up = nullptr;  // ny*nbin*ninterface
     double *pb_lay = nullptr, *pb_int = nullptr;                                     // nbin*(nlayer+2), nbin*ninterface
     // work arrays of the elimination, shared by the columns (solved one after the other on one stream)
-    double *alpha = nullptr, *beta = nullptr, *s_down = nullptr, *s_up = nullptr, *c_prime = nullptr, *d_prime = nullptr;
+    // (alpha, beta and the source terms, which nothing reads after the elimination, are not materialised here)
+    double *c_prime = nullptr, *d_prime = nullptr;
 };
 
 struct ProfileEntry {

@@ -431,7 +431,6 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
         RT_ALLOC(m.F_down, C * nc * I); RT_ALLOC(m.F_up, C * nc * I);
         RT_ALLOC(m.Fc_down, C * nc * I); RT_ALLOC(m.Fc_up, C * nc * I);
         RT_ALLOC(m.pb_lay, C * X * (L + 2)); RT_ALLOC(m.pb_int, C * X * I);
-        for (double** q : {&m.alpha, &m.beta, &m.s_down, &m.s_up}) RT_ALLOC(*q, nc * L * halves);
         RT_ALLOC(m.c_prime, nc * (halves * 2 * I)); RT_ALLOC(m.d_prime, nc * (halves * 2 * I));
     } else {
         RT_ALLOC(rt->coef, C * rt->g.coef_elems_per_col);
@@ -795,7 +794,7 @@ static int matrix_solve(hx_rt* rt) {
             rc = hx_internal_fband_matrix_iso(
                 ctx, rt->done + c, m.F_down + c * wgI, m.F_up + c * wgI, rt->F_dir_wg + c * wgI, pbl, m.w0_u + c * wgL,
                 m.M_u + c * wgL, m.N_u + c * wgL, m.P_u + c * wgL, m.Gp_u + c * wgL, m.Gm_u + c * wgL,
-                rt->g0_tot_lay + c * bI, m.alpha, m.beta, m.s_down, m.s_up, m.c_prime, m.d_prime, m.trigger + c * nc,
+                rt->g0_tot_lay + c * bI, nullptr, nullptr, nullptr, nullptr, m.c_prime, m.d_prime, m.trigger + c * nc,
                 m.trans_u + c * wgL, rt->surf_albedo + c * X, f.g_0, f.singlewalk, cp.R_star, cp.a, rt->I, rt->X,
                 cp.f_factor, cp.mu_star, rt->Y, f.epsi, f.dir_beam, f.clouds, f.scat_corr, f.debug, f.i2s_transition);
         else
@@ -805,13 +804,13 @@ static int matrix_solve(hx_rt* rt) {
                 rt->dtau_u + c * wgL, rt->dtau_l + c * wgL, m.dtc_u + c * bL, m.dtc_l + c * bL, m.M_u + c * wgL,
                 m.M_l + c * wgL, m.N_u + c * wgL, m.N_l + c * wgL, m.P_u + c * wgL, m.P_l + c * wgL, m.Gp_u + c * wgL,
                 m.Gp_l + c * wgL, m.Gm_u + c * wgL, m.Gm_l + c * wgL, rt->g0_tot_lay + c * bI, rt->g0_tot_int + c * bI,
-                m.alpha, m.beta, m.s_down, m.s_up, m.c_prime, m.d_prime, m.trigger + c * nc, m.trans_u + c * wgL,
+                nullptr, nullptr, nullptr, nullptr, m.c_prime, m.d_prime, m.trigger + c * nc, m.trans_u + c * wgL,
                 m.trans_l + c * wgL, rt->surf_albedo + c * X, f.g_0, f.singlewalk, cp.R_star, cp.a, rt->I, rt->X,
                 cp.f_factor, cp.mu_star, rt->Y, f.epsi, f.delta_tau_limit, f.dir_beam, f.clouds, f.scat_corr, f.debug,
                 f.i2s_transition);
         if (rc) return rc;
     }
-    k_rt_matrix_bands<<<dim3(hx_cdiv(rt->X, 64), rt->I, rt->C), 64, 0, ctx->stream>>>(
+    k_rt_matrix_bands<<<dim3(hx_cdiv(rt->X, QUAD_BINS), rt->I, rt->C), 256, 2 * QUAD_BINS * (rt->Y + 1) * sizeof(double), ctx->stream>>>(
         m.F_down, m.F_up, rt->F_down_band_n, rt->F_up_band_n, rt->gauss_w, rt->X, rt->Y, rt->I, rt->done);
     HX_LAUNCH_CHECK(ctx);
     return 0;

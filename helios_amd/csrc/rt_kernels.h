@@ -886,23 +886,39 @@ __global__ void __launch_bounds__(256) k_rt_matrix_planck(const double* __restri
 }
 
 // Gauss quadrature of the solver's interface fluxes (kernels.cu:2474-2476) into the band arrays of the loop, [x][i].
-// grid (ceil(X / 64), I, C)
-__global__ void __launch_bounds__(64) k_rt_matrix_bands(const double* __restrict__ F_down_wg, const double* __restrict__ F_up_wg,
-                                                        double* __restrict__ F_down_band_n, double* __restrict__ F_up_band_n,
-                                                        const double* __restrict__ gauss_w, int X, int Y, int I,
-                                                        const int* __restrict__ done) {
-    const int col = blockIdx.z, i = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (done[col] || x >= X) return;
-    const size_t nc = (size_t)X * Y, base = (size_t)col * nc * I + nc * i + (size_t)Y * x;
-    double d = 0.0, u = 0.0;
-    for (int y = 0; y < Y; y++) {
+// grid (ceil(X / QUAD_BINS), I, C), 256 threads: the workgroup reads its bins' ny*QUAD_BINS spectral points of one
+// interface as one contiguous run, weights them into LDS, and one thread per bin adds its Gauss points in order (a thread
+// per bin reading its own ny values took 0.65 ms at 10 000 x 101 x 20: one 64-byte sector per double)
+constexpr int QUAD_BINS = 32;
+__global__ void __launch_bounds__(256) k_rt_matrix_bands(const double* __restrict__ F_down_wg, const double* __restrict__ F_up_wg,
+                                                         double* __restrict__ F_down_band_n, double* __restrict__ F_up_band_n,
+                                                         const double* __restrict__ gauss_w, int X, int Y, int I,
+                                                         const int* __restrict__ done) {
+    extern __shared__ __align__(16) double smem[];
+    const int col = blockIdx.z, i = blockIdx.y, x0 = blockIdx.x * QUAD_BINS;
+    if (done[col]) return;
+    const int nb = min(QUAD_BINS, X - x0), pitch = Y + 1;
+    double* su = smem;
+    double* sd = smem + QUAD_BINS * pitch;
+    const size_t nc = (size_t)X * Y, base = (size_t)col * nc * I + nc * i + (size_t)Y * x0;
+    for (int t = threadIdx.x; t < nb * Y; t += blockDim.x) {
+        const int xl = t / Y, y = t - xl * Y;
         const double w = 0.5 * gauss_w[y];
-        u += w * F_up_wg[base + y];
-        d += w * F_down_wg[base + y];
+        su[xl * pitch + y] = w * F_up_wg[base + t];
+        sd[xl * pitch + y] = w * F_down_wg[base + t];
     }
-    const size_t b = ((size_t)col * X + x) * I + i;
-    F_up_band_n[b] = u;
-    F_down_band_n[b] = d;
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+        const int xl = threadIdx.x;
+        double d = 0.0, u = 0.0;
+        for (int y = 0; y < Y; y++) {
+            u += su[xl * pitch + y];
+            d += sd[xl * pitch + y];
+        }
+        const size_t b = ((size_t)col * X + x0 + xl) * I + i;
+        F_up_band_n[b] = u;
+        F_down_band_n[b] = d;
+    }
 }
 
 // ---- per iteration: wavelength totals, level 1 ---------------------------------------------------

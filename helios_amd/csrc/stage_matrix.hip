@@ -16,31 +16,66 @@ struct Thomas {
     size_t c, nc;
     double sup;  // super-diagonal of the previous row == sub-diagonal of the current one
     int row;
+    double cp, dp;  // c', d' of the previous row (kept in registers: read back from the work arrays they were two
+                    // dependent memory round trips per row)
 
     // row 0 (BOA): -A x0 + x1 = src
     __device__ void first(double albedo, double src) {
         sup = 1.0;
-        c_prime[c] = sup / (-albedo);
-        d_prime[c] = src / (-albedo);
+        cp = sup / (-albedo);
+        dp = src / (-albedo);
+        c_prime[c] = cp;
+        d_prime[c] = dp;
         row = 1;
     }
     __device__ void push(double b, double sup_new, double d) {
-        const size_t k = c + nc * row, km = k - nc;
-        const double den = b - sup * c_prime[km];
-        c_prime[k] = sup_new / den;
-        d_prime[k] = (d - sup * d_prime[km]) / den;
+        const size_t k = c + nc * row;
+        const double den = b - sup * cp;
+        const double cn = sup_new / den, dn = (d - sup * dp) / den;
+        c_prime[k] = cn;
+        d_prime[k] = dn;
+        cp = cn;
+        dp = dn;
         sup = sup_new;
         row++;
     }
     // last row (TOA): sub-diagonal only
     __device__ double last(double src) {
-        const size_t k = c + nc * row, km = k - nc;
-        const double x = (src - sup * d_prime[km]) / (0.0 - sup * c_prime[km]);
+        const size_t k = c + nc * row;
+        const double x = (src - sup * dp) / (0.0 - sup * cp);
         d_prime[k] = x;
         return x;
     }
 };
 
+// Back-substitution x[i] = d'[i] - c'[i] x[i+1] for i = top ... 0: the rows' coefficients are requested eight at a time
+// (one at a time, every step waited for its own two loads); `emit(i, x)` stores x[i] where it belongs.
+template <bool ABS_TINY, class Emit>
+__device__ __forceinline__ void back_substitute(const double* __restrict__ c_prime, const double* __restrict__ d_prime,
+                                                size_t c, size_t nc, int top, double xi, Emit emit) {
+    int i = top;
+    while (i >= 0) {
+        double cpv[8], dpv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = max(i - u, 0);
+            cpv[u] = c_prime[c + nc * r];
+            dpv[u] = d_prime[c + nc * r];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i - u < 0) break;
+            xi = dpv[u] - cpv[u] * xi;
+            if (ABS_TINY && xi < 1e-100) xi = fabs(xi);
+            emit(i - u, xi);
+        }
+        i -= 8;
+    }
+}
+
+// LEAN: the call of the device-resident loop -- the work arrays alpha ... s_up, which nothing reads, are not written, and
+// without a direct beam its (zero) arrays and G+- are not read: traffic, the kernel runs at the memory system's rate
+template <bool LEAN>
 __global__ void __launch_bounds__(256)
 k_fband_matrix_iso(double* __restrict__ F_down, double* __restrict__ F_up,
                    const double* __restrict__ F_dir, const double* __restrict__ planckband_lay,
@@ -73,32 +108,36 @@ k_fband_matrix_iso(double* __restrict__ F_down, double* __restrict__ F_up,
         for (int j = 0; j < nl; j++) {
             const size_t k = c + nc * j;
             const double M = M_term[k], N = N_term[k], P = P_term[k], w0 = w_0[k];
-            const double Gm = G_minus[k], Gp = G_plus[k];
             const double g0 = clouds == 1 ? g_0_tot_lay[x + (size_t)nbin * j] : g_0;
             const double E = E_factor(w0, g0, scat_corr, i2s);
-            const double Fdir_top = F_dir[k + nc];
+            const double Fdir_top = (!LEAN || dir_beam == 1) ? F_dir[k + nc] : 0.0;
             const double al = P / M, be = -N / M;
             const double planck = 2.0 * HX_PI * epsi * (1.0 - w0) / (E - w0) * (N + M - P) * B[j];
-            const double dd = dmin(0.0, Fdir_bot / (-mu_star) * (Gm * M + Gp * N) - Fdir_top / (-mu_star) * P * Gm);
-            const double du = dmin(0.0, Fdir_top / (-mu_star) * (Gm * N + Gp * M) - Fdir_bot / (-mu_star) * P * Gp);
+            double dd = 0.0, du = 0.0;
+            if (!LEAN || dir_beam == 1) {
+                const double Gm = G_minus[k], Gp = G_plus[k];
+                dd = dmin(0.0, Fdir_bot / (-mu_star) * (Gm * M + Gp * N) - Fdir_top / (-mu_star) * P * Gm);
+                du = dmin(0.0, Fdir_top / (-mu_star) * (Gm * N + Gp * M) - Fdir_bot / (-mu_star) * P * Gp);
+            }
             const double sd = 1.0 / M * (planck + dd), su = 1.0 / M * (planck + du);
-            alpha[k] = al;
-            beta[k] = be;
-            s_down[k] = sd;
-            s_up[k] = su;
+            if (!LEAN) {
+                alpha[k] = al;
+                beta[k] = be;
+                s_down[k] = sd;
+                s_up[k] = su;
+            }
             th.push(-be, -al, sd);  // down equation of slab j
             th.push(-be, 1.0, su);  // up equation of slab j
             Fdir_bot = Fdir_top;
         }
         double xi = th.last(src_toa);
         F_up[c + nc * nl] = xi;
-        for (int i = 2 * ni - 2; i >= 0; i--) {
-            xi = d_prime[c + nc * i] - c_prime[c + nc * i] * xi;
+        back_substitute<false>(c_prime, d_prime, c, nc, 2 * ni - 2, xi, [&](int i, double x) {
             if (i % 2 == 0)
-                F_down[c + nc * (i / 2)] = xi;
+                F_down[c + nc * (i / 2)] = x;
             else
-                F_up[c + nc * ((i - 1) / 2)] = xi;
-        }
+                F_up[c + nc * ((i - 1) / 2)] = x;
+        });
     } else {
         double Fd = src_toa;
         F_down[c + nc * nl] = Fd;
@@ -123,6 +162,7 @@ struct MatrixNoniso {
     double *alpha, *beta, *s_down, *s_up, *c_prime, *d_prime;
 };
 
+template <bool LEAN>
 __global__ void __launch_bounds__(256)
 k_fband_matrix_noniso(double* __restrict__ F_down, double* __restrict__ F_up,
                       double* __restrict__ Fc_down, double* __restrict__ Fc_up,
@@ -155,7 +195,6 @@ k_fband_matrix_noniso(double* __restrict__ F_down, double* __restrict__ F_up,
             const size_t k = c + nc * i, b = x + (size_t)nbin * i;
             const double M = lower ? q.Ml[k] : q.Mu[k], N = lower ? q.Nl[k] : q.Nu[k];
             const double P = lower ? q.Pl[k] : q.Pu[k], w0 = lower ? q.w0l[k] : q.w0u[k];
-            const double Gm = lower ? q.Gml[k] : q.Gmu[k], Gp = lower ? q.Gpl[k] : q.Gpu[k];
             const double dtau = lower ? q.dtl[k] + q.dcl[b] : q.dtu[k] + q.dcu[b];
             double g0 = g_0;
             if (clouds == 1) g0 = ((lower ? q.g0_int[b] : q.g0_int[b + nbin]) + q.g0_lay[b]) / 2.0;
@@ -170,34 +209,38 @@ k_fband_matrix_noniso(double* __restrict__ F_down, double* __restrict__ F_up,
                 pd = (M + N) * B_bot - P * B_top + epsi / (E * (1.0 - w0 * g0)) * (P - M + N) * pgrad;
                 pu = (M + N) * B_top - P * B_bot + epsi / (E * (1.0 - w0 * g0)) * (M - N - P) * pgrad;
             }
-            const double F_bot = lower ? F_dir[k] : Fc_dir[k];
-            const double F_top = lower ? Fc_dir[k] : F_dir[k + nc];
-            const double dd = dmin(0.0, F_bot / (-mu_star) * (Gm * M + Gp * N) - F_top / (-mu_star) * P * Gm);
-            const double du = dmin(0.0, F_top / (-mu_star) * (Gm * N + Gp * M) - F_bot / (-mu_star) * P * Gp);
+            double dd = 0.0, du = 0.0;
+            if (!LEAN || dir_beam == 1) {
+                const double Gm = lower ? q.Gml[k] : q.Gmu[k], Gp = lower ? q.Gpl[k] : q.Gpu[k];
+                const double F_bot = lower ? F_dir[k] : Fc_dir[k];
+                const double F_top = lower ? Fc_dir[k] : F_dir[k + nc];
+                dd = dmin(0.0, F_bot / (-mu_star) * (Gm * M + Gp * N) - F_top / (-mu_star) * P * Gm);
+                du = dmin(0.0, F_top / (-mu_star) * (Gm * N + Gp * M) - F_bot / (-mu_star) * P * Gp);
+            }
             const double al = P / M, be = -N / M;
             const double sd = 1.0 / M * (2.0 * HX_PI * epsi * (1.0 - w0) / (E - w0) * pd + dd);
             const double su = 1.0 / M * (2.0 * HX_PI * epsi * (1.0 - w0) / (E - w0) * pu + du);
             const size_t kj = c + nc * j;
-            q.alpha[kj] = al;
-            q.beta[kj] = be;
-            q.s_down[kj] = sd;
-            q.s_up[kj] = su;
+            if (!LEAN) {
+                q.alpha[kj] = al;
+                q.beta[kj] = be;
+                q.s_down[kj] = sd;
+                q.s_up[kj] = su;
+            }
             th.push(-be, -al, sd);
             th.push(-be, 1.0, su);
         }
         double xi = th.last(src_toa);
         F_up[c + nc * nl] = xi;
-        for (int i = 4 * ni - 4; i >= 0; i--) {
-            xi = q.d_prime[c + nc * i] - q.c_prime[c + nc * i] * xi;
-            if (xi < 1e-100) xi = fabs(xi);
+        back_substitute<true>(q.c_prime, q.d_prime, c, nc, 4 * ni - 4, xi, [&](int i, double x) {
             const size_t k = c + nc * (i >> 2);
             switch (i & 3) {
-                case 0: F_down[k] = xi; break;
-                case 1: F_up[k] = xi; break;
-                case 2: Fc_down[k] = xi; break;
-                default: Fc_up[k] = xi; break;
+                case 0: F_down[k] = x; break;
+                case 1: F_up[k] = x; break;
+                case 2: Fc_down[k] = x; break;
+                default: Fc_up[k] = x; break;
             }
-        }
+        });
     } else {
         // pure absorption (kernels.cu:2286-2421)
         double Fd = src_toa;
@@ -253,7 +296,7 @@ int hx_internal_fband_matrix_iso(hx_context* ctx, const int* skip, double* F_dow
                         double epsi, int dir_beam, int clouds, int scat_corr, int debug,
                         double i2s_transition) {
     (void)singlewalk;
-    k_fband_matrix_iso<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
+    (skip ? k_fband_matrix_iso<true> : k_fband_matrix_iso<false>)<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
         F_down_wg, F_up_wg, F_dir_wg, planckband_lay, w_0, M_term, N_term, P_term, G_plus, G_minus,
         g_0_tot_lay, alpha, beta, source_term_down, source_term_up, c_prime, d_prime, scat_trigger,
         trans_wg, surf_albedo, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
@@ -289,7 +332,7 @@ int hx_internal_fband_matrix_noniso(
                       N_upper, N_lower, P_upper, P_lower, G_plus_upper, G_plus_lower, G_minus_upper,
                       G_minus_lower, g_0_tot_lay, g_0_tot_int, trans_wg_upper, trans_wg_lower,
                       alpha, beta, source_term_down, source_term_up, c_prime, d_prime};
-    k_fband_matrix_noniso<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
+    (skip ? k_fband_matrix_noniso<true> : k_fband_matrix_noniso<false>)<<<hx_cdiv((long long)ny * nbin, 256), 256, 0, ctx->stream>>>(
         F_down_wg, F_up_wg, Fc_down_wg, Fc_up_wg, F_dir_wg, Fc_dir_wg, planckband_lay, planckband_int,
         q, scat_trigger, surf_albedo, g_0, Rstar, a, numinterfaces, nbin, f_factor, mu_star, ny, epsi,
         delta_tau_limit, dir_beam, clouds, scat_corr, i2s_transition, skip);
