@@ -546,6 +546,10 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     const size_t L = rt->L, I = rt->I, X = rt->X;
+    if (rt->matrix && surf_albedo)  // row 0 of the tridiagonal system divides by it; the reader keeps it >= 1e-8 (read.py:1261)
+        for (size_t x = 0; x < X; x++)
+            if (!(surf_albedo[x] > 0.0))
+                return rt_fail(rt, HX_E_ARG, "the matrix method needs a surface albedo > 0 in every bin (the reference's reader sets at least 1e-8)");
     for (int c = c0; c < c1; c++) {
         std::vector<double> du(L), dl(L);
         const double g = rt->cols[c].g;
@@ -562,7 +566,10 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
             rc |= h2d(rt, rt->mx.dcol_iso + c * L, du.data(), L * 8);
         }
         rc |= h2d(rt, rt->T_lay + c * (L + 1), T_lay, (L + 1) * 8);
-        if (surf_albedo) rc |= h2d(rt, rt->surf_albedo + c * X, surf_albedo, X * 8);
+        if (surf_albedo) {
+            rc |= h2d(rt, rt->surf_albedo + c * X, surf_albedo, X * 8);
+            rt->have_albedo = true;
+        }
         if (starflux) rc |= h2d(rt, rt->starflux + c * X, starflux, X * 8);
     }
     return rc;
@@ -821,6 +828,7 @@ int hx_rt_refresh(hx_rt* rt) {
     hx_context* ctx = rt->ctx;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables && rt->have_planck, HX_E_STATE,
                "set grid, tables and build the Planck table first");
+    HX_REQUIRE(ctx, !rt->matrix || rt->have_albedo, HX_E_STATE, "the matrix method needs a surface albedo (> 0) per column");
     const int X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, C = rt->C;
     const size_t nc = (size_t)X * Y;
     int rc = 0;

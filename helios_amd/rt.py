@@ -262,13 +262,17 @@ def batch_from_case(ctx, c, ncol=1, nspecies=0, columns=None):
         cols = [dict(col, **{k: v for k, v in cp.items() if k in col}) for cp in columns]
     rt = RTBatch(ctx, c.nbin, c.ny, c.nlayer, ncol, c.ntemp, c.npress, c.plancktable_dim,
                  c.plancktable_step, flags, cols, nspecies=nspecies)
-    rt.set_grid(c.opac_interwave, c.opac_deltawave, c.opac_wave, c.gauss_y, c.gauss_weight, c.ktemp, c.kpress)
-    if nspecies == 0:
-        rt.set_premixed_tables(c.opac_k, c.opac_scat_cross, c.opac_meanmass)
-    rt.set_column_profile(-1, c.p_lay, c.p_int, c.T_lay, c.surf_albedo, c.starflux)
-    if c.clouds:
-        rt.set_column_clouds(-1, c.abs_cross_all_clouds_lay, c.abs_cross_all_clouds_int,
-                             c.scat_cross_all_clouds_lay, c.scat_cross_all_clouds_int,
-                             c.g_0_all_clouds_lay, c.g_0_all_clouds_int)
-    rt.set_state(-1, "c_p_lay", np.asarray(c.c_p_lay, np.float64))
+    try:
+        rt.set_grid(c.opac_interwave, c.opac_deltawave, c.opac_wave, c.gauss_y, c.gauss_weight, c.ktemp, c.kpress)
+        if nspecies == 0:
+            rt.set_premixed_tables(c.opac_k, c.opac_scat_cross, c.opac_meanmass)
+        rt.set_column_profile(-1, c.p_lay, c.p_int, c.T_lay, c.surf_albedo, c.starflux)
+        if c.clouds:
+            rt.set_column_clouds(-1, c.abs_cross_all_clouds_lay, c.abs_cross_all_clouds_int,
+                                 c.scat_cross_all_clouds_lay, c.scat_cross_all_clouds_int,
+                                 c.g_0_all_clouds_lay, c.g_0_all_clouds_int)
+        rt.set_state(-1, "c_p_lay", np.asarray(c.c_p_lay, np.float64))
+    except Exception:
+        rt.close()         # a refused input must not leave the batch's device memory behind
+        raise
     return rt

@@ -299,6 +299,17 @@ def test_fused_matrix_method_batch_of_columns(ctx, port):
         fh.compare(f, o, c0, rtol=1e-7)
 
 
+def test_fused_matrix_method_refuses_a_black_surface(ctx):
+    """row 0 of the tridiagonal system divides by the surface albedo (kernels.cu:2203-2215; the reference's reader keeps it
+    >= 1e-8, read.py:1261): a zero is refused when the column is handed over instead of ending in NaNs"""
+    from helios_amd import _lib
+    from helios_amd.rt import batch_from_case
+    c0 = cases.make_case(nbin=5, nlayer=6, albedo=0.0)
+    c0.flux_calc_method = "matrix"
+    with pytest.raises(_lib.HeliosHipError, match="albedo"):
+        batch_from_case(ctx, c0)
+
+
 def test_fused_stops_at_convergence(ctx, port):
     """a column whose every layer satisfies the criterion is frozen on the device exactly where the
     reference's loop would exit (computation.py:938), however late the host looks"""
