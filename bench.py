@@ -567,8 +567,11 @@ def main():
     for x in secondary:
         wx = WORKLOADS[x]
         hx_ = bool(wx.get("nspecies")) and wx["nbin"] >= 5000
-        r = measure(ctx, ranks, x, wx.get("columns_per_gpu", 1), 20 if hx_ else 100, 10, seed,
-                    profile_steps=args.profile_steps)
+        try:
+            r = measure(ctx, ranks, x, wx.get("columns_per_gpu", 1), 20 if hx_ else 100, 10, seed,
+                        profile_steps=args.profile_steps)
+        except Exception as e:   # the headline above is measured and stands; a secondary that could not run says why
+            r = {"error": "%s: %s" % (type(e).__name__, e)}   # (a batch that does not fit fails before any collective)
         sec[x] = r
     line["secondary"] = sec or None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
