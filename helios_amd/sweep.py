@@ -87,7 +87,7 @@ def _prepare_column(base_argv, overrides, shared):
 def _batch_signature(q):
     return (int(q.nbin), int(q.ny), int(q.nlayer), int(q.scat), int(q.dir_beam), int(q.clouds), int(q.scat_corr),
             int(q.smooth), int(q.convection), str(q.opacity_mixing), float(q.g_0), float(q.epsi), str(q.planet_type),
-            int(q.iso), int(q.singlewalk))
+            int(q.iso), int(q.singlewalk), str(q.flux_calc_method))
 
 
 def _radiation_loop(computer, quants, rt):

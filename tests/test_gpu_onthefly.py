@@ -433,6 +433,29 @@ def test_sweep_batch_equals_individual_runs(tmp_path):
             k += 1
 
 
+def test_sweep_with_the_matrix_method_equals_individual_runs(tmp_path):
+    """`flux calculation method = matrix` in a sweep: four columns through one device batch (the solver runs column by
+    column inside the loop, the work arrays of the elimination are shared) end where their own single runs end"""
+    import sweep
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "24 6 5 13",
+            "-number_of_layers", "14", "-maximum_number_of_iterations", "20000", "-name", "mx",
+            "-radiative_equilibrium_criterion", "1e-4", "-convective_adjustment", "no", "-surface_albedo", "0.1",
+            "-flux_calculation_method", "matrix"]
+    out = str(tmp_path) + "/"
+    cols, spectra = sweep.main(["-sweep", "internal_temperature=100,700;f_factor=0.25,0.6"] + base +
+                               ["-output_directory", out + "batch/"])
+    assert len(cols) == 4 and spectra.shape == (4, 24) and all(q.flux_calc_method == "matrix" for q in cols)
+    k = 0
+    for T_int in ("100", "700"):
+        for f in ("0.25", "0.6"):
+            single = _run_driver(base + ["-output_directory", out + "single/", "-name", "s%d" % k,
+                                         "-internal_temperature", T_int, "-f_factor", f], True)
+            assert single.rt is not None and int(cols[k].iter_value) == int(single.iter_value), k
+            np.testing.assert_allclose(cols[k].T_lay, single.T_lay, rtol=1e-12, err_msg="column %d" % k)
+            np.testing.assert_allclose(spectra[k], single.F_up_band[-24:], rtol=1e-12)
+            k += 1
+
+
 def test_sweep_of_post_processing_runs_is_one_pass_per_column(tmp_path):
     """`-run_type post-processing` in a sweep (singlewalk = 1, isothermal layers): the batch takes ONE pass without a
     temperature step -- every column keeps the T-P profile it was given and ends where its own single post-processing run
