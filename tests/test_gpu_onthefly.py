@@ -300,6 +300,29 @@ def test_run_helios_post_processing_of_a_converged_profile(tmp_path):
     np.testing.assert_allclose(pp.F_net, ps.F_net, rtol=1e-8, atol=1e-11 * np.abs(ps.F_up_tot).max())
 
 
+def test_run_helios_post_processing_with_the_matrix_method(tmp_path):
+    """the use the reference's documentation recommends the matrix method for (`docs/sections/parameters.rst:326`: "for
+    post-processing only"): one pass over a given profile, isothermal layers, one tridiagonal solve per spectral point.
+    The device-resident pass equals the per-stage one, and the direct solve is the limit of the 1001 sweeps"""
+    wd = str(tmp_path)
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 7",
+            "-number_of_layers", "40", "-maximum_number_of_iterations", "20000", "-output_directory", wd + "/",
+            "-radiative_equilibrium_criterion", "1e-5", "-convective_adjustment", "no", "-surface_albedo", "0.1"]
+    _run_driver(base + ["-name", "run"], True)
+    pp = base + ["-run_type", "post-processing", "-path_to_temperature_file", os.path.join(wd, "run", "run_tp.dat")]
+    mx = _run_driver(pp + ["-name", "mx", "-flux_calculation_method", "matrix"], True)
+    assert int(mx.singlewalk) == 1 and int(mx.iso) == 1 and mx.rt is not None and mx.flux_calc_method == "matrix"
+    ps = _run_driver(pp + ["-name", "mx2", "-flux_calculation_method", "matrix"], False)
+    assert ps.rt is None
+    for k in ("F_up_band", "F_down_band", "contr_func_band"):
+        np.testing.assert_allclose(getattr(mx, k), getattr(ps, k), rtol=1e-9, atol=1e-13 * getattr(ps, k).max(), err_msg=k)
+    np.testing.assert_allclose(mx.F_net, ps.F_net, rtol=1e-8, atol=1e-11 * np.abs(ps.F_up_tot).max())
+    sw = _run_driver(pp + ["-name", "sw"], True)                    # the 1000*scat+1 sweeps of the iterative method
+    X, L = int(mx.nbin), int(mx.nlayer)
+    # (observed: the 1001 sweeps have come within 2e-6 of the direct solution)
+    np.testing.assert_allclose(mx.F_up_band[L * X:], sw.F_up_band[L * X:], rtol=1e-4, atol=1e-10 * sw.F_up_band.max())
+
+
 CONV_ARGV = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "30 6 5 11",
              "-number_of_layers", "25", "-maximum_number_of_iterations", "20000", "-name", "cv",
              "-radiative_equilibrium_criterion", "1e-4", "-internal_temperature", "1500", "-kappa_value", "0.2"]
