@@ -4,6 +4,11 @@
 #include "hx_common.h"
 
 #include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
 
 extern "C" {
 
@@ -170,5 +175,64 @@ int hx_mem_info(hx_context* ctx, size_t* out_free, size_t* out_total) {
     HX_HIP(ctx, hipMemGetInfo(out_free, out_total));
     return 0;
 }
+
+// ---- host utility (no device call): the rows of the per-bin output tables ---------------------------------------------
+// The reference's writers (source/write.py:576-714) put one row per wavelength bin into fourteen text files: the bin's
+// geometry, then one cell per level -- 14 million cells at 10 000 bins x 100 layers, two seconds of single-threaded
+// number formatting, four times the iteration to equilibrium itself.  printf's conversions are the ones Python's
+// `%`-operator performs (both round correctly), so the rows are formatted here by several threads.
+static bool cell_format_ok(const char* f) {  // %-<width>[.<precision>](e|g)
+    if (!f || f[0] != '%' || f[1] != '-') return false;
+    const char* p = f + 2;
+    if (!isdigit((unsigned char)*p)) return false;
+    while (isdigit((unsigned char)*p)) p++;
+    if (*p == '.') {
+        p++;
+        if (!isdigit((unsigned char)*p)) return false;
+        while (isdigit((unsigned char)*p)) p++;
+    }
+    return (*p == 'e' || *p == 'g') && p[1] == 0;
+}
+
+int hx_host_format_rows(const double* prefix, const double* values, int nrows, int ncols, const char* cell_format,
+                        int nthreads, char** out_text, size_t* out_len) {
+    if (!prefix || !values || !out_text || !out_len || nrows < 0 || ncols < 0 || !cell_format_ok(cell_format)) return HX_E_ARG;
+    nthreads = std::max(1, std::min(nthreads, std::max(1, nrows / 64)));
+    std::vector<std::string> part(nthreads);
+    auto work = [&](int t) {
+        const int r0 = (int)((long long)nrows * t / nthreads), r1 = (int)((long long)nrows * (t + 1) / nthreads);
+        std::string& o = part[t];
+        o.reserve((size_t)(r1 - r0) * (72 + (size_t)ncols * 26));
+        char buf[512];
+        for (int r = r0; r < r1; r++) {
+            const double* p = prefix + 4 * (size_t)r;
+            o.append(buf, snprintf(buf, sizeof buf, "\n%-8g%-18.9g%-21.9g%-19.9g", p[0], p[1], p[2], p[3]));
+            const double* v = values + (size_t)ncols * r;
+            for (int c = 0; c < ncols; c++) {
+                double x = v[c];
+                if (x != x) x = fabs(x);  // printf writes the sign of a NaN ("-nan"), Python does not
+                o.append(buf, snprintf(buf, sizeof buf, cell_format, x));
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    size_t total = 0;
+    for (auto& o : part) total += o.size();
+    char* text = (char*)malloc(total ? total : 1);
+    if (!text) return HX_E_ARG;
+    size_t at = 0;
+    for (auto& o : part) {
+        memcpy(text + at, o.data(), o.size());
+        at += o.size();
+    }
+    *out_text = text;
+    *out_len = total;
+    return 0;
+}
+
+void hx_host_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -97,6 +97,42 @@ def _mean_or_flag(value):
     return "{:<20}".format("temp_too_low") if value == -3 else "{:<20g}".format(value)
 
 
+def _format_rows(quant, values, cell):
+    """the rows of a per-bin table -- "\n" + bin index, centre, lower edge and width in micron, then one cell per level --
+    formatted by the library's host utility on several threads (hx_host_format_rows: printf's conversions are the ones of
+    the `%` operator; byte-identical to `_format_rows_python`, which the tests hold it to)"""
+    import ctypes
+    from . import _lib
+    l = _lib.lib()
+    X = int(quant.nbin)
+    prefix = np.empty((X, 4))
+    prefix[:, 0] = np.arange(X)
+    prefix[:, 1] = np.asarray(quant.opac_wave, float)[:X] * 1e4
+    prefix[:, 2] = np.asarray(quant.opac_interwave, float)[:X] * 1e4
+    prefix[:, 3] = np.asarray(quant.opac_deltawave, float)[:X] * 1e4
+    v = np.ascontiguousarray(values, np.float64)
+    text, n = ctypes.c_void_p(), ctypes.c_size_t()
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = l.hx_host_format_rows(prefix.ctypes.data_as(dp), v.ctypes.data_as(dp), X, int(v.shape[1]), cell.encode(),
+                               min(64, os.cpu_count() or 1), ctypes.byref(text), ctypes.byref(n))
+    if rc != 0:
+        raise _lib.HeliosHipError("hx_host_format_rows failed with status %d (cell format %r)" % (rc, cell))
+    try:
+        return ctypes.string_at(text, n.value)        # ASCII bytes
+    finally:
+        l.hx_host_free(text)
+
+
+def _format_rows_python(quant, values, cell):
+    """the same rows through Python's own formatting (the statement of what the rows are; used by the tests)"""
+    row_fmt = cell * int(values.shape[1])
+    out = []
+    for x in range(int(quant.nbin)):
+        out.append(Write._bin_prefix(quant, x))
+        out.append(row_fmt % tuple(values[x].tolist()))
+    return "".join(out).encode("ascii")
+
+
 class Write(object):
 
     # ---- plumbing -----------------------------------------------------------------------------------
@@ -123,16 +159,11 @@ class Write(object):
         nlev = int(getattr(quant, levels))
         X = int(quant.nbin)
         values = matrix(quant)
-        row_fmt = cell * nlev
-        with open(Write._path(quant, read, suffix), "w", encoding="utf-8") as f:
-            f.write(title)
-            f.write(("\n{:<8}{:<18}{:21}{:%d}" % w4).format(*_BIN_HEAD))
-            f.write("".join(("{:<%d}{:g}{:<4}" % lw).format(label, i, "]") for i in range(nlev)))
-            out = []
-            for x in range(X):
-                out.append(Write._bin_prefix(quant, x))
-                out.append(row_fmt % tuple(values[x].tolist()))
-            f.write("".join(out))
+        head = title + ("\n{:<8}{:<18}{:21}{:%d}" % w4).format(*_BIN_HEAD)
+        head += "".join(("{:<%d}{:g}{:<4}" % lw).format(label, i, "]") for i in range(nlev))
+        with open(Write._path(quant, read, suffix), "wb") as f:
+            f.write(head.encode("utf-8"))
+            f.write(_format_rows(quant, values, cell))
 
     @staticmethod
     def convert_1_0_to_yes_no(variable):
@@ -305,17 +336,16 @@ class Write(object):
     def write_planck_center(quant, read):
         """layer centres plus the stellar and the internal-temperature Planck columns"""
         X, L = int(quant.nbin), int(quant.nlayer)
-        with open(Write._path(quant, read, "_planck_cent.dat"), "w") as f:
-            f.write("This file contains the Planck (blackbody) function at each layer center and "
-                    "from the stellar (2nd last column) and internal (last column) temperatures. "
-                    "\nPlanck function given in [erg s^-1 cm^-3 sr^-1].")
-            f.write("\n{:<8}{:<18}{:21}{:19}".format(*_BIN_HEAD))
-            for i in range(L):
-                f.write("{:<6}{:g}{:<4}".format("B_lay[", i, "]"))
-            f.write("{:<16}{:<16}".format("Planck_T_star", "Planck_T_intern"))
-            rows = np.asarray(quant.planckband_lay, float).reshape(X, L + 2)
-            row_fmt = "%-16g" * (L + 2)
-            f.write("".join(Write._bin_prefix(quant, x) + row_fmt % tuple(rows[x].tolist()) for x in range(X)))
+        head = ("This file contains the Planck (blackbody) function at each layer center and "
+                "from the stellar (2nd last column) and internal (last column) temperatures. "
+                "\nPlanck function given in [erg s^-1 cm^-3 sr^-1].")
+        head += "\n{:<8}{:<18}{:21}{:19}".format(*_BIN_HEAD)
+        head += "".join("{:<6}{:g}{:<4}".format("B_lay[", i, "]") for i in range(L))
+        head += "{:<16}{:<16}".format("Planck_T_star", "Planck_T_intern")
+        rows = np.asarray(quant.planckband_lay, float).reshape(X, L + 2)
+        with open(Write._path(quant, read, "_planck_cent.dat"), "wb") as f:
+            f.write(head.encode("utf-8"))
+            f.write(_format_rows(quant, rows, "%-16g"))
 
     @staticmethod
     def write_opacities(quant, read):

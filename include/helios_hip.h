@@ -77,6 +77,13 @@ int hx_d2h(hx_context* ctx, void* hptr, const void* dptr, size_t nbytes);
 int hx_d2d(hx_context* ctx, void* dst, const void* src, size_t nbytes);
 int hx_memset0(hx_context* ctx, void* dptr, size_t nbytes);
 int hx_mem_info(hx_context* ctx, size_t* out_free, size_t* out_total);
+/* Host utility (no context, no device call): nrows rows "\n%-8g%-18.9g%-21.9g%-19.9g" of prefix[4 * r ...] followed by
+ * ncols cells `cell_format` ("%-<width>[.<precision>]e" or "...g") of values[ncols * r ...] -- the rows of the reference's
+ * per-bin output tables (source/write.py:576-714), formatted by `nthreads` threads.  *out_text is released with
+ * hx_host_free. */
+int hx_host_format_rows(const double* prefix, const double* values, int nrows, int ncols, const char* cell_format,
+                        int nthreads, char** out_text, size_t* out_len);
+void hx_host_free(void* p);
 
 /* ---- (3) per-stage entry points: one per reference kernel ------------------------------------
  * Each comment gives the kernel it replaces (source/kernels.cu) and its launcher

@@ -40,6 +40,29 @@ def test_writers_byte_identical(tmp_path, tag, kw):
             assert len(a) == len(b), f
 
 
+@pytest.mark.parametrize("cell", ["%-16.8e", "%-16g", "%-15g", "%-25g", "%-17g"])
+def test_table_rows_formatted_by_the_library_equal_pythons(cell):
+    """hx_host_format_rows (printf, several threads) against the `%` operator on awkward cells: signs, zeros of both
+    signs, denormals, three-digit exponents, cells wider than their field, integers, infinities, NaNs of both signs"""
+    from helios_amd import write
+    rng = np.random.default_rng(3)
+    X, nlev = 517, 23
+    v = rng.normal(size=(X, nlev)) * 10.0 ** rng.integers(-320, 308, size=(X, nlev)).astype(float)
+    v[0, :12] = [0.0, -0.0, 5e-324, -2.2e-308, 1.7976931348623157e308, -1e-300, 123456789.0, 1e16, 0.1, 100000.0,
+                 999999.5, 1e-5]
+    v[1, :6] = [np.inf, -np.inf, np.nan, -np.nan, 1.0, -1.0]
+    v[2] = np.round(rng.uniform(-1e6, 1e6, nlev))
+    q = type("Q", (), {})()
+    q.nbin = X
+    q.opac_wave = 0.3e-4 * (500.0 / 0.3) ** (np.arange(X) / X)
+    q.opac_interwave = q.opac_wave * 0.99
+    q.opac_deltawave = q.opac_wave * 1e-3
+    a = write._format_rows(q, v, cell)
+    b = write._format_rows_python(q, v, cell)
+    assert a == b
+    assert a.count(b"\n") == X
+
+
 @pytest.mark.parametrize("tag,kw", [("g13", dict(nlayer=13)), ("g50", dict(nlayer=50, p_boa=1e9, p_toa=1e-1, g=980.0))])
 def test_grid_construction(tag, kw):
     q = mk.grid_state(**kw)
