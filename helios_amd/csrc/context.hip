@@ -199,7 +199,9 @@ int hx_host_format_rows(const double* prefix, const double* values, int nrows, i
     if (!prefix || !values || !out_text || !out_len || nrows < 0 || ncols < 0 || !cell_format_ok(cell_format)) return HX_E_ARG;
     nthreads = std::max(1, std::min(nthreads, std::max(1, nrows / 64)));
     std::vector<std::string> part(nthreads);
+    std::vector<char> failed(nthreads, 0);  // an exception (out of memory) must not leave a thread: it would end the process
     auto work = [&](int t) {
+      try {
         const int r0 = (int)((long long)nrows * t / nthreads), r1 = (int)((long long)nrows * (t + 1) / nthreads);
         std::string& o = part[t];
         o.reserve((size_t)(r1 - r0) * (72 + (size_t)ncols * 26));
@@ -214,11 +216,20 @@ int hx_host_format_rows(const double* prefix, const double* values, int nrows, i
                 o.append(buf, snprintf(buf, sizeof buf, cell_format, x));
             }
         }
+      } catch (...) {
+        failed[t] = 1;
+      }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    try {
+        for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+    } catch (...) {  // no more threads to be had: the rows of the missing ones are formatted here
+        for (int t = (int)th.size() + 1; t < nthreads; t++) work(t);
+    }
     work(0);
     for (auto& t : th) t.join();
+    for (char f : failed)
+        if (f) return HX_E_ARG;
     size_t total = 0;
     for (auto& o : part) total += o.size();
     char* text = (char*)malloc(total ? total : 1);
