@@ -38,8 +38,8 @@ WORKLOADS = {
                desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
     "c2beam": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, dir_beam=1, albedo=0.1,
                    desc="config 2's shape with the direct beam and a reflecting surface (five coefficient planes)"),
-    "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20,
-               desc="BASELINE config 1 shape: 300 bins x 50 layers, premixed"),
+    "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20, scat=0,
+               desc="BASELINE config 1: single column, 300 bins x 50 layers, premixed, no scattering"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
                desc="BASELINE config 3: on-the-fly mixing, 20 species random overlap, 10 000 bins x 100 layers"),
     "c5": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, nspecies=20, clouds=2, albedo="smoothed", scat_corr=1,
@@ -76,7 +76,7 @@ def build_case(w, seed):
     c = C()
     c.nbin, c.nlayer, c.ny, c.ntemp, c.npress = w["nbin"], w["nlayer"], w["ny"], w["ntemp"], w["npress"]
     c.ninterface = c.nlayer + 1
-    c.iso, c.scat, c.dir_beam, c.clouds, c.scat_corr, c.geom_zenith_corr = 0, 1, 0, 0, 0, 0
+    c.iso, c.scat, c.dir_beam, c.clouds, c.scat_corr, c.geom_zenith_corr = 0, int(w.get("scat", 1)), 0, 0, 0, 0
     c.g_0, c.epsi, c.epsi2, c.i2s_transition = 0.0, 0.5, 0.5, 0.1
     c.w_0_limit, c.w_0_scat_limit, c.delta_tau_limit = 1.0 - 1e-10, 1e-3, 1e-4
     c.f_factor, c.mu_star = 0.5, float(np.cos(np.pi - np.pi / 3.0))
