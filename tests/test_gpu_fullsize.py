@@ -347,6 +347,53 @@ def test_config5_full_size_clouds_beam_i2s_albedo_and_convection(ctx, port):
         rt.close()
 
 
+def test_config1_run_to_equilibrium_vs_the_reference_on_the_gpu(ctx):
+    """BASELINE config 1 as BASELINE.json names it -- single column, premixed opacity table, 300 bins x 50 layers, no
+    scattering -- as a WHOLE run: the reference's kernels (gfx950 build) under the reference's control flow
+    (tests/loop_driver.py) against hx_rt_run with its device-side convergence latch: same number of iterations, T-P
+    profile, net flux and emission spectrum at the end and after 1, 10, 11, 50 iterations"""
+    import bench
+    import loop_driver as ld
+    import oracle
+    from impls import RefImpl
+    from helios_amd.rt import batch_from_case
+    if oracle.refgpu is None:
+        pytest.skip("oracle/_ref/libhelios_ref_gfx950.so not present")
+    refgpu = RefImpl(oracle.refgpu)
+    c0 = bench.build_case(bench.WORKLOADS["c1"], 20241)
+    assert (c0.nbin, c0.nlayer, c0.scat) == (300, 50, 0)
+    cr = _block_case(c0, 0, c0.nbin)
+    s = cases.alloc_state(cr)
+    cases.setup_planck(refgpu, cr, s)
+    n_ref, snaps, reason = ld.radiation_loop(refgpu, cr, s, ld.SNAP_AT)
+    assert reason == "converged" and n_ref > 100
+    X, I = c0.nbin, c0.nlayer + 1
+    rt = batch_from_case(ctx, c0)
+    try:
+        rt.build_planck_table(1)
+        rt.set_state(-1, "planck_grid", s.planck_grid)
+        it = 0
+        stops = sorted(ld.SNAP_AT)
+        while True:
+            nxt = min([p for p in stops if p > it] + [it + 10 - it % 10])
+            rt.run(it, nxt - it)
+            done = int(rt.get("done")[0])
+            it = int(rt.get("iters_done")[0]) if done else nxt
+            if it in ld.SNAP_AT or done:
+                want = snaps["end" if done else it]
+                fs = np.abs(want["F_up_tot"]).max()
+                np.testing.assert_allclose(rt.get("T_lay"), want["T_lay"], rtol=1e-6, err_msg="T_lay after %d" % it)
+                np.testing.assert_allclose(rt.get("F_net"), want["F_net"], rtol=1e-6, atol=1e-9 * fs)
+                np.testing.assert_allclose(rt.get("F_up_band")[X * (I - 1):], want["F_up_band_TOA"], rtol=1e-6,
+                                           atol=1e-13 * want["F_up_band_TOA"].max())
+            if done:
+                break
+            assert it < 20000
+        assert it == n_ref, "iterations: %d, reference %d" % (it, n_ref)
+    finally:
+        rt.close()
+
+
 def _premixed_column_vs_reference(ctx, c0):
     """first iteration of a premixed column through the fused path and through the reference's kernels on this GPU
     (every array above 1 MB stays on the device between the reference's launches); all bins compared"""
