@@ -22,6 +22,22 @@ from helios_amd.write import Write  # noqa: E402
 Z = np.load(os.path.join(GOLD, "host_functions.npz"))
 
 
+def test_table_row_formatter_takes_only_the_writers_cell_formats():
+    """the cell format reaches printf: anything but %-<width>[.<precision>]e / g is refused (no %s, %n, second conversion)"""
+    import ctypes
+    from helios_amd import _lib
+    l = _lib.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    pre, val = np.zeros((2, 4)), np.ones((2, 3))
+    text, n = ctypes.c_void_p(), ctypes.c_size_t()
+    for bad in (b"%s", b"%-16.8e%n", b"%-16.8e %-16.8e", b"%16g", b"%-g", b"%-16.f", b"", b"%-16.8x"):
+        assert l.hx_host_format_rows(pre.ctypes.data_as(dp), val.ctypes.data_as(dp), 2, 3, bad, 2, ctypes.byref(text),
+                                     ctypes.byref(n)) != 0, bad
+    assert l.hx_host_format_rows(pre.ctypes.data_as(dp), val.ctypes.data_as(dp), 0, 3, b"%-16g", 2, ctypes.byref(text),
+                                 ctypes.byref(n)) == 0 and n.value == 0
+    l.hx_host_free(text)
+
+
 @pytest.mark.parametrize("tag,kw", [("a", dict()), ("b", dict(seed=8, iso=1, T_star=0.0, convection=0, nbin=3, nlayer=4))])
 def test_writers_byte_identical(tmp_path, tag, kw):
     q = mk.writer_state(**kw)
