@@ -386,16 +386,24 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
     import torch
     w = WORKLOADS[wname]
     rank, world = ranks.rank, ranks.world
-    c = build_case(w, seed)
     sweep = bool(w.get("sweep"))
-    rt = make_batch(ctx, c, ncol, first_column=rank * ncol, sweep=sweep)
-    # every column of a run differs: the sweep's own parameters, or a few per cent in the start profile
-    T_start = [c.T_lay * (1.0 + 0.01 * (rank * ncol + i)) for i in range(ncol)]
-    if not sweep and (ncol > 1 or world > 1):
-        for i in range(ncol):
-            rt.set_temperatures(i, T_start[i])
-    rt.build_planck_table(1)
-    ctx.synchronize()
+    err = None
+    try:   # everything that allocates: a batch that does not fit one rank's GPU must not leave the others in a collective
+        c = build_case(w, seed)
+        rt = make_batch(ctx, c, ncol, first_column=rank * ncol, sweep=sweep)
+        # every column of a run differs: the sweep's own parameters, or a few per cent in the start profile
+        T_start = [c.T_lay * (1.0 + 0.01 * (rank * ncol + i)) for i in range(ncol)]
+        if not sweep and (ncol > 1 or world > 1):
+            for i in range(ncol):
+                rt.set_temperatures(i, T_start[i])
+        rt.build_planck_table(1)
+        ctx.synchronize()
+    except Exception as e:
+        err = e
+    failed = [r for r, v in enumerate(ranks.gather_scalars(0.0 if err is None else 1.0)) if v]
+    if failed:   # the same decision on every rank, before the first barrier of the measurement
+        raise RuntimeError("workload %s: rank(s) %s could not set up the batch%s"
+                           % (wname, failed, ": %s: %s" % (type(err).__name__, err) if err is not None else ""))
     run = rt.run
     if phase == "convection":
         # a profile with a super-adiabatic interior, so that every iteration adjusts a deep convective zone
@@ -571,7 +579,7 @@ def main():
             r = measure(ctx, ranks, x, wx.get("columns_per_gpu", 1), 20 if hx_ else 100, 10, seed,
                         profile_steps=args.profile_steps)
         except Exception as e:   # the headline above is measured and stands; a secondary that could not run says why
-            r = {"error": "%s: %s" % (type(e).__name__, e)}   # (a batch that does not fit fails before any collective)
+            r = {"error": "%s: %s" % (type(e).__name__, e)}   # (measure() lets the ranks agree on a failed set-up first)
         sec[x] = r
     line["secondary"] = sec or None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

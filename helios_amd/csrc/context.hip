@@ -185,13 +185,15 @@ static bool cell_format_ok(const char* f) {  // %-<width>[.<precision>](e|g)
     if (!f || f[0] != '%' || f[1] != '-') return false;
     const char* p = f + 2;
     if (!isdigit((unsigned char)*p)) return false;
-    while (isdigit((unsigned char)*p)) p++;
+    // width and precision at most 64: a cell never outgrows the 512-byte buffer it is formatted into
+    int width = 0, prec = 0;
+    while (isdigit((unsigned char)*p)) { width = std::min(1000, 10 * width + (*p - '0')); p++; }
     if (*p == '.') {
         p++;
         if (!isdigit((unsigned char)*p)) return false;
-        while (isdigit((unsigned char)*p)) p++;
+        while (isdigit((unsigned char)*p)) { prec = std::min(1000, 10 * prec + (*p - '0')); p++; }
     }
-    return (*p == 'e' || *p == 'g') && p[1] == 0;
+    return width <= 64 && prec <= 64 && (*p == 'e' || *p == 'g') && p[1] == 0;
 }
 
 int hx_host_format_rows(const double* prefix, const double* values, int nrows, int ncols, const char* cell_format,

@@ -34,6 +34,13 @@
 #define RO_DPP_MINMAX4 1   // same-box A/B at config 3: 43.6 -> 43.05 ms per refresh
 #endif
 
+// phase markers for the static instruction budget (tools/isa_stats.py --phases): comments in the listing, nothing else
+#ifdef RO_MARKERS
+#define RO_MARK(name) asm volatile("; RO_MARK " name)
+#else
+#define RO_MARK(name)
+#endif
+
 namespace ro {
 
 constexpr int NY = 20;
@@ -395,6 +402,7 @@ __device__ __forceinline__ void fill_runs(Shared& sh, const Lane& ln, Keys& v, i
 }
 
 __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, double my_mix, double my_add, Counters& cnt) {
+    RO_MARK("prologue");
     // corners of the tableau, wave-uniform
     const double m0 = __shfl(my_mix, 0), a0 = __shfl(my_add, 0), m19 = __shfl(my_mix, NY - 1), a19 = __shfl(my_add, NY - 1);
     // less than 1 % of the other everywhere: correlated-k (:3297-3310)
@@ -441,6 +449,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     const int bl = dmax ? 64 - __clzll((long long)dmax) : 0;
     const int sh_bits = bl > 23 ? bl - 23 : 0;
     double K[SLOTS], g[SLOTS];
+    RO_MARK("fill");
     if (monotone && yx == NY && rows_apart) {
         // nothing to sort: rank w = 8 lane + r is cell (w / 20, w % 20) -- the sums and weights straight from the curves,
         // no keys, no LDS images
@@ -467,6 +476,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
                 else fill_runs<true, false>(sh, ln, v, yx, hmin, sh_bits);
             }
             int lv = lane;
+            RO_MARK("network");
             asm volatile("" : "+v"(lv));  // what the network derives from the lane id (exchange addresses, bits 3-5) is
                                           // rebuilt per problem and does not sit in registers between the problems
             sort512_from_runs16(v, lv, ln);
@@ -475,6 +485,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
             else fill<false, true>(sh, ln, lane, v, yx, hmin, sh_bits);
             sort512(v, lane, ln);
         }
+        RO_MARK("fetch");
         sync();
 #pragma unroll
         for (int r = 0; r < SLOTS; r++) {
@@ -483,6 +494,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
             g[r] = *(const double*)((const char*)sh.B + src);
         }
     }
+    RO_MARK("finish");
     // exact finish: any inversion left by the quantisation?
     const int next = (lane < 63 ? lane + 1 : lane) << 2, prev = (lane > 0 ? lane - 1 : lane) << 2;
     int passes = 0;
@@ -509,6 +521,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         if (sw_lo) { K[0] = kp7; g[0] = gp7; }
     }
     cnt.passes += passes;
+    RO_MARK("scan");
     // cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376): 8 per lane + wave exclusive scan
     double csum = 0.0;
 #pragma unroll
@@ -525,6 +538,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         run += g[r];
     }
     sync();
+    RO_MARK("search");
     // re-binning (:3379-3396): first w >= 1 with Y_w > y_q, at most one Gauss point per w
     int w = N + lane;  // beyond the Gauss points: ascending, so that no skip is seen there
     double yq = 0.0;
@@ -552,11 +566,13 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         wq = t + lane;
         cnt.skipped += __popcll(__ballot(lane < NY && wq != w));
     }
+    RO_MARK("interpolate");
     double out = my_mix;  // w = 400: the walk ran out of sums, the reference leaves the entry as it was
     if (lane < NY && wq < N) {
         const int i0 = padded(wq - 1), i1 = padded(wq);
         out = (sh.A[i0] * (sh.B[i1] - yq) + sh.A[i1] * (yq - sh.B[i0])) / (sh.B[i1] - sh.B[i0]);
     }
+    RO_MARK("end");
     return out;
 }
 

@@ -131,7 +131,7 @@ struct hx_rt {
     bool has_heating = false;
 
     bool matrix = false;           // hx_rt_flags.matrix
-    bool have_albedo = false;      // a surface albedo has been handed over (the matrix method divides by it)
+    std::vector<char> have_albedo; // per column: a surface albedo has been handed over (the matrix method divides by it)
     hx::MatrixArrays mx;
 
     // profiling

@@ -227,8 +227,10 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.k = a.k; f.nxb = a.nxb; f.ypb = a.ypb; f.nparts = a.nparts; f.G = a.G; f.NW = a.NW;
     f.dir_beam = a.dir_beam; f.nsweep = a.nsweep; f.keep_down = a.keep_down; f.has_vp = a.has_vp;
     f.pl_vp = a.pl_vp; f.pl_dd = a.pl_dd; f.nplane = a.nplane; f.iso = a.iso;
+#ifdef HX_PROFILING  // profiling builds only (make PROFILING=1): switches parts of k_rt_flux off, the results are wrong
     static const int debug_skip = [] { const char* e = getenv("HELIOS_RT_DEBUG_SKIP"); return e ? atoi(e) : 0; }();
     f.debug_skip = debug_skip;
+#endif
     f.Kconst = a.Kconst;
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
@@ -364,9 +366,12 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     // segments of the sweeps: two half-layers per layer (read.py:888-895), or the layers themselves when isothermal
     rt->H = flags->iso ? rt->L : 2 * rt->L;
     rt->C = dims->ncol;
+    rt->have_albedo.assign(dims->ncol, 0);
     // computation.py:531-537: 3*scat+1 sweeps per iteration, 1000*scat+1 in the post-processing run type
     rt->nsweep = (flags->singlewalk ? 1000 : 3) * (flags->scat ? 1 : 0) + 1;
+#ifdef HX_PROFILING
     if (const char* e = getenv("HELIOS_RT_DEBUG_NSWEEP")) rt->nsweep = atoi(e);  // profiling experiments only
+#endif
     if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g))
         return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512 (1024 isothermal layers); use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
@@ -568,7 +573,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
         rc |= h2d(rt, rt->T_lay + c * (L + 1), T_lay, (L + 1) * 8);
         if (surf_albedo) {
             rc |= h2d(rt, rt->surf_albedo + c * X, surf_albedo, X * 8);
-            rt->have_albedo = true;
+            rt->have_albedo[c] = 1;
         }
         if (starflux) rc |= h2d(rt, rt->starflux + c * X, starflux, X * 8);
     }
@@ -828,7 +833,8 @@ int hx_rt_refresh(hx_rt* rt) {
     hx_context* ctx = rt->ctx;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables && rt->have_planck, HX_E_STATE,
                "set grid, tables and build the Planck table first");
-    HX_REQUIRE(ctx, !rt->matrix || rt->have_albedo, HX_E_STATE, "the matrix method needs a surface albedo (> 0) per column");
+    HX_REQUIRE(ctx, !rt->matrix || std::all_of(rt->have_albedo.begin(), rt->have_albedo.end(), [](char v) { return v != 0; }),
+               HX_E_STATE, "the matrix method needs a surface albedo (> 0) for every column of the batch");
     const int X = rt->X, Y = rt->Y, L = rt->L, I = rt->I, C = rt->C;
     const size_t nc = (size_t)X * Y;
     int rc = 0;

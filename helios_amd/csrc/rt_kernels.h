@@ -798,9 +798,14 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
         // Gauss quadrature of the interface fluxes: stage[yl][xl][dir][i], summed over yl in order.
         // The lane map is derived afresh (e for "epilogue"): carried across the sweeps it lived in scratch
         const LaneMap e = lane_map(a, bx, part, opaque_tid());
+#ifdef HX_PROFILING  // HELIOS_RT_DEBUG_SKIP: bit 0 no quadrature, bit 1 no state stores -- not in the shipped library
+        const int debug_skip = a.debug_skip;
+#else
+        constexpr int debug_skip = 0;
+#endif
         auto store_state = [&]() {
             const size_t eoff = e.tile * (size_t)ROWS * 64 + e.lane;
-            if (!(a.debug_skip & 2)) {
+            if (!(debug_skip & 2)) {
                 double* ut = a.Utile + col * a.flux_col + eoff;
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store(Uo[r], ut + r * 64);
@@ -812,7 +817,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             }
             if (e.valid && e.j == 0) a.U0[col * nc + e.sp] = U0;
         };
-        if (!(a.debug_skip & 1)) {  // profiling only (HELIOS_RT_DEBUG_SKIP): bit 0 no quadrature, bit 1 no state stores
+        if (!(debug_skip & 1)) {
             if (e.valid) {
                 // Row r of this lane is node h = h0 + r.  Staggered grid: an even node gives D at interface h/2, an odd
                 // one U at interface (h+1)/2 -- with the lane's parity p folded into two base pointers the rows use

@@ -42,4 +42,4 @@ python3 bench.py --workload c5premixed --steps 30 --warmup 10 --no-cpu-baseline 
 # two ranks on the one GPU of this box through the gloo hook: the multi-rank path incl. the config-4 share as `secondary`
 HELIOS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 10 --secondary c4small > $O/bench_2ranks_one_gpu_gloo.json 2>> $O/bench.err
 for K in generic ktable dominated; do for S in q32 bitonic rank; do HELIOS_RO_SORT=$S python3 tools/ro_bench.py --kind $K --reps 3; done; done > $O/ro_bench.txt 2>&1
-tail -c 400 $O/c2_bench.json
+tail -c 400 $O/bench_n1.json
