@@ -16,9 +16,10 @@ scaling, no collective on the iteration path, the emission spectra gathered over
 the N = 1 member of a 1/2/4/8 series IS the single-GPU headline.  `python bench.py --gpus N` without a launcher starts
 the N ranks itself (a child `python -m torch.distributed.run ...`, before this process touches a GPU).
 
-The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly) and config 5 (30 000
-x 200, 20 species on the fly, two cloud decks, beam, albedo, I2S); at N > 1 config 4 -- each GPU's share of the
-512-column sweep, 64 on-the-fly columns per GPU in one batch.  `steady_state_200` is the headline workload over 200
+The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly), config 4 at reduced
+width (8 of the sweep's 512 on-the-fly columns in one batch) and config 5 (30 000 x 200, 20 species on the fly, two cloud
+decks, beam, albedo, I2S); at N > 1 config 4 -- each GPU's share of the 512-column sweep, 64 on-the-fly columns per GPU in
+one batch.  `steady_state_200` is the headline workload over 200
 iterations from iteration 0 (20 refreshes), SURVEY.md 8(d)'s definition of the metric.
 """
 import argparse
@@ -29,6 +30,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU baseline's OpenMP threads stay on the cores they start on, packed onto neighbouring cores (one NUMA domain for the
+# thread counts that win): read by the OpenMP runtime when it is loaded, so set before anything loads it
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np  # noqa: E402
 
@@ -59,6 +64,11 @@ WORKLOADS = {
                     desc="config 4 shape at 500 bins x 40 layers x 5 species, 6 columns per GPU (quick check)"),
     "c3small": dict(nbin=1000, nlayer=100, ny=20, ntemp=12, npress=10, nspecies=20,
                     desc="config 3 shape at 1000 bins (quick check)"),
+    "c2small": dict(nbin=1000, nlayer=100, ny=20, ntemp=12, npress=10,
+                    desc="config 2 shape at 1000 bins (quick check)"),
+    "c4x8": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=8, sweep=True,
+                 desc="BASELINE config 4 at reduced width: 8 columns of the 512-column sweep (g x a x T_intern grid) in one "
+                      "batch on one GPU, on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
 }
 
 
@@ -248,9 +258,10 @@ def cpu_baseline(w, seed):
                 host_cores=ncpu, thread_probe_iterations_per_s={str(k): round(v, 3) for k, v in probe.items()},
                 sample="%d of %d bins x %d layers x %d Gauss points%s, %d iterations from iteration 0 (one opacity "
                        "refresh per 10), oracle/helios_oracle.c built %s with OpenMP over bins on %d threads (the fastest "
-                       "of %s on %d usable cores, probed on refresh-free iterations), %.1f s"
+                       "of %s on %d usable cores, probed on refresh-free iterations; OMP_PROC_BIND=%s OMP_PLACES=%s), %.1f s; "
+                       "the value is the rate of the bins that were run (bins are independent: nothing is extrapolated)"
                        % (nb, w["nbin"], c.nlayer, c.ny, ", %d species" % len(c.species) if species else "", n_it,
-                          flags, threads, sorted(probe), ncpu, dt))
+                          flags, threads, sorted(probe), ncpu, os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES"), dt))
 
 
 def load_counters(workload):
@@ -453,14 +464,21 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
         roofline = kernel_roofline(rt, c, wname, ncol, run, start + steps, profile_steps, dt / steps)
 
     # the path's only exchange: gather the emission spectra of all columns once, after the run
-    from helios_amd.parallel import gather_spectra
-    spec = np.stack([rt.get("F_up_band", i)[-c.nbin:] for i in range(ncol)])
+    # (from the library's band array on the device: strided view -> one [columns, bins] tensor -> all-gather; the host
+    # sees the result only)
+    from helios_amd.parallel import gather_spectra, emission_spectra_on_device
+    ctx.synchronize()
+    spec = emission_spectra_on_device(rt, ncol)
     gather_ms = None
     if ranks.dist is not None:
+        torch.cuda.synchronize()
         tg = time.perf_counter()
         spec = gather_spectra(spec, ranks.dist, device=ranks.coll_device)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
+    else:
+        spec = spec.cpu().numpy()
+    assert spec.shape == (ncol * world, c.nbin)
 
     total_cols = ncol * world
     out = {
@@ -478,6 +496,8 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
         "columns_converged_during_run": int(sum(done)),
         "spectra_gather_ms": gather_ms,
         "spectrum_checksum": float(np.sum(spec)),
+        # per column, in global column order (rank-major blocks): shows that the gather put every rank's rows where they belong
+        "spectrum_checksum_per_column": [float(v) for v in spec.sum(axis=1)] if total_cols <= 64 else None,
         "roofline": roofline,
     }
     if steady_state and phase == "radiative":
@@ -511,7 +531,7 @@ def main():
                     help="headline workload (default c2, the configuration the metric is quoted on, at every N)")
     ap.add_argument("--columns-per-gpu", type=int, default=None)
     ap.add_argument("--secondary", default="default",
-                    help="'default' (N = 1: c3,c5; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
+                    help="'default' (N = 1: c3,c4x8,c5; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
                          "the same run into the line's `secondary` block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
@@ -536,7 +556,7 @@ def main():
     warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
     ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
     if args.secondary == "default":
-        secondary = (["c3", "c5"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
+        secondary = (["c3", "c4x8", "c5"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
     else:
         secondary = [x for x in args.secondary.split(",") if x and x != "none"]
     for x in secondary:
@@ -570,6 +590,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
     line.update(head)
     line["env_knobs"] = knobs
+    # what the collective layer itself reports: the backend of the process group and the number of ranks it connected
+    # ("nccl" is RCCL on ROCm; the gloo hook of the single-GPU tests says so here)
+    line["process_group"] = None if dist is None else {
+        "backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()),
+        "rccl_world": int(dist.get_world_size()) if str(dist.get_backend()) == "nccl" else None,
+        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if str(dist.get_backend()) == "nccl" else None,
+        "ranks_seen_by_all_gather": len(ranks.gather_scalars(float(rank)))}
     # the other configurations, measured live in this run on every rank (weak scaling like the headline)
     sec = {}
     for x in secondary:

@@ -456,6 +456,10 @@ class Compute(object):
                 rt.set_species(s, sp.opacity_pretab if sp.absorbing == "yes" else None, scat, sp.weight,
                                is_h2o=2 if (sp.scattering == "yes" and sp.name == "H2O") else 0,
                                is_cia=1 if "CIA" in sp.name else 0, in_mu=1 if hsfunc._counts_for_mu(sp) else 0)
+                # calculate_vmr_for_all_species on the device: a FastChem species hands over its (T, P) table once and its
+                # profile is interpolated from the device's temperatures at every refresh (host_functions.py:874-910)
+                if getattr(sp, "source_for_vmr", "") == "FastChem" and getattr(sp, "vmr_pretab", None) is not None:
+                    rt.set_species_vmr_table(s, np.asarray(sp.vmr_pretab, np.float64).reshape(-1))
         else:
             rt.set_premixed_tables(q.opac_k, q.opac_scat_cross, q.opac_meanmass)
         if self._kappa_from_table(q):
@@ -490,12 +494,25 @@ class Compute(object):
         return n
 
     def _push_vmr(self, quant):
-        """hand the current per-species VMR profiles to the fused state (host step of the refresh)"""
+        """hand the per-species VMR profiles to the fused state, once per loop: the profiles of species with a constant
+        or file-given mixing ratio never change, those of FastChem species are re-interpolated on the device at every
+        refresh (`RTBatch.set_species_vmr_table`) -- the values sent here for them are overwritten there"""
         hsfunc.calculate_vmr_for_all_species(quant)
         L, I = _i(quant.nlayer), _i(quant.ninterface)
         vl = np.array([np.asarray(sp.vmr_layer, np.float64)[:L] for sp in quant.species_list])
         vi = np.array([np.asarray(sp.vmr_interface, np.float64)[:I] for sp in quant.species_list])
         quant.rt.set_column_vmr(int(getattr(quant, "rt_col", 0)), vl, vi)
+
+    def _pull_vmr(self, quant):
+        """the mixing-ratio profiles of the last refresh, back onto the species (write.py prints them)"""
+        rt, col = quant.rt, int(getattr(quant, "rt_col", 0))
+        L, I, S = _i(quant.nlayer), _i(quant.ninterface), len(quant.species_list)
+        vl, vi = rt.get("vmr_lay", col).reshape(S, I), rt.get("vmr_int", col).reshape(S, I)
+        for s, sp in enumerate(quant.species_list):
+            if getattr(sp, "source_for_vmr", "") == "FastChem":
+                sp.vmr_layer = np.array(vl[s, :L], quant.fl_prec)
+                if quant.iso == 0:
+                    sp.vmr_interface = np.array(vi[s], quant.fl_prec)
 
     def radiation_loop(self, quant, write=None, read=None, rt_plot=None):
         """iterate to radiative equilibrium (reference computation.py:827-990)"""
@@ -506,7 +523,6 @@ class Compute(object):
             quant.rt = self._make_rt(quant)
         rt = quant.rt
         L = _i(quant.nlayer)
-        fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in quant.species_list)
         self.ctx.timer_start()
         if quant.singlewalk == 1:
             # post-processing run type (computation.py:983-984): one pass -- refresh, 1000*scat+1 sweeps inside one
@@ -525,7 +541,7 @@ class Compute(object):
         while condition1 and condition2 and condition3:
             # work up to the next host-visible event: a refresh that needs host VMRs, a criterion
             # relaxation, the 100-iteration surface-temperature check, or the iteration limit
-            if quant.opacity_mixing == "on-the-fly" and it % 10 == 0 and (it == 0 or fastchem):
+            if quant.opacity_mixing == "on-the-fly" and it == 0:
                 self._push_vmr(quant)
             nxt = min(it + (10 - it % 10), _i(quant.max_nr_iterations) + 1)
             for r in quant.crit_relaxation_numbers:
@@ -611,6 +627,8 @@ class Compute(object):
         quant.dev_T_store.set(rt.get("T_store", col))
         quant.dev_planckband_grid.copy_from_device(rt.device_ptr("planck_grid"), quant.dev_planckband_grid.nbytes)
         quant.T_lay = rt.get("T_lay", col)
+        if quant.opacity_mixing == "on-the-fly":
+            self._pull_vmr(quant)
         # transmission arrays for the post-loop diagnostics come from the per-stage kernel
         self.calculate_transmission(quant)
 
@@ -708,7 +726,6 @@ class Compute(object):
         rt.set_state(0, "dampara", np.array([dampara], np.float64))
         rt.set_state(0, "done", np.zeros(1, np.int32))
         rt.set_convergence_limit(0, quant.rad_convergence_limit)
-        fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in quant.species_list)
         self.ctx.timer_start()
         it, done = 0, 0
         while not done:
@@ -719,16 +736,9 @@ class Compute(object):
                 if it < r < nxt:
                     nxt = int(r)
             nxt = self._stop_for_coupling_output(quant, it, nxt)
-            if quant.opacity_mixing == "on-the-fly" and it % 10 == 0 and fastchem:
-                # mixing ratios follow the profile: once before the adjustment (for the mean molecular mass), once
-                # for the adjusted profile that the refresh sees (computation.py:1030-1036, :1056-1061)
-                self._push_vmr(quant)
-                rt.conv_adjust(it)
-                self._push_vmr(quant)
-                rt.conv_advance(it)
-                rt.conv_run(it + 1, nxt - it - 1)
-            else:
-                rt.conv_run(it, nxt - it)
+            # (the mixing ratios of FastChem species follow the profile on the device: before the adjustment for the mean
+            # molecular mass, and for the adjusted profile in the refresh -- computation.py:1030-1036, :1056-1061)
+            rt.conv_run(it, nxt - it)
             self.report_diagnostics(quant)
             it = nxt
             done = int(rt.get("done")[0])                        # one small D2H per <= 10 iterations

@@ -64,9 +64,11 @@ struct Shared {
     // op: the curve that is stronger at y = 0 (outer fill loop), ip: the other one.  The entries from NY on are constants,
     // (inf, 0): what the padding slots of the run layout read, so that their sum is inf and their weight 0 without a
     // branch or a select (inf + inf = inf, 0 * 0 = 0)
+    // (A and B first: their byte offsets inside the struct are then multiples of 512 and fold into the offset fields of the
+    // paired 64-byte-strided LDS instructions instead of costing an addition per access)
+    double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded rank: sorted sum / abscissa
     Pair op[NTAB_O], ip[NTAB_I];
     double gy[NY];
-    double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded rank: sorted sum / abscissa
 };
 
 struct Lane {

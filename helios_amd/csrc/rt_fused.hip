@@ -537,6 +537,22 @@ int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const doub
     return 0;
 }
 
+// calculate_vmr_for_all_species on the device (host_functions.py:874-910): a species whose mixing ratio is tabulated on the
+// opacity tables' (T, P) grid -- vmr_pretab[p + npress * t], what read.py keeps per FastChem species -- follows the
+// temperatures of every refresh without a host step.  NULL: back to the profiles of hx_rt_set_column_vmr.
+int hx_rt_set_species_vmr_table(hx_rt* rt, int s, const double* vmr_pretab) {
+    if (!rt) return HX_E_ARG;
+    HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
+    HX_REQUIRE(rt->ctx, rt->d.ntemp >= 2 && rt->d.npress >= 2, HX_E_ARG, "a mixing-ratio table needs at least 2 x 2 nodes");
+    Species& sp = rt->species[s];
+    sp.vmr_from_tab = vmr_pretab != nullptr;
+    rt->species_dev_stale = true;
+    if (!vmr_pretab) return 0;
+    const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
+    if (!sp.vmr_tab) RT_ALLOC(sp.vmr_tab, ntp);
+    return h2d(rt, sp.vmr_tab, vmr_pretab, ntp * 8);
+}
+
 static int for_cols(hx_rt* rt, int col, int* c0, int* c1) {
     if (col < 0) { *c0 = 0; *c1 = rt->C; return 0; }
     if (col >= rt->C) return rt_fail(rt, HX_E_ARG, "column index out of range");
@@ -696,7 +712,8 @@ static int upload_species_table(hx_rt* rt) {
     std::vector<int> abs;
     for (int s = 0; s < S; s++) {
         const Species& sp = rt->species[s];
-        sd[s] = SpeciesDev{sp.pretab, sp.scat_cross, sp.weight, sp.absorbing ? 1 : 0, sp.scattering ? 1 : 0,
+        sd[s] = SpeciesDev{sp.pretab, sp.scat_cross, sp.vmr_from_tab ? sp.vmr_tab : nullptr, sp.weight, sp.absorbing ? 1 : 0,
+                           sp.scattering ? 1 : 0,
                            // random overlap unless CIA (computation.py:1343) or one Gauss point per bin (opacity sampling:
                            // condition_for_correlated_k includes ny == 1, kernels.cu:3302)
                            sp.is_h2o ? 1 : 0, (rt->f.kcoeff_mixing_ro && !sp.is_cia && rt->Y != 1) ? 1 : 0,
@@ -1107,7 +1124,8 @@ int hx_rt_conv_adjust(hx_rt* rt, int itervalue) {
             int rc = upload_species_table(rt);
             if (rc) return rc;
             k_rt_mmm_from_vmr<<<dim3(hx_cdiv(rt->L, 64), rt->C), 64, 0, ctx->stream>>>(
-                (const SpeciesDev*)rt->species_dev, rt->d.nspecies, rt->vmr_lay, rt->mmm_lay, rt->L, rt->I);
+                (const SpeciesDev*)rt->species_dev, rt->d.nspecies, rt->vmr_lay, rt->mmm_lay, rt->L, rt->I, rt->T_lay,
+                rt->p_lay, rt->ktemp, rt->d.ntemp, rt->kpress, rt->d.npress);
             HX_LAUNCH_CHECK(ctx);
         }
     }
@@ -1330,6 +1348,11 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
     if (n == "scat_cross_int") return get_plain(rt, rt->scat_cross_int + c * X * I, X * I * 8, out, out_bytes);
     if (n == "g_0_tot_lay") return get_plain(rt, rt->g0_tot_lay + c * X * I, X * L * 8, out, out_bytes);
     if (n == "g_0_tot_int") return get_plain(rt, rt->g0_tot_int + c * X * I, X * I * 8, out, out_bytes);
+    // mixing-ratio profiles as the last refresh used them, [nspecies][ninterface] (layer rows: the first nlayer entries)
+    if ((n == "vmr_lay" || n == "vmr_int") && rt->d.nspecies > 0) {
+        const size_t S = rt->d.nspecies;
+        return get_plain(rt, (n == "vmr_lay" ? rt->vmr_lay : rt->vmr_int) + c * S * I, S * I * 8, out, out_bytes);
+    }
     if (n == "iters_done") return get_plain(rt, rt->iters_done + c, 4, out, out_bytes);
     if (n == "planck_grid")
         return get_plain(rt, rt->planck_grid, (size_t)(rt->d.plancktable_dim + 1) * X * 8, out, out_bytes);
@@ -1500,6 +1523,9 @@ int hx_rt_device_ptr(hx_rt* rt, int col, const char* name, void** out_dptr) {
     else if (n == "meanmolmass_lay") p = rt->mmm_lay + c * I;
     else if (n == "meanmolmass_int") p = rt->mmm_int + c * I;
     else if (n == "planck_grid") p = rt->planck_grid;
+    // band fluxes in the internal layout [bin][interface] (hx_rt_get returns the reference's [interface][bin])
+    else if (n == "F_up_band_n") p = rt->F_up_band_n + c * X * I;
+    else if (n == "F_down_band_n") p = rt->F_down_band_n + c * X * I;
     else if (n == "F_net") p = rt->F_net + c * I;
     else if (n == "F_up_tot") p = rt->F_up_tot + c * I;
     else if (n == "F_down_tot") p = rt->F_down_tot + c * I;

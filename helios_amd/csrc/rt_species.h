@@ -24,9 +24,36 @@ namespace hx {
 struct SpeciesDev {
     const double* pretab;      // [t][p][x][y] flat (reference order) or null
     const double* scat_cross;  // [x] or null
+    const double* vmr_tab;     // mixing ratio on the opacity tables' (T, P) grid, [p + npress * t], or null: profile given by the host
     double weight;             // molar weight
     int absorbing, scattering, is_h2o, ro, in_mu, pad;
 };
+
+// Mixing ratio of a tabulated species at one level: bilinear in (T, log10 P) on the nodes of the opacity tables, clamped to
+// the table edges -- interpolate_grid_to_lay_or_int (host_functions.py:904-910: scipy's RectBivariateSpline(kx = 1,
+// ky = 1) evaluated point by point), in the term order of helios_amd/host_functions.py.  The nodes are searched (no
+// uniform-grid assumption, as in scipy).
+__device__ __forceinline__ int last_node_not_above(const double* grid, int n, double v, bool log_nodes) {
+    int lo = 0, hi = n - 1;  // largest k in [0, n-2] with node(k) <= v (v is clamped into the grid)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        const double node = log_nodes ? log10(grid[mid]) : grid[mid];
+        if (node <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double vmr_from_table(const double* tab, double T, double P, const double* ktemp, int ntemp,
+                                                 const double* kpress, int npress) {
+    const double t = dmin(ktemp[ntemp - 1], dmax(ktemp[0], T));
+    const double p = dmin(log10(kpress[npress - 1]), dmax(log10(kpress[0]), log10(P)));
+    const int it = last_node_not_above(ktemp, ntemp, t, false), ip = last_node_not_above(kpress, npress, p, true);
+    const double t0 = ktemp[it], t1 = ktemp[it + 1], p0 = log10(kpress[ip]), p1 = log10(kpress[ip + 1]);
+    const double ft = (t - t0) / (t1 - t0), fp = (p - p0) / (p1 - p0);
+    const double v00 = tab[ip + npress * it], v10 = tab[ip + npress * (it + 1)], v01 = tab[ip + 1 + npress * it],
+                 v11 = tab[ip + 1 + npress * (it + 1)];
+    return v00 * (1 - ft) * (1 - fp) + v10 * ft * (1 - fp) + v01 * (1 - ft) * fp + v11 * ft * fp;
+}
 
 struct MixArgs {
     int X, Y, L, I, C, S, ntemp, npress, nabs;
@@ -50,7 +77,13 @@ __global__ void k_rt_species_prep(MixArgs a) {
     for (int pass = 0; pass < 2; pass++) {
         const bool lay = pass == 0;
         if (lay && i >= a.L) continue;
-        const double* vmr = (lay ? a.vmr_lay : a.vmr_int) + (size_t)col * a.S * a.I;
+        double* vmr = const_cast<double*>(lay ? a.vmr_lay : a.vmr_int) + (size_t)col * a.S * a.I;
+        const double T = lay ? a.T_lay[(size_t)col * (a.L + 1) + i] : a.T_int[(size_t)col * a.I + i];
+        const double P = lay ? a.p_lay[(size_t)col * a.L + i] : a.p_int[(size_t)col * a.I + i];
+        // calculate_vmr_for_all_species (host_functions.py:874-901) for the species that come with a (T, P) table: the
+        // profile follows the temperatures of this refresh, on the device
+        for (int s = 0; s < a.S; s++)
+            if (a.sp[s].vmr_tab) vmr[(size_t)s * a.I + i] = vmr_from_table(a.sp[s].vmr_tab, T, P, a.ktemp, a.ntemp, a.kpress, a.npress);
         double num = 0.0, tot = 0.0;  // host_functions.py:927-959
         for (int s = 0; s < a.S; s++)
             if (a.sp[s].in_mu) {
@@ -59,8 +92,6 @@ __global__ void k_rt_species_prep(MixArgs a) {
             }
         const double mmm = num / tot * HX_AMU;
         (lay ? a.mmm_lay : a.mmm_int)[(size_t)col * a.I + i] = mmm;
-        const double T = lay ? a.T_lay[(size_t)col * (a.L + 1) + i] : a.T_int[(size_t)col * a.I + i];
-        const double P = lay ? a.p_lay[(size_t)col * a.L + i] : a.p_int[(size_t)col * a.I + i];
         (lay ? a.tp_lay : a.tp_int)[(size_t)col * a.I + i] = locate_tp(T, P, a.ktemp, a.ntemp, a.kpress, a.npress, false, false);
         double* fac = (lay ? a.fac_lay : a.fac_int) + ((size_t)col * a.I + i) * a.S;
         for (int s = 0; s < a.S; s++) {
@@ -71,11 +102,18 @@ __global__ void k_rt_species_prep(MixArgs a) {
 }
 
 // mean molecular mass of the layers only (the convection loop refreshes it ahead of the adjustment, computation.py:1030-1036)
-__global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, const double* __restrict__ vmr_lay,
-                                  double* __restrict__ mmm_lay, int L, int I) {
+// (the mixing ratios of tabulated species are brought up to the present layer temperatures first, :1035)
+__global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, double* __restrict__ vmr_lay,
+                                  double* __restrict__ mmm_lay, int L, int I, const double* __restrict__ T_lay,
+                                  const double* __restrict__ p_lay, const double* __restrict__ ktemp, int ntemp,
+                                  const double* __restrict__ kpress, int npress) {
     const int col = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L) return;
-    const double* vmr = vmr_lay + (size_t)col * S * I;
+    double* vmr = vmr_lay + (size_t)col * S * I;
+    for (int s = 0; s < S; s++)
+        if (sp[s].vmr_tab)
+            vmr[(size_t)s * I + i] = vmr_from_table(sp[s].vmr_tab, T_lay[(size_t)col * (L + 1) + i], p_lay[(size_t)col * L + i],
+                                                    ktemp, ntemp, kpress, npress);
     double num = 0.0, tot = 0.0;
     for (int s = 0; s < S; s++)
         if (sp[s].in_mu) {

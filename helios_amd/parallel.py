@@ -60,31 +60,55 @@ class WorkList:
         return cols
 
 
+class _DeviceView(object):
+    """a strided view of device memory owned by the library, for torch.as_tensor (the CUDA array interface)"""
+
+    def __init__(self, ptr, shape, strides_bytes):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 3,
+                                         "strides": tuple(int(v) for v in strides_bytes)}
+
+
+def emission_spectra_on_device(rt, ncol=None):
+    """the top-of-atmosphere upward band fluxes of the batch's columns as ONE torch tensor on the GPU, [ncol, nbin],
+    copied out of the library's band array on the device (internal layout [column][bin][interface]: the spectrum is the
+    last interface of every bin) -- no host round trip between the iteration and the gather.  The caller has synchronised
+    the library's stream."""
+    import torch
+    ncol = rt.ncol if ncol is None else int(ncol)
+    X, I = rt.nbin, rt.ninterface
+    base = rt.device_ptr("F_up_band_n", 0).value
+    view = _DeviceView(base + 8 * (I - 1), (ncol, X), (8 * X * I, 8 * I))
+    return torch.as_tensor(view, device="cuda").contiguous()
+
+
 def gather_spectra(local, dist=None, device=None, columns=None):
-    """all-gather per-column output vectors: local [ncol_local, n] -> [ncol_total, n] on every rank.
+    """all-gather per-column output vectors: local [ncol_local, n] -> [ncol_total, n] on every rank (a numpy array).
+    `local` is a numpy array or a torch tensor; a tensor that already lives on the collective's device (`device="cuda"`
+    for RCCL) is gathered from there -- padded, exchanged and trimmed on the GPU, one copy to the host at the end.
     Column counts may differ between ranks (padding to the maximum, then trimming).  `columns`: the global indices of
     the local rows (default: ranks hold consecutive blocks in rank order); the result is in global column order."""
-    local = np.ascontiguousarray(local, dtype=np.float64)
+    is_tensor = not isinstance(local, np.ndarray) and hasattr(local, "detach")
     if dist is None or not dist.is_initialized():
-        return local
+        return local.detach().cpu().numpy() if is_tensor else np.ascontiguousarray(local, dtype=np.float64)
     import torch
     world = dist.get_world_size()
     dev = device if device is not None else "cpu"
+    t = local.detach() if is_tensor else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    t = t.to(dev, torch.float64)
     shapes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(shapes, torch.tensor([local.shape[0], local.shape[1] if local.ndim == 2 else 0],
-                                         dtype=torch.int64, device=dev))
+    dist.all_gather(shapes, torch.tensor([t.shape[0], t.shape[1] if t.dim() == 2 else 0], dtype=torch.int64, device=dev))
     counts = [int(c[0].item()) for c in shapes]
     width = max(int(c[1].item()) for c in shapes)       # a rank of a dynamic sweep may have claimed nothing
-    if local.shape[0] == 0:
-        local = np.zeros((0, width))
+    n = t.shape[0]
     nmax = max(counts)
-    pad = np.zeros((nmax, width + 1))                   # last entry of a row: its global column index
-    pad[:local.shape[0], :-1] = local
-    pad[:local.shape[0], -1] = -1.0 if columns is None else np.asarray(columns, np.float64)
-    mine = torch.from_numpy(pad).to(dev)
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    rows = np.concatenate([o.cpu().numpy()[:n] for o, n in zip(out, counts)], axis=0)
+    pad = torch.zeros((nmax, width + 1), dtype=torch.float64, device=dev)   # last entry of a row: its global column index
+    if n:
+        pad[:n, :-1] = t
+        pad[:n, -1] = -1.0 if columns is None else torch.as_tensor(np.asarray(columns, np.float64), device=dev)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    rows = torch.cat([o[:k] for o, k in zip(out, counts)], dim=0).cpu().numpy()
     if columns is None:
         return rows[:, :-1]
     order = np.argsort(rows[:, -1].astype(np.int64), kind="stable")

@@ -104,6 +104,12 @@ class RTBatch(object):
         self._ck(self._l.hx_rt_set_species(self.handle, s, _dp(p), _dp(q), float(weight), int(is_h2o),
                                            int(is_cia), int(in_mu)), "hx_rt_set_species")
 
+    def set_species_vmr_table(self, s, vmr_pretab):
+        """the species' mixing ratio on the opacity tables' (T, P) grid, [p + npress * t]: its profile follows the
+        temperatures on the device at every refresh (None: back to the profiles of set_column_vmr)"""
+        t = _f64(vmr_pretab)
+        self._ck(self._l.hx_rt_set_species_vmr_table(self.handle, s, _dp(t)), "hx_rt_set_species_vmr_table")
+
     def set_column_profile(self, col, p_lay, p_int, T_lay, surf_albedo=None, starflux=None):
         arrs = [_f64(a) for a in (p_lay, p_int, T_lay, surf_albedo, starflux)]
         self._ck(self._l.hx_rt_set_column_profile(self.handle, col, *[_dp(a) for a in arrs]),
@@ -202,6 +208,7 @@ class RTBatch(object):
             "kappa_lay": (L, np.float64), "kappa_int": (L + 1, np.float64), "c_p_lay": (L, np.float64),
             "F_smooth_sum": (L, np.float64), "F_add_heat_lay": (L, np.float64), "F_add_heat_sum": (L, np.float64),
             "planck_grid": ((self.dims.plancktable_dim + 1) * X, np.float64),
+            "vmr_lay": (max(1, self.dims.nspecies) * I, np.float64), "vmr_int": (max(1, self.dims.nspecies) * I, np.float64),
         }
         return table[name]
 

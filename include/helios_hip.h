@@ -366,6 +366,11 @@ int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opa
  * (computation.py:1343); in_mu = contributes to the mean molecular mass (host_functions.py:940) */
 int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const double* scat_cross,
                       double weight, int is_h2o, int is_cia, int in_mu);
+/* A6 on the device: calculate_vmr_for_all_species + interpolate_grid_to_lay_or_int (source/host_functions.py:874-910).
+ * vmr_pretab[p + npress * t] on the opacity tables' (T, P) grid, as source/read.py keeps it per FastChem species
+ * (Species.vmr_pretab); the species' profile is then interpolated at every refresh from the device's temperatures,
+ * bilinear in (T, log10 P), clamped at the table edges.  NULL returns the species to hx_rt_set_column_vmr's profiles. */
+int hx_rt_set_species_vmr_table(hx_rt* rt, int s, const double* vmr_pretab);
 /* per-column host inputs; col < 0 broadcasts to all columns.  vmr_* : [nspecies][nlayer] / [nspecies][ninterface] */
 int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const double* p_int,
                              const double* T_lay, const double* surf_albedo,
