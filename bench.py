@@ -391,7 +391,8 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
     return roofline
 
 
-def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", profile_steps=20, steady_state=False):
+def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", profile_steps=20, steady_state=False,
+            device_warmup_ms=25.0):
     """one workload on this rank's GPU: W warm-up steps, K timed steps between barriers (max over ranks), roofline
     passes, the gather of the emission spectra.  Returns the fields of its line."""
     import torch
@@ -438,7 +439,7 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
     # after 45 0.417 ms, after 205 0.417 ms at config 2).  Whole decades, so that the timed window sees the opacity
     # refreshes where it would have seen them; reported as device_warmup_iterations.
     device_warmup = 0
-    while time.perf_counter() - tw < 0.025 and device_warmup < 200:
+    while time.perf_counter() - tw < device_warmup_ms * 1e-3 and device_warmup < 200:
         run(warmup + device_warmup, 10)
         ctx.synchronize()
         device_warmup += 10
@@ -536,6 +537,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--allow-debug-knobs", action="store_true")
+    ap.add_argument("--device-warmup-ms", type=float, default=25.0,
+                    help="untimed decades of iterations are added to the warm-up until the device has been busy this long "
+                         "(0: exactly --warmup iterations, so that two runs do the same iterations)")
     ap.add_argument("--phase", default="radiative", choices=["radiative", "convection"],
                     help="which loop a step is taken from: radiation_loop (default, the headline number) or "
                          "convection_loop (convective adjustment + sweeps + temperature step, all on the device)")
@@ -583,7 +587,7 @@ def main():
     seed = 20240 + 2
     ctx = Context(device_index)
     head = measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase=args.phase, profile_steps=args.profile_steps,
-                   steady_state=True)
+                   steady_state=True, device_warmup_ms=args.device_warmup_ms)
     line = {"metric": "rad-conv iterations/sec x (lambda-bins x layers)", "value": head.pop("value"),
             "unit": head.pop("unit"), "n_gpus": world, "steps": head.pop("steps"), "warmup": head.pop("warmup"),
             "device_warmup_iterations": head.pop("device_warmup_iterations"), "ms_per_step": head.pop("ms_per_step"),
@@ -604,7 +608,7 @@ def main():
         hx_ = bool(wx.get("nspecies")) and wx["nbin"] >= 5000
         try:
             r = measure(ctx, ranks, x, wx.get("columns_per_gpu", 1), 20 if hx_ else 100, 10, seed,
-                        profile_steps=args.profile_steps)
+                        profile_steps=args.profile_steps, device_warmup_ms=args.device_warmup_ms)
         except Exception as e:   # the headline above is measured and stands; a secondary that could not run says why
             r = {"error": "%s: %s" % (type(e).__name__, e)}   # (measure() lets the ranks agree on a failed set-up first)
         sec[x] = r

@@ -295,7 +295,7 @@ __device__ __forceinline__ double shfl(int addr, double x) {  // the value of la
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ int padded(int w) { return w + (w >> 3); }
+__device__ __forceinline__ constexpr int padded(int w) { return w + (w >> 3); }
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_or_zero(double x) {  // the DPP-selected lane's value, 0.0 where there is none
@@ -530,6 +530,11 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     for (int r = 0; r < SLOTS; r++) csum += g[r];
     double run = wave_inclusive_sum(csum) - csum;
     sync();  // every lane has fetched its (K, g): A and B change meaning
+    // the abscissae go to LDS at pitch 9 per lane (conflict-free stores); the ninth cell of a lane takes the NEXT lane's first
+    // abscissa, so that the image is a gap-free ascending array and the search below needs no index arithmetic
+    const double y_first = fma(0.5, g[0], run);
+    const double y_next = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(y_first), 0x130, 0xF, 0xF, false),
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(y_first), 0x130, 0xF, 0xF, false));  // wave_shl:1
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
         const int w = SLOTS * lane + r;
@@ -539,6 +544,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         }
         run += g[r];
     }
+    if (SLOTS * lane < N) sh.B[9 * lane + SLOTS] = y_next;  // (lane 49: the padding's abscissa, the total weight, above every Gauss point)
     sync();
     RO_MARK("search");
     // re-binning (:3379-3396): first w >= 1 with Y_w > y_q, at most one Gauss point per w
@@ -546,14 +552,20 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     double yq = 0.0;
     if (lane < NY) {
         yq = sh.gy[lane];
-        // lower bound over w = 1 ... 399 with lengths known at compile time: ten dependent LDS reads, no loop control
-        int base = 1;
+        // lower bound over the padded indices 1 ... 449 (w = 1 ... 399 and the duplicates) with lengths known at compile
+        // time: ten dependent LDS reads at immediate offsets from one running byte offset -- compare, add, select per step
+        constexpr int NP = padded(N - 1) + 1;   // 449
+        const char* Bb = (const char*)sh.B;
+        unsigned pb = 8;
 #pragma unroll
-        for (int len = N - 1; len > 1; len -= len / 2) {
-            const int probe = base + len / 2 - 1;
-            base = sh.B[padded(probe)] > yq ? base : probe + 1;
+        for (int len = NP; len > 1; len -= len / 2) {
+            const int half = len / 2;
+            pb = *(const double*)(Bb + pb + 8 * (half - 1)) > yq ? pb : pb + 8 * half;
         }
-        w = base + (sh.B[padded(base)] > yq ? 0 : 1);
+        pb += *(const double*)(Bb + pb) > yq ? 0u : 8u;
+        const unsigned pi = pb >> 3;
+        w = (int)(pi - (__umul24(pi, 7282u) >> 16));     // padded index -> rank: minus pi / 9 (exact below 512); a duplicate cell
+                                                // 9 l + 8 gives 8 l + 8, the rank it stands for
     }
     // a Gauss point that falls into the interval of its predecessor takes the next one (the reference's walk advances w
     // before it looks at the next point, and reports a malfunction, :3383-3387): w'_q = max over j <= q of (w_j + q - j)

@@ -51,7 +51,17 @@ def rel(x, y):
 
 
 def compare_snap(a, b):
-    return {"T_lay": float(np.abs(np.asarray(a["T_lay"]) / np.asarray(b["T_lay"]) - 1.0).max()),
+    # where the temperatures differ most: the flux divergence F_net[i] - F_net[i+1] that drove the layer's last step, on
+    # both sides, in units of the largest net flux (a divergence at the rounding level of the totals is amplified by the
+    # pseudo-time step, dT ~ |dF|^0.1, kernels.cu:2694-2698)
+    Ta, Tb = np.asarray(a["T_lay"], float), np.asarray(b["T_lay"], float)
+    L = len(Ta) - 1
+    i = int(np.argmax(np.abs(Ta[:L] / Tb[:L] - 1.0)))
+    fa, fb = np.asarray(a["F_net"], float), np.asarray(b["F_net"], float)
+    scale = max(np.abs(fb).max(), 1e-300)
+    worst = {"layer": i, "flux divergence there / max |F_net| (library, reference)": [float((fa[i] - fa[i + 1]) / scale),
+                                                                                    float((fb[i] - fb[i + 1]) / scale)]}
+    return {"T_lay": float(np.abs(Ta / Tb - 1.0).max()), "layer with the largest temperature difference": worst,
             "F_net (of max |F_net|)": rel(a["F_net"], b["F_net"]),
             "F_up_tot": rel(a["F_up_tot"], b["F_up_tot"]), "F_down_tot": rel(a["F_down_tot"], b["F_down_tot"]),
             "emission spectrum (of its maximum)": rel(a["F_up_band_TOA"], b["F_up_band_TOA"]),

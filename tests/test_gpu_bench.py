@@ -130,49 +130,59 @@ def test_bench_secondary_workload_under_a_launcher():
 
 def test_bench_eight_ranks_rehearsal_on_one_gpu():
     """the 8-GPU launch of the driver, rehearsed on this box's one GPU through the gloo hook: eight ranks, each with its own
-    context, column and start profile; per-rank arrays of length 8, the spectra gathered from device tensors in global
-    column order, the process group echoed into the line, and the sharded sweep as secondary workload"""
+    context, column and start profile; per-rank arrays of length 8, the process group echoed into the line, the sharded
+    sweep as secondary workload -- and the spectra, gathered from device tensors, in global column order: the same eight
+    columns as ONE batch in one process give the same per-column checksums in the same order"""
     env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo")
+    common = ["--steps", "10", "--warmup", "10", "--workload", "c2small", "--profile-steps", "0", "--device-warmup-ms", "0",
+              "--no-cpu-baseline"]
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "8", "--steps", "10",
-                        "--warmup", "10", "--workload", "c2small", "--secondary", "c4small", "--profile-steps", "0"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "8", "--secondary",
+                        "c4small"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     line = _last_json(p.stdout)
     assert line["n_gpus"] == 8 and line["config"]["columns_total"] == 8 and line["config"]["columns_per_gpu"] == 1
     assert len(line["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in line["per_rank_ms_per_step"])
     pg = line["process_group"]
     assert pg["backend"] == "gloo" and pg["world_size"] == 8 and pg["ranks_seen_by_all_gather"] == 8 and pg["rccl_world"] is None
-    # every rank's column starts 1 % hotter than the previous rank's: the gathered spectra are in rank order
     cs = line["spectrum_checksum_per_column"]
-    assert len(cs) == 8 and all(b > a for a, b in zip(cs, cs[1:])), cs
+    assert len(cs) == 8 and len(set(cs)) == 8
     assert abs(sum(cs) - line["spectrum_checksum"]) <= 1e-9 * abs(line["spectrum_checksum"])
     sec = line["secondary"]["c4small"]
     assert sec["config"]["columns_total"] == 48 and len(sec["per_rank_ms_per_step"]) == 8 and sec["spectra_gather_ms"] is not None
     assert len(sec["spectrum_checksum_per_column"]) == 48
+    one = subprocess.run([sys.executable, "bench.py", "--columns-per-gpu", "8", "--secondary", "none"] + common, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    one = _last_json(one.stdout)
+    assert one["config"]["columns_total"] == 8 and one["process_group"] is None
+    for a, b in zip(cs, one["spectrum_checksum_per_column"]):        # column k of the batch = the column of rank k
+        assert abs(a - b) <= 1e-9 * abs(b), (cs, one["spectrum_checksum_per_column"])
 
 
 def test_sweep_work_list_is_exhausted_by_eight_ranks(tmp_path):
-    """HELIOS_SWEEP_PARTITION=dynamic:1 with eight ranks (gloo hook: all on GPU 0) and six columns: every column is claimed
-    exactly once, at least two ranks claim nothing, the spectra arrive in sweep order and equal the one-process sweep"""
+    """HELIOS_SWEEP_PARTITION=dynamic:1 with eight ranks (gloo hook: all on GPU 0) and twelve columns: the ranks claim
+    columns one at a time until the list is exhausted -- every column is run exactly once, by whichever rank got there
+    first -- and the spectra arrive in sweep order and equal the one-process sweep"""
     import numpy as np
     sys.path.insert(0, ROOT)
     import sweep
     base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "20 6 5 11",
             "-number_of_layers", "16", "-maximum_number_of_iterations", "20000", "-name", "wl8",
             "-radiative_equilibrium_criterion", "1e-4", "-convective_adjustment", "no"]
-    spec = "internal_temperature=150,600,1100;f_factor=0.25,0.5"
+    spec = "internal_temperature=150,600,1100;f_factor=0.25,0.4,0.5,0.6"
     cols, spectra = sweep.main(["-sweep", spec] + base + ["-output_directory", str(tmp_path) + "/one/"])
+    assert len(cols) == 12
     env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo", HELIOS_SWEEP_PARTITION="dynamic:1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
                         "--master-addr", "127.0.0.1", "--master-port", "29543", "sweep.py", "-sweep", spec] + base +
                        ["-output_directory", str(tmp_path) + "/eight/"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=1500)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[-6000:]
     assert "Load over 8 ranks" in p.stdout
     z = np.load(os.path.join(str(tmp_path), "eight", "wl8_sweep_spectra.npz"))
     np.testing.assert_allclose(z["F_up_TOA"], spectra, rtol=1e-12)
-    for k in range(6):
+    for k in range(12):
         a = open(os.path.join(str(tmp_path), "one", "wl8_%d" % k, "wl8_%d_tp.dat" % k)).read()
         b = open(os.path.join(str(tmp_path), "eight", "wl8_%d" % k, "wl8_%d_tp.dat" % k)).read()
         assert a == b, k
