@@ -40,7 +40,9 @@ def main():
     ap.add_argument("--T-intern", type=float, default=600.0, help="internal temperature [K]: a hot interior, so that the "
                                                                     "radiative equilibrium is super-adiabatic at depth")
     ap.add_argument("--criterion", type=float, default=1e-8)
-    ap.add_argument("--max-iterations", type=int, default=30000)
+    ap.add_argument("--max-iterations", type=int, default=100000)
+    ap.add_argument("--relax", default="10000,20000", help="iteration counts at which the criterion is relaxed tenfold "
+                                                           "(the reference's default, param.dat:116)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from helios_amd import host_functions as hs
@@ -58,7 +60,9 @@ def main():
     c.rad_convergence_limit = a.criterion
     c.c_p_lay = np.full(c.nlayer, pc.R_UNIV / KAPPA)                # read.py:1178-1180
     ctx = Context(0)
-    q = store_from_case(ctx, c, max_nr_iterations=a.max_iterations, name="c5", convection=1, kappa=KAPPA,
+    relax = tuple(int(float(v)) for v in a.relax.split(",") if v)
+    q = store_from_case(ctx, c, crit_relaxation_numbers=relax, max_nr_iterations=a.max_iterations, name="c5", convection=1,
+                        kappa=KAPPA,
                         on_the_fly=bool(c.get("species")))
     q.T_intern = np.float64(a.T_intern)
     comp = Compute(ctx)
@@ -99,7 +103,7 @@ def main():
         "convective layers": int(conv[:L].sum()),
         "neighbouring convective pairs": int(len(lay)),
         "max |d ln T / d ln p - kappa| / kappa over those pairs": float(np.abs(grad / KAPPA - 1.0).max()) if len(lay) else None,
-        "largest local flux divergence of a radiative layer / F_down (criterion %g)" % a.criterion: float(local.max()) if len(local) else None,
+        "largest local flux divergence of a radiative layer / F_down (criterion at the end %g)" % float(q.rad_convergence_limit): float(local.max()) if len(local) else None,
         "all temperatures and band fluxes finite": bool(np.all(np.isfinite(T)) and np.all(np.isfinite(up)) and np.all(np.isfinite(down))),
         "smallest band flux (up, down, direct)": [float(up.min()), float(down.min()), float(fdir.min())],
         "k-distributions of the last refresh ascending and positive": bool(opl.min() > 0 and np.all(np.diff(opl, axis=2) >= 0)),
@@ -112,7 +116,8 @@ def main():
           and checks["k-distributions of the last refresh ascending and positive"] and dg["ro_rebin_skipped"] == 0
           and (len(lay) == 0 or np.abs(grad / KAPPA - 1.0).max() < 1e-6))
     out = {"workload": w["desc"], "nbin": X, "nlayer": L, "ny": Y, "species": len(q.species_list), "T_intern": a.T_intern,
-           "rad_convergence_limit": a.criterion, "driver": "Compute.radiation_loop + Compute.convection_loop on a Store",
+           "rad_convergence_limit": a.criterion, "criterion_relaxed_tenfold_at": list(relax),
+           "criterion_at_the_end": float(q.rad_convergence_limit), "driver": "Compute.radiation_loop + Compute.convection_loop on a Store",
            "radiation_loop": {"iterations": n_rad, "seconds": rad_s, "ms_per_iteration": rad_s / max(n_rad, 1) * 1e3},
            "convection_loop": {"iterations": n_conv, "seconds": conv_s, "ms_per_iteration": conv_s / max(n_conv, 1) * 1e3},
            "set_up_seconds (tables generated and uploaded, Store allocated)": setup_s,

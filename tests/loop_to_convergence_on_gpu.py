@@ -88,26 +88,23 @@ def library_snapshot(rt, c):
     return out
 
 
-def run_library(ctx, c0, species_tabs, vl, vi, max_iterations, convection):
+def run_library(rt, c0, max_iterations, convection, relax=()):
     """the device-resident loops, one iteration per call so that the discrete state of every iteration can be read"""
     from helios_amd import host_functions as hs
-    from helios_amd.rt import batch_from_case
     L = c0.nlayer
-    species = c0.get("species")
-    rt = batch_from_case(ctx, c0, ncol=1, nspecies=len(species) if species else 0)
-    if species:
-        for k, sp in enumerate(species):
-            rt.set_species(k, species_tabs[k], sp["scat"], sp["weight"], is_h2o=0, is_cia=0, in_mu=1)
-        rt.set_column_vmr(-1, vl, vi)
     rt.build_planck_table(1)
     grid = rt.get("planck_grid")
     rec = dict(abort=[], prefactor=[])
     snaps, at = {}, set(snap_points(max_iterations))
     it, done, jump = 0, 0, False
+    limit = float(c0.rad_convergence_limit)
     t0 = time.perf_counter()
     while not done and not jump and it < max_iterations + 1:
         rt.run(it, 1)
         it += 1
+        if it in relax:                     # computation.py:974-975: the criterion is relaxed when the NEW count is listed
+            limit *= 10.0
+            rt.set_convergence_limit(0, limit)
         rec["abort"].append(rt.get("abort"))
         rec["prefactor"].append(rt.get("delta_t_prefactor"))
         done = int(rt.get("done", 0)[0])
@@ -143,6 +140,9 @@ def run_library(ctx, c0, species_tabs, vl, vi, max_iterations, convection):
                     n = int(rt.get("iters_done", 0)[0])
                     break
                 n += 1
+                if n in relax:              # computation.py:1158-1159
+                    limit *= 10.0
+                    rt.set_convergence_limit(0, limit)
                 crec["conv_layer"].append(rt.get("conv_layer"))
                 crec["marked_red"].append(rt.get("marked_red"))
                 crec["prefactor"].append(rt.get("delta_t_prefactor"))
@@ -154,7 +154,7 @@ def run_library(ctx, c0, species_tabs, vl, vi, max_iterations, convection):
     return out
 
 
-def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, convection):
+def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, convection, relax=()):
     from helios_amd import host_functions as hs
     from helios_amd import phys_const as pc
     X, Y, L, I = c0.nbin, c0.ny, c0.nlayer, c0.nlayer + 1
@@ -212,7 +212,8 @@ def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, conve
 
     t0 = time.perf_counter()
     n_ref, snaps, reason = loop_driver.radiation_loop(ref, c, s, snap_at=snap_points(max_iterations),
-                                                      max_nr_iterations=max_iterations, refresh=refresh, on_iteration=each)
+                                                      max_nr_iterations=max_iterations, refresh=refresh, on_iteration=each,
+                                                      crit_relaxation_numbers=relax)
     out = dict(n_rad=int(n_ref), rad_seconds=time.perf_counter() - t0, rad_snaps=snaps, rad_rec=rec, rad_exit=reason)
     if convection:
         crec = dict(conv_layer=[], marked_red=[], prefactor=[])
@@ -224,7 +225,8 @@ def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, conve
 
         t0 = time.perf_counter()
         n, csnaps, q = loop_driver.convection_loop(ref, hs, c, s, KAPPA, snap_at=snap_points(max_iterations),
-                                                   max_nr_iterations=max_iterations, refresh=refresh, on_iteration=ceach)
+                                                   max_nr_iterations=max_iterations, refresh=refresh, on_iteration=ceach,
+                                                   crit_relaxation_numbers=relax)
         out.update(n_conv=int(n), conv_seconds=time.perf_counter() - t0, conv_snaps=csnaps, conv_rec=crec)
     for b in held:
         b.free()
@@ -234,12 +236,14 @@ def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, conve
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2")
-    ap.add_argument("--max-iterations", type=int, default=6000)
+    ap.add_argument("--max-iterations", type=int, default=100000)
     ap.add_argument("--nbin", type=int, default=0, help="override the workload's number of bins")
     ap.add_argument("--nlayer", type=int, default=0, help="override the workload's number of layers")
     ap.add_argument("--convection", action="store_true", help="radiation loop, then the convection loop from its end state")
     ap.add_argument("--T-intern", type=float, default=0.0, help="internal temperature [K] (convection runs want a hot interior)")
     ap.add_argument("--criterion", type=float, default=0.0, help="rad_convergence_limit (default: the workload's 1e-8)")
+    ap.add_argument("--relax", default="10000,20000", help="iteration counts at which the criterion is relaxed tenfold "
+                                                           "(the reference's default, param.dat:116)")
     ap.add_argument("--skip-reference", action="store_true", help="library only (to look for a suitable column)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -264,7 +268,9 @@ def main():
     X, Y, L, I = c0.nbin, c0.ny, c0.nlayer, c0.nlayer + 1
     ctx = Context(0)
     species = c0.get("species")
-    tabs, d_tabs, vl, vi = [], [], None, None
+    from helios_amd.rt import batch_from_case
+    rt = batch_from_case(ctx, c0, ncol=1, nspecies=len(species) if species else 0)
+    d_tabs, vl, vi = [], None, None
     if species:   # on-the-fly mixing: every k-table once, to the library and -- device-resident -- to the reference
         vl = np.array([np.full(L, sp["vmr"]) for sp in species])
         vi = np.array([np.full(I, sp["vmr"]) for sp in species])
@@ -272,19 +278,21 @@ def main():
             tab = sp["pretab"]
             if isinstance(tab, str):
                 tab = syn.ktable(np.random.default_rng(sp["table_seed"]), X, Y, c0.ktemp, c0.kpress, c0.gauss_y)
-            tabs.append(tab)
+            rt.set_species(k, tab, sp["scat"], sp["weight"], is_h2o=0, is_cia=0, in_mu=1)
             d_tabs.append(lib.buf(tab) if (tab is not None and not a.skip_reference) else None)
-    ours = run_library(ctx, c0, tabs, vl, vi, a.max_iterations, a.convection)
-    del tabs
+            del tab
+        rt.set_column_vmr(-1, vl, vi)
+    relax = tuple(int(float(v)) for v in a.relax.split(",") if v)
+    ours = run_library(rt, c0, a.max_iterations, a.convection, relax)
     out = {"workload": w["desc"], "nbin": int(X), "nlayer": int(L), "T_intern": a.T_intern or 100.0,
-           "rad_convergence_limit": float(c0.rad_convergence_limit),
+           "rad_convergence_limit": float(c0.rad_convergence_limit), "criterion_relaxed_tenfold_at": list(relax),
            "libhelios_hip": {"radiation_loop_iterations": ours["n_rad"], "left_the_loop": ours["rad_exit"],
                              "seconds (one call and four read-backs per iteration)": ours["rad_seconds"]}}
     if a.convection:
         out["libhelios_hip"].update({"convection_loop_iterations": ours["n_conv"], "convection_seconds": ours["conv_seconds"],
                                      "unstable_layers_at_entry": ours["conv_unstable_at_entry"]})
     if not a.skip_reference:
-        theirs = run_reference(lib, c0, d_tabs, vl, vi, ours["grid"], a.max_iterations, a.convection)
+        theirs = run_reference(lib, c0, d_tabs, vl, vi, ours["grid"], a.max_iterations, a.convection, relax)
         for t in d_tabs:
             if t is not None:
                 t.free()
