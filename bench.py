@@ -18,7 +18,7 @@ the N ranks itself (a child `python -m torch.distributed.run ...`, before this p
 
 The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly), config 4 at reduced
 width (8 of the sweep's 512 on-the-fly columns in one batch) and config 5 (30 000 x 200, 20 species on the fly, two cloud
-decks, beam, albedo, I2S); at N > 1 config 4 -- each GPU's share of the 512-column sweep, 64 on-the-fly columns per GPU in
+decks, beam, albedo, I2S) from the radiation loop and from the convection loop; at N > 1 config 4 -- each GPU's share of the 512-column sweep, 64 on-the-fly columns per GPU in
 one batch.  `steady_state_200` is the headline workload over 200
 iterations from iteration 0 (20 refreshes), SURVEY.md 8(d)'s definition of the metric.
 """
@@ -66,6 +66,11 @@ WORKLOADS = {
                     desc="config 3 shape at 1000 bins (quick check)"),
     "c2small": dict(nbin=1000, nlayer=100, ny=20, ntemp=12, npress=10,
                     desc="config 2 shape at 1000 bins (quick check)"),
+    "c5conv": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, nspecies=20, clouds=2, albedo="smoothed", scat_corr=1,
+                   g_0=0.3, dir_beam=1, phase="convection",
+                   desc="BASELINE config 5, one column, steps taken from the CONVECTION loop (convective adjustment of a deep "
+                        "zone, sweeps, layer marking, equilibrium test and temperature step on the device): 30 000 bins x 200 "
+                        "layers, 20 species mixed on the fly, I2S correction, two cloud decks, direct beam, surface albedo"),
     "c4x8": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=8, sweep=True,
                  desc="BASELINE config 4 at reduced width: 8 columns of the 512-column sweep (g x a x T_intern grid) in one "
                       "batch on one GPU, on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
@@ -265,16 +270,76 @@ def cpu_baseline(w, seed):
 
 
 def load_counters(workload):
-    """per-launch counter figures measured with rocprofv3 --pmc in separate passes and committed under profiles/
-    (the bench itself runs without the profiler): (dict, source file) or (None, None)"""
+    """per-launch counter figures: measured live by this run when it could (LIVE_COUNTERS, filled by live_counters()),
+    else those committed under profiles/ from an earlier rocprofv3 --pmc run: (dict, source) or (None, None)"""
+    if workload in LIVE_COUNTERS:
+        return LIVE_COUNTERS[workload]
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, None
-    alias = {"c4": "c3"}      # same kernels on the same column shape: per-column figures scale with the column count
+    alias = {"c4": "c3", "c4x8": "c3"}      # same kernels on the same column shape: per-column figures scale with the column count
     with open(tpath) as f:
         d = json.load(f).get(alias.get(workload, workload))
     src = "profiles/traffic.json" + (" (per column, measured on %s)" % alias[workload] if workload in alias else "")
     return (d, src) if d else (None, None)
+
+
+LIVE_COUNTERS = {}
+
+
+def live_counters(workload, counters=("FETCH_SIZE", "WRITE_SIZE"), ncol=1):
+    """HBM traffic per launch, measured NOW: this command again as a child under `rocprofv3 --pmc <counter>
+    --kernel-trace`, one pass per counter (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in separate passes, both in KiB,
+    FETCH_SIZE doubled on gfx950), a short run of the same workload without secondaries.  Returns (dict, source) in the
+    form of profiles/traffic.json, or None when the profiler is not there or a pass fails (the committed figures are
+    quoted then, and `traffic_source` says so)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None
+    per = {}
+    with tempfile.TemporaryDirectory(prefix="helios_pmc_") as tmp:
+        for cname in counters:
+            out = os.path.join(tmp, cname)
+            cmd = [prof, "--pmc", cname, "--kernel-trace", "-d", out, "-o", "run", "--", sys.executable,
+                   os.path.abspath(__file__), "--workload", workload, "--steps", "10", "--warmup", "10", "--no-cpu-baseline",
+                   "--profile-steps", "0", "--secondary", "none", "--live-counters", "off", "--device-warmup-ms", "0",
+                   "--columns-per-gpu", str(int(ncol))]
+            env = dict(os.environ, TMPDIR=tmp)
+            try:
+                p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=600)
+            except Exception:
+                return None
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if p.returncode != 0 or not dbs:
+                return None
+            try:
+                db = sqlite3.connect(dbs[0])
+                rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection "
+                                  "where counter_name = ? group by kernel_name", (cname,)).fetchall()
+            except Exception:
+                return None
+            per[cname] = {name: (n, avg) for name, n, avg in rows}
+
+    def pick(key):
+        f = [v for k, v in per.get("FETCH_SIZE", {}).items() if key in k]
+        w = [v for k, v in per.get("WRITE_SIZE", {}).items() if key in k]
+        if not f or not w:
+            return None, None
+        return (2.0 * f[0][1] + w[0][1]) * 1024.0, f[0][0]
+    flux, nflux = pick("k_rt_flux")
+    mix, nmix = pick("k_rt_mix_species")
+    valu = [v for k, v in per.get("SQ_INSTS_VALU", {}).items() if "k_rt_mix_species" in k]
+    d = dict(rt_flux_hbm_bytes_per_launch=flux, rt_mix_hbm_bytes_per_launch=mix,
+             rt_mix_valu_instructions_per_launch=valu[0][1] if valu else None, launches_counted=nflux or nmix,
+             columns_in_the_measured_batch=int(ncol))
+    src = ("measured in this run: `rocprofv3 --pmc %s --kernel-trace -- python3 bench.py --workload %s --steps 10 ...`, one pass "
+           "per counter, hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half)"
+           % (" | ".join(counters), workload))
+    return d, src
 
 
 def env_knobs(allow_debug):
@@ -353,7 +418,7 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
         achieved = B_E / (flux_ms * 1e-3) / 1e9
         traffic = counters.get("rt_flux_hbm_bytes_per_launch") if counters else None
         if traffic is not None:
-            traffic *= ncol                         # measured with one column per launch
+            traffic *= ncol / float(counters.get("columns_in_the_measured_batch", 1))   # (the committed figures: one column)
         roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
                         frac=achieved / 8000.0, traffic=traffic, traffic_source=counter_source if traffic else None,
                         algorithmic_bytes_per_launch=B_E, actual_bytes_model_per_launch=tm["step_actual"],
@@ -372,12 +437,14 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
         achieved = B_T / (mix_ms * 1e-3) / 1e9
         traffic = counters.get("rt_mix_hbm_bytes_per_launch") if counters else None
         roofline = dict(bound="hbm", kernel="k_rt_mix_species", achieved=achieved, peak=8000.0, unit="GB/s",
-                        frac=achieved / 8000.0, traffic=traffic * ncol if traffic else None,
+                        frac=achieved / 8000.0,
+                        traffic=traffic * ncol / float(counters.get("columns_in_the_measured_batch", 1)) if traffic else None,
                         traffic_source=counter_source if traffic else None,
                         algorithmic_bytes_per_launch=B_T, avg_launch_ms=mix_ms, launches_timed=1)
         valu = counters.get("rt_mix_valu_instructions_per_launch") if counters else None
         if valu:
             peak = 1024 * 2.4e9 / 4.0               # SIMDs x clock / 4 cycles per wave64 instruction
+            valu = valu / float(counters.get("columns_in_the_measured_batch", 1))
             rate = valu * ncol / (mix_ms * 1e-3)
             roofline["valu_issue"] = dict(achieved=rate / 1e9, peak=peak / 1e9, unit="G wavefront-instructions/s",
                                           frac=rate / peak, instructions_per_launch=valu * ncol, source=counter_source)
@@ -532,11 +599,15 @@ def main():
                     help="headline workload (default c2, the configuration the metric is quoted on, at every N)")
     ap.add_argument("--columns-per-gpu", type=int, default=None)
     ap.add_argument("--secondary", default="default",
-                    help="'default' (N = 1: c3,c4x8,c5; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
+                    help="'default' (N = 1: c3,c4x8,c5,c5conv; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
                          "the same run into the line's `secondary` block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--allow-debug-knobs", action="store_true")
+    ap.add_argument("--live-counters", default="headline", choices=["off", "headline", "all"],
+                    help="N = 1 only: measure the HBM traffic (and, for mixing workloads, the vector instructions) per launch "
+                         "in this run -- child passes of this command under rocprofv3 --pmc -- for the headline workload, or "
+                         "for every workload of the line ('all': about a minute more per species workload)")
     ap.add_argument("--device-warmup-ms", type=float, default=25.0,
                     help="untimed decades of iterations are added to the warm-up until the device has been busy this long "
                          "(0: exactly --warmup iterations, so that two runs do the same iterations)")
@@ -560,13 +631,21 @@ def main():
     warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
     ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
     if args.secondary == "default":
-        secondary = (["c3", "c4x8", "c5"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
+        secondary = (["c3", "c4x8", "c5", "c5conv"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
     else:
         secondary = [x for x in args.secondary.split(",") if x and x != "none"]
     for x in secondary:
         if x not in WORKLOADS:
             raise SystemExit("unknown secondary workload %r" % x)
 
+    if world == 1 and args.live_counters != "off":
+        # before this process touches the GPU: the profiler's children have the device to themselves
+        for x in [wname] + (secondary if args.live_counters == "all" else []):
+            species = bool(WORKLOADS[x].get("nspecies"))
+            got = live_counters(x, ("FETCH_SIZE", "WRITE_SIZE") + (("SQ_INSTS_VALU",) if species else ()),
+                                ncol if x == wname else WORKLOADS[x].get("columns_per_gpu", 1))
+            if got is not None:
+                LIVE_COUNTERS[x] = got
     import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
     dist = None
     # test hook for single-GPU machines: HELIOS_BENCH_BACKEND=gloo runs all ranks on GPU 0 with CPU-side collectives,
@@ -608,7 +687,8 @@ def main():
         hx_ = bool(wx.get("nspecies")) and wx["nbin"] >= 5000
         try:
             r = measure(ctx, ranks, x, wx.get("columns_per_gpu", 1), 20 if hx_ else 100, 10, seed,
-                        profile_steps=args.profile_steps, device_warmup_ms=args.device_warmup_ms)
+                        phase=wx.get("phase", "radiative"), profile_steps=args.profile_steps,
+                        device_warmup_ms=args.device_warmup_ms)
         except Exception as e:   # the headline above is measured and stands; a secondary that could not run says why
             r = {"error": "%s: %s" % (type(e).__name__, e)}   # (measure() lets the ranks agree on a failed set-up first)
         sec[x] = r

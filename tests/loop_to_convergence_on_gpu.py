@@ -233,7 +233,7 @@ def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, conve
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--max-iterations", type=int, default=100000)
@@ -246,7 +246,7 @@ def main():
                                                            "(the reference's default, param.dat:116)")
     ap.add_argument("--skip-reference", action="store_true", help="library only (to look for a suitable column)")
     ap.add_argument("--out", default="")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     lib = oracle.refgpu
     if lib is None and not a.skip_reference:
         raise SystemExit("oracle/_ref/libhelios_ref_gfx950.so (or a GPU) is not available")
@@ -335,7 +335,9 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         with open(a.out, "w") as f:
             f.write(text + "\n")
-    print(json.dumps(out))
+    if argv is None:
+        print(json.dumps(out))
+    return out
 
 
 if __name__ == "__main__":

@@ -9,14 +9,14 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O && cd $R
 stats() {   # stats <workload> <bench args...>
   local W=$1; shift
-  rocprofv3 --kernel-trace --stats -d $O/prof_$W -o run -- python3 bench.py --workload $W "$@" --no-cpu-baseline --profile-steps 0 --secondary none > $O/prof_$W.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/prof_$W -o run -- python3 bench.py --workload $W "$@" --no-cpu-baseline --profile-steps 0 --secondary none --live-counters off > $O/prof_$W.log 2>&1
   python3 tools/rocpd_summary.py $(find $O/prof_$W -name "*.db" | head -1) > $O/${W}_kernel_stats.txt 2>&1
   rm -rf $O/prof_$W
 }
 traffic() { # traffic <workload> <bench args...>: FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU in separate passes
   local W=$1; shift
   for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
-    rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${W}_$C -o run -- python3 bench.py --workload $W "$@" --no-cpu-baseline --profile-steps 0 --secondary none > $O/pmc_${W}_$C.log 2>&1
+    rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${W}_$C -o run -- python3 bench.py --workload $W "$@" --no-cpu-baseline --profile-steps 0 --secondary none --live-counters off > $O/pmc_${W}_$C.log 2>&1
   done
   python3 tools/pmc_traffic.py $(find $O/pmc_${W}_FETCH_SIZE -name "*.db" | head -1) $(find $O/pmc_${W}_WRITE_SIZE -name "*.db" | head -1) $W \
       $(find $O/pmc_${W}_SQ_INSTS_VALU -name "*.db" | head -1) > $O/${W}_pmc_traffic.txt 2>&1
@@ -27,10 +27,11 @@ traffic c2 --steps 20 --warmup 10
 traffic c3 --steps 10 --warmup 10
 traffic c5 --steps 10 --warmup 10
 cp profiles/traffic.json $O/traffic.json
-# the driver's line: config 2 as the headline, config 3 and config 5 (20 species on the fly + clouds + beam) live in `secondary`
+# the driver's line: config 2 as the headline (its HBM traffic counted live, in child passes under rocprofv3), config 3, config 4
+# at 8 columns and config 5 (20 species on the fly + clouds + beam) live in `secondary`
 python3 bench.py > $O/bench_n1.json 2> $O/bench.err
 stats c2 --steps 50 --warmup 10
-python3 bench.py --workload c3 > $O/c3_bench.json 2>> $O/bench.err
+python3 bench.py --workload c3 --live-counters all > $O/c3_bench.json 2>> $O/bench.err
 stats c3 --steps 20 --warmup 10
 stats c5 --steps 20 --warmup 10
 python3 bench.py --workload c4 --steps 10 --warmup 10 > $O/c4_bench_64columns.json 2>> $O/bench.err
@@ -39,7 +40,8 @@ python3 bench.py --columns-per-gpu 4 --steps 50 --no-cpu-baseline --secondary no
 python3 bench.py --phase convection --steps 100 --no-cpu-baseline > $O/c2_bench_convection_loop.json 2>> $O/bench.err
 python3 bench.py --workload c5 --steps 20 --warmup 10 > $O/c5_bench.json 2>> $O/bench.err
 python3 bench.py --workload c5premixed --steps 30 --warmup 10 --no-cpu-baseline > $O/c5premixed_bench.json 2>> $O/bench.err
-# two ranks on the one GPU of this box through the gloo hook: the multi-rank path incl. the config-4 share as `secondary`
-HELIOS_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 10 --secondary c4small > $O/bench_2ranks_one_gpu_gloo.json 2>> $O/bench.err
+python3 bench.py --phase convection --workload c5 --steps 20 --warmup 10 --no-cpu-baseline --secondary none --live-counters off > $O/c5_bench_convection_loop.json 2>> $O/bench.err
+# eight ranks on the one GPU of this box through the gloo hook: the multi-rank path incl. the config-4 share as `secondary`
+HELIOS_BENCH_BACKEND=gloo python3 bench.py --gpus 8 --workload c2small --steps 20 --warmup 10 --secondary c4small --no-cpu-baseline > $O/bench_8ranks_one_gpu_gloo.json 2>> $O/bench.err
 for K in generic ktable dominated; do for S in q32 bitonic rank; do HELIOS_RO_SORT=$S python3 tools/ro_bench.py --kind $K --reps 3; done; done > $O/ro_bench.txt 2>&1
 tail -c 400 $O/bench_n1.json
