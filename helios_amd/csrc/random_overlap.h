@@ -53,6 +53,15 @@ constexpr int LDS_N = 512;   // by fill position (<= 511) or by padded rank (399
 // serves as the tie-break of equal quantised sums just as well.  Index PAD holds (inf, 0) for every padding slot.
 constexpr int ROW_PITCH = 21;
 constexpr int PAD = 511;
+// Cells of the two images that no path writes after init: the fill uses the indices 21 i + j <= 418 and PAD, the sorted
+// images the padded ranks <= 449.  They hold the re-binning of a PRESORTED tableau, worked out once per wavefront
+// (prepare_presorted): rank w of such a tableau is cell (w / 20, w % 20) whatever the two curves are, so the weights in rank
+// order, their abscissae and the pair of ranks that brackets each Gauss point do not depend on the problem.  For Gauss
+// point q: A[PRE_Y + q], B[PRE_Y + q] = abscissae of the two ranks; the 64 bits of A[PRE_C + q] = LDS byte offsets of their
+// cells' table entries (per rank: op entry | ip entry << 16; 0: the walk ran out of sums, :3379-3396); the bits of
+// B[PRE_C] = Gauss points moved on by the reference's walk (:3383-3387) per problem.
+constexpr int PRE_Y = 452, PRE_C = 480;
+static_assert(NY * NY - 1 + (NY * NY - 1) / 8 + 1 < PRE_Y && PRE_Y + NY <= PRE_C && PRE_C + NY <= PAD, "free cells of the images");
 
 constexpr int NTAB_O = 21, NTAB_I = 28;  // table entries per curve: 20 Gauss points, then constants for the padding slots
 
@@ -80,10 +89,6 @@ struct Lane {
     unsigned e0step;       // padded fill position 21 i + j of slot 0 | its step per slot (1 along a row, 21 down a column) << 16
     unsigned ij;           // i | j << 8 of slot 0 | (1 << 16 if i steps, 1 << 24 if j steps): the crossing case's fill positions
     unsigned padlo, padhi; // all ones where the slots 0-3 / 4-7 are padding
-    // the presorted tableau read in rank order (rank w = 8 lane + r is cell (w / 20, w % 20)): offsets of op[w0 / 20] and
-    // ip[w0 % 20] for w0 = 8 lane, and the first slot that belongs to the next row
-    unsigned pa, pb;
-    int wrap;
 };
 
 struct Counters {
@@ -115,17 +120,9 @@ __device__ __forceinline__ void run_lane(Lane& ln, int lane) {
     }
     ln.e0step = (unsigned)(ROW_PITCH * i + j) | (unsigned)(di ? ROW_PITCH : 1) << 16;
     ln.ij = (unsigned)i | (unsigned)j << 8 | (unsigned)di << 16 | (unsigned)dj << 24;
-    const int w0 = 8 * lane;
-    if (w0 < N) {
-        ln.pa = OP + PS * (w0 / NY);
-        ln.pb = IP + PS * (w0 % NY);
-        ln.wrap = NY - w0 % NY;   // slots r >= wrap: next row, column r - wrap
-    } else {
-        ln.pa = OP + PS * NY;
-        ln.pb = IP + PS * NY;
-        ln.wrap = SLOTS;
-    }
 }
+
+__device__ __forceinline__ void prepare_presorted(Shared& sh, int lane);
 
 __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const double* gauss_weight, const double* gauss_y) {
     if (lane < NY) {
@@ -146,6 +143,7 @@ __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const doubl
         sh.A[PAD] = __builtin_inf();
         sh.B[PAD] = 0.0;
     }
+    prepare_presorted(sh, lane);
 }
 
 __device__ __forceinline__ void flush(const Counters& c, int lane, unsigned long long* diag) {
@@ -329,6 +327,103 @@ __device__ __forceinline__ void sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The abscissae of the eight ranks a lane holds (exclusive prefix `run` of the weights before them), and optionally the
+// sums, to LDS at pitch 9 per lane (conflict-free stores); the ninth cell of a lane takes the NEXT lane's first abscissa, so
+// that the image is a gap-free ascending array and the search needs no index arithmetic.  All 64 lanes call.
+template <bool WITH_SUMS>
+__device__ __forceinline__ void put_abscissae(Shared& sh, int lane, const double (&K)[SLOTS], const double (&g)[SLOTS], double run) {
+    const double y_first = fma(0.5, g[0], run);
+    const double y_next = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(y_first), 0x130, 0xF, 0xF, false),
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(y_first), 0x130, 0xF, 0xF, false));  // wave_shl:1
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const int w = SLOTS * lane + r;
+        if (w < N) {
+            if (WITH_SUMS) sh.A[9 * lane + r] = K[r];  // = padded(w)
+            sh.B[9 * lane + r] = fma(0.5, g[r], run);  // = run + 0.5 g bit for bit (0.5 g is exact): one instruction
+        }
+        run += g[r];
+    }
+    if (SLOTS * lane < N) sh.B[9 * lane + SLOTS] = y_next;  // (lane 49: the padding's abscissa, the total weight, above every Gauss point)
+}
+
+// re-binning (:3379-3396): the rank w >= 1 whose abscissa is the first above Gauss point `lane`'s (returned in yq), at most
+// one Gauss point per rank.  All 64 lanes call; lanes >= NY return a rank beyond the sums.
+__device__ __forceinline__ int locate(Shared& sh, int lane, double& yq, unsigned& skipped) {
+    int w = N + lane;  // beyond the Gauss points: ascending, so that no skip is seen there
+    yq = 0.0;
+    if (lane < NY) {
+        yq = sh.gy[lane];
+        // lower bound over the padded indices 1 ... 449 (w = 1 ... 399 and the duplicates) with lengths known at compile
+        // time: ten dependent LDS reads at immediate offsets from one running byte offset -- compare, add, select per step
+        constexpr int NP = padded(N - 1) + 1;   // 449
+        const char* Bb = (const char*)sh.B;
+        unsigned pb = 8;
+#pragma unroll
+        for (int len = NP; len > 1; len -= len / 2) {
+            const int half = len / 2;
+            pb = *(const double*)(Bb + pb + 8 * (half - 1)) > yq ? pb : pb + 8 * half;
+        }
+        pb += *(const double*)(Bb + pb) > yq ? 0u : 8u;
+        const unsigned pi = pb >> 3;
+        w = (int)(pi - (__umul24(pi, 7282u) >> 16));     // padded index -> rank: minus pi / 9 (exact below 512); a duplicate cell
+                                                // 9 l + 8 gives 8 l + 8, the rank it stands for
+    }
+    // a Gauss point that falls into the interval of its predecessor takes the next one (the reference's walk advances w
+    // before it looks at the next point, and reports a malfunction, :3383-3387): w'_q = max over j <= q of (w_j + q - j)
+    int wq = w;
+    const int wprev = __shfl_up(w, 1);
+    if (__ballot(lane >= 1 && lane < NY && w <= wprev) != 0) {  // never seen with Gauss-Legendre points and weights
+        int t = lane < NY ? w - lane : -(1 << 20);
+        for (int d = 1; d < 32; d <<= 1) {
+            const int up = __shfl_up(t, d);
+            if (lane >= d) t = max(t, up);
+        }
+        wq = t + lane;
+        skipped += __popcll(__ballot(lane < NY && wq != w));
+    }
+    return wq;
+}
+
+__device__ __forceinline__ void prepare_presorted(Shared& sh, int lane) {
+    sync();  // the half weights and the Gauss points are in LDS
+    // exactly what mix() does with a tableau it finds presorted -- weights in rank order, their sum per lane, the wave scan,
+    // the abscissae, the interval search, the skip rule -- so that the values kept here are the ones it would compute
+    const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
+    double K[SLOTS], g[SLOTS];
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const int w = SLOTS * lane + r;
+        K[r] = 0.0;
+        g[r] = w < N ? sh.op[w / NY].hw * sh.ip[w % NY].hw : 0.0;
+    }
+    double csum = 0.0;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) csum += g[r];
+    const double run = wave_inclusive_sum(csum) - csum;
+    put_abscissae<false>(sh, lane, K, g, run);
+    sync();
+    double yq;
+    unsigned skipped = 0;
+    const int wq = locate(sh, lane, yq, skipped);
+    double y0 = 0.0, y1 = 0.0;
+    unsigned long long cells = 0ull;
+    if (lane < NY && wq < N) {
+        y0 = sh.B[padded(wq - 1)];
+        y1 = sh.B[padded(wq)];
+        const unsigned c0 = (OP + PS * ((wq - 1) / NY)) | (IP + PS * ((wq - 1) % NY)) << 16;
+        const unsigned c1 = (OP + PS * (wq / NY)) | (IP + PS * (wq % NY)) << 16;
+        cells = (unsigned long long)c1 << 32 | c0;
+    }
+    sync();  // every lane has read its abscissae: the images are free again
+    if (lane < NY) {
+        sh.A[PRE_Y + lane] = y0;
+        sh.B[PRE_Y + lane] = y1;
+        sh.A[PRE_C + lane] = __longlong_as_double((long long)cells);
+    }
+    if (lane == 0) sh.B[PRE_C] = __longlong_as_double((long long)skipped);
+}
+
 // One problem.  Lanes 0..19 pass the running mix and the new absorber's (already scaled) k-coefficients at their Gauss
 // point and receive the mixed value (kernels.cu:3293-3396, ro_method == 1, s > 0, ny == 20).  All 64 lanes must call.
 template <bool MONOTONE, bool CROSSING>
@@ -343,7 +438,7 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
     for (int r = 0; r < SLOTS; r++) {
         const int e = 64 * r + lane;
         double K = __builtin_inf(), g = 0.0;
-        unsigned key = 0xFFFFFE00u | (unsigned)e;
+        unsigned key = 0xFFFFFE00u | (unsigned)PAD;
         if (r < 6 || (r == 6 && lane < N - 6 * 64)) {  // e < 400: every lane for r < 6, 16 lanes for r = 6, none for r = 7
             int aq = 16 * (e / 20), ar = 16 * (e % 20);  // byte offsets of op[e / 20], ip[e % 20]
             if (CROSSING) {  // the curves cross: two fill regions (:3332-3365)
@@ -365,8 +460,10 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
             if (!MONOTONE) q23 = min(q23, 0x7FFFFFu);
             key = q23 << 9 | (unsigned)e;
         }
-        sh.A[e] = K;
-        sh.B[e] = g;
+        // (padding positions share the cell PAD and the all-ones key: the cells above the sums belong to prepare_presorted)
+        const int cell = (r < 6 || (r == 6 && lane < N - 6 * 64)) ? e : PAD;
+        sh.A[cell] = K;
+        sh.B[cell] = g;
         v.k[r] = key;
     }
 }
@@ -450,24 +547,27 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(kmax));
     const int bl = dmax ? 64 - __clzll((long long)dmax) : 0;
     const int sh_bits = bl > 23 ? bl - 23 : 0;
-    double K[SLOTS], g[SLOTS];
     RO_MARK("fill");
     if (monotone && yx == NY && rows_apart) {
-        // nothing to sort: rank w = 8 lane + r is cell (w / 20, w % 20) -- the sums and weights straight from the curves,
-        // no keys, no LDS images
-        const char* base = (const char*)&sh;
-        unsigned pa = ln.pa, pb = ln.pb;
-        int wrap = ln.wrap;
-        asm volatile("" : "+v"(pa), "+v"(pb), "+v"(wrap));
-#pragma unroll
-        for (int r = 0; r < SLOTS; r++) {
-            const bool next_row = r >= wrap;
-            const Pair po = *(const Pair*)(base + pa + (next_row ? (unsigned)sizeof(Pair) : 0u));
-            const Pair pi = *(const Pair*)(base + pb + (unsigned)sizeof(Pair) * r - (next_row ? (unsigned)sizeof(Pair) * NY : 0u));
-            K[r] = po.v + pi.v;
-            g[r] = po.hw * pi.hw;
+        // nothing to sort -- and nothing to scan or to search either: rank w is cell (w / 20, w % 20), the abscissae and
+        // the ranks that bracket each Gauss point are those prepare_presorted() worked out (same arithmetic, same bits)
+        double out = my_mix;
+        if (lane < NY) {
+            const unsigned long long cells = (unsigned long long)__double_as_longlong(sh.A[PRE_C + lane]);
+            if (cells != 0ull) {
+                const char* base = (const char*)&sh;
+                const unsigned c0 = (unsigned)cells, c1 = (unsigned)(cells >> 32);
+                const double K0 = ((const Pair*)(base + (c0 & 0xFFFFu)))->v + ((const Pair*)(base + (c0 >> 16)))->v;
+                const double K1 = ((const Pair*)(base + (c1 & 0xFFFFu)))->v + ((const Pair*)(base + (c1 >> 16)))->v;
+                const double yq = sh.gy[lane], y0 = sh.A[PRE_Y + lane], y1 = sh.B[PRE_Y + lane];
+                out = (K0 * (y1 - yq) + K1 * (yq - y0)) / (y1 - y0);
+            }
         }
-    } else {
+        cnt.skipped += (unsigned)__double_as_longlong(sh.B[PRE_C]);
+        return out;
+    }
+    double K[SLOTS], g[SLOTS];
+    {
         Keys v;
         if (monotone) {
             if (yx == NY) {
@@ -530,56 +630,11 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     for (int r = 0; r < SLOTS; r++) csum += g[r];
     double run = wave_inclusive_sum(csum) - csum;
     sync();  // every lane has fetched its (K, g): A and B change meaning
-    // the abscissae go to LDS at pitch 9 per lane (conflict-free stores); the ninth cell of a lane takes the NEXT lane's first
-    // abscissa, so that the image is a gap-free ascending array and the search below needs no index arithmetic
-    const double y_first = fma(0.5, g[0], run);
-    const double y_next = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(y_first), 0x130, 0xF, 0xF, false),
-                                           __builtin_amdgcn_update_dpp(0, __double2loint(y_first), 0x130, 0xF, 0xF, false));  // wave_shl:1
-#pragma unroll
-    for (int r = 0; r < SLOTS; r++) {
-        const int w = SLOTS * lane + r;
-        if (w < N) {
-            sh.A[9 * lane + r] = K[r];  // = padded(w)
-            sh.B[9 * lane + r] = fma(0.5, g[r], run);  // = run + 0.5 g bit for bit (0.5 g is exact): one instruction
-        }
-        run += g[r];
-    }
-    if (SLOTS * lane < N) sh.B[9 * lane + SLOTS] = y_next;  // (lane 49: the padding's abscissa, the total weight, above every Gauss point)
+    put_abscissae<true>(sh, lane, K, g, run);
     sync();
     RO_MARK("search");
-    // re-binning (:3379-3396): first w >= 1 with Y_w > y_q, at most one Gauss point per w
-    int w = N + lane;  // beyond the Gauss points: ascending, so that no skip is seen there
-    double yq = 0.0;
-    if (lane < NY) {
-        yq = sh.gy[lane];
-        // lower bound over the padded indices 1 ... 449 (w = 1 ... 399 and the duplicates) with lengths known at compile
-        // time: ten dependent LDS reads at immediate offsets from one running byte offset -- compare, add, select per step
-        constexpr int NP = padded(N - 1) + 1;   // 449
-        const char* Bb = (const char*)sh.B;
-        unsigned pb = 8;
-#pragma unroll
-        for (int len = NP; len > 1; len -= len / 2) {
-            const int half = len / 2;
-            pb = *(const double*)(Bb + pb + 8 * (half - 1)) > yq ? pb : pb + 8 * half;
-        }
-        pb += *(const double*)(Bb + pb) > yq ? 0u : 8u;
-        const unsigned pi = pb >> 3;
-        w = (int)(pi - (__umul24(pi, 7282u) >> 16));     // padded index -> rank: minus pi / 9 (exact below 512); a duplicate cell
-                                                // 9 l + 8 gives 8 l + 8, the rank it stands for
-    }
-    // a Gauss point that falls into the interval of its predecessor takes the next one (the reference's walk advances w
-    // before it looks at the next point, and reports a malfunction, :3383-3387): w'_q = max over j <= q of (w_j + q - j)
-    int wq = w;
-    const int wprev = __shfl_up(w, 1);
-    if (__ballot(lane >= 1 && lane < NY && w <= wprev) != 0) {  // never seen with Gauss-Legendre points and weights
-        int t = lane < NY ? w - lane : -(1 << 20);
-        for (int d = 1; d < 32; d <<= 1) {
-            const int up = __shfl_up(t, d);
-            if (lane >= d) t = max(t, up);
-        }
-        wq = t + lane;
-        cnt.skipped += __popcll(__ballot(lane < NY && wq != w));
-    }
+    double yq;
+    const int wq = locate(sh, lane, yq, cnt.skipped);
     RO_MARK("interpolate");
     double out = my_mix;  // w = 400: the walk ran out of sums, the reference leaves the entry as it was
     if (lane < NY && wq < N) {

@@ -63,6 +63,8 @@ def compare_snap(a, b):
                                                                                     float((fb[i] - fb[i + 1]) / scale)]}
     return {"T_lay": float(np.abs(Ta / Tb - 1.0).max()), "layer with the largest temperature difference": worst,
             "F_net (of max |F_net|)": rel(a["F_net"], b["F_net"]),
+            "F_net (of max F_up_tot: the scale of the totals it is the difference of)":
+                float(np.abs(fa - fb).max() / max(np.abs(np.asarray(b["F_up_tot"], float)).max(), 1e-300)),
             "F_up_tot": rel(a["F_up_tot"], b["F_up_tot"]), "F_down_tot": rel(a["F_down_tot"], b["F_down_tot"]),
             "emission spectrum (of its maximum)": rel(a["F_up_band_TOA"], b["F_up_band_TOA"]),
             "abort flags set": [int(np.sum(a["abort"])), int(np.sum(b["abort"]))],
