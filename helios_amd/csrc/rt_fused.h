@@ -133,6 +133,15 @@ struct hx_rt {
     bool has_heating = false;
 
     bool matrix = false;           // hx_rt_flags.matrix
+    // The iteration index lives on the device (iter_dev[0]: index of the next iteration; k_rt_nodes, the first kernel of an
+    // iteration, moves it to iter_dev[1] and increments): the kernels of an iteration then have the SAME arguments every
+    // time, and the nine refresh-free iterations between two opacity refreshes are replayed as one hipGraph where the
+    // launches, not the GPU, bound the loop (small grids: hx_rt_run)
+    int* iter_dev = nullptr;
+    int iter_dev_expected = -1;    // what iter_dev[0] holds as far as the host knows (-1: unknown)
+    hipGraphExec_t iter_graph = nullptr;
+    bool graph_stale = true;       // arguments may have changed since the capture
+    int use_graph = -1;            // -1: decide from the grid size (HELIOS_RT_GRAPH=0|1 overrides), 0 / 1
     std::vector<char> have_albedo; // per column: a surface albedo has been handed over (the matrix method divides by it)
     hx::MatrixArrays mx;
 

@@ -171,6 +171,7 @@ KArgs make_args(hx_rt* rt) {
     a.ktable = rt->opac_k; a.crosstable = rt->opac_scat_cross; a.ktemp = rt->ktemp; a.kpress = rt->kpress;
     a.tp_lay = (const TPIndex*)rt->tp_lay; a.tp_int = (const TPIndex*)rt->tp_int;
     a.ntemp = rt->d.ntemp; a.npress = rt->d.npress; a.from_table = 0;
+    a.iter_dev = rt->iter_dev;
     return a;
 }
 
@@ -367,6 +368,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->H = flags->iso ? rt->L : 2 * rt->L;
     rt->C = dims->ncol;
     rt->have_albedo.assign(dims->ncol, 0);
+    RT_ALLOC(rt->iter_dev, 2);
     // computation.py:531-537: 3*scat+1 sweeps per iteration, 1000*scat+1 in the post-processing run type
     rt->nsweep = (flags->singlewalk ? 1000 : 3) * (flags->scat ? 1 : 0) + 1;
 #ifdef HX_PROFILING
@@ -473,6 +475,7 @@ int hx_rt_destroy(hx_rt* rt) {
     if (!rt) return 0;
     if (rt->ctx) (void)hipStreamSynchronize(rt->ctx->stream);
     ProfScope::flush(rt);
+    if (rt->iter_graph) (void)hipGraphExecDestroy(rt->iter_graph);
     for (void* p : rt->allocs) (void)hipFree(p);
     delete rt;
     return 0;
@@ -482,6 +485,7 @@ int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_d
                    const double* opac_wave, const double* gauss_y, const double* gauss_weight,
                    const double* ktemp, const double* kpress) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int rc = 0;
     rc |= h2d(rt, rt->interwave, opac_interwave, (rt->X + 1) * 8);
     rc |= h2d(rt, rt->deltawave, opac_deltawave, rt->X * 8);
@@ -497,6 +501,7 @@ int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_d
 int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opac_scat_cross,
                               const double* opac_meanmass) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, rt->d.nspecies == 0, HX_E_STATE, "object was created for on-the-fly mixing");
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
     if (!rt->opac_k) {
@@ -515,6 +520,7 @@ int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opa
 int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const double* scat_cross,
                       double weight, int is_h2o, int is_cia, int in_mu) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
     Species& sp = rt->species[s];
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
@@ -542,6 +548,7 @@ int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const doub
 // temperatures of every refresh without a host step.  NULL: back to the profiles of hx_rt_set_column_vmr.
 int hx_rt_set_species_vmr_table(hx_rt* rt, int s, const double* vmr_pretab) {
     if (!rt) return HX_E_ARG;
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
     HX_REQUIRE(rt->ctx, rt->d.ntemp >= 2 && rt->d.npress >= 2, HX_E_ARG, "a mixing-ratio table needs at least 2 x 2 nodes");
     Species& sp = rt->species[s];
@@ -564,6 +571,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
                              const double* T_lay, const double* surf_albedo,
                              const double* starflux) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     const size_t L = rt->L, I = rt->I, X = rt->X;
@@ -598,6 +606,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
 
 int hx_rt_set_column_vmr(hx_rt* rt, int col, const double* vmr_lay, const double* vmr_int) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     HX_REQUIRE(rt->ctx, rt->d.nspecies > 0, HX_E_STATE, "no species in a premixed object");
@@ -617,6 +626,7 @@ int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
                             const double* scat_cross_int, const double* g_0_lay,
                             const double* g_0_int) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     HX_REQUIRE(rt->ctx, rt->f.clouds == 1, HX_E_STATE, "object was created with clouds = 0");
@@ -635,6 +645,7 @@ int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
 int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
                              const double* F_add_heat_sum) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) {
@@ -646,6 +657,7 @@ int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
 
 int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) rc |= h2d(rt, rt->T_lay + (size_t)c * (rt->L + 1), T_lay, (rt->L + 1) * 8);
@@ -654,6 +666,7 @@ int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
 
 int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) {
@@ -666,6 +679,7 @@ int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
 
 int hx_rt_build_planck_table(hx_rt* rt, int energy_correction) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, rt->have_grid, HX_E_STATE, "hx_rt_set_grid first");
     hx_context* ctx = rt->ctx;
     const int X = rt->X, dim = rt->d.plancktable_dim, step = rt->d.plancktable_step;
@@ -866,6 +880,7 @@ int hx_rt_refresh(hx_rt* rt) {
         HX_REQUIRE(ctx, nabs <= MIX_MAX_ABSORBERS, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 48 absorbers");
     }
     KArgs a = make_args(rt);
+    rt->iter_dev_expected = -1;   // k_rt_nodes below moves the device's iteration counter on (hx_rt_step sets it right again)
     {   // interface temperatures (and node Planck values) of the CURRENT layer temperatures
         ProfScope ps(rt, "rt_nodes");
         dim3 grid(hx_cdiv(X, 32), hx_cdiv(rt->H + 3, 32), C);
@@ -1012,21 +1027,38 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         q.step_temperature = step_temperature;
         q.done_w = rt->done;
         q.iters_done = rt->iters_done;
+        q.iter_dev = rt->iter_dev;
         k_rt_totals_b<<<rt->C, 1024, 0, ctx->stream>>>(q);
         HX_LAUNCH_CHECK(ctx);
     }
     return 0;
 }
 
+__global__ void k_rt_set_iteration(int* iter_dev, int next) { iter_dev[0] = next; }
+
+// the device's iteration counter shows `itervalue` as the next iteration (one tiny launch, only when the host's calls were
+// not consecutive: the first iteration of a loop, a restart, a step behind the convection loop)
+static int sync_iteration_counter(hx_rt* rt, int itervalue) {
+    if (rt->iter_dev_expected == itervalue) return 0;
+    k_rt_set_iteration<<<1, 1, 0, rt->ctx->stream>>>(rt->iter_dev, itervalue);
+    HX_LAUNCH_CHECK(rt->ctx);
+    rt->iter_dev_expected = itervalue;
+    return 0;
+}
+
 int hx_rt_step(hx_rt* rt, int itervalue, int step_temperature) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    int rc = sync_iteration_counter(rt, itervalue);
+    if (rc) return rc;
     bool nodes_done = false;
     if (itervalue % 10 == 0 || !rt->refreshed) {  // computation.py:860
-        int rc = hx_rt_refresh(rt);                // (also evaluates the nodes for this iteration)
+        rc = hx_rt_refresh(rt);                    // (also evaluates the nodes for this iteration)
         if (rc) return rc;
         nodes_done = true;
     }
-    return rt_step_kernels(rt, itervalue, step_temperature, nodes_done);
+    rc = rt_step_kernels(rt, itervalue, step_temperature, nodes_done);
+    rt->iter_dev_expected = rc ? -1 : itervalue + 1;   // k_rt_nodes has moved the counter on
+    return rc;
 }
 
 // ---- convection loop (reference computation.py:992-1174) -------------------------------------------------
@@ -1091,6 +1123,7 @@ int hx_rt_kappa_cp_refresh(hx_rt* rt) {
 int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, const double* entr_press,
                           int entr_npress, const double* entr_kappa, const double* entr_c_p) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, entr_ntemp > 1 && entr_npress > 1 && entr_temp && entr_press && entr_kappa && entr_c_p,
                HX_E_ARG, "hx_rt_set_kappa_table: need a (T, P) grid of at least 2 x 2");
     const size_t n = (size_t)entr_ntemp * entr_npress;
@@ -1158,6 +1191,7 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
         nodes_done = true;
     }
     KArgs a = make_args(rt);
+    rt->iter_dev_expected = -1;   // (the convection loop passes its own iteration index; k_rt_nodes still counts)
     if (!nodes_done) {
         ProfScope ps(rt, "rt_nodes");
         dim3 grid(hx_cdiv(rt->X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
@@ -1215,11 +1249,74 @@ int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps) {
     return 0;
 }
 
+// Nine refresh-free iterations as one hipGraph.  Where an iteration is a few microseconds of GPU work (the reference's
+// default problem is 386 bins x 105 layers; BASELINE config 1 is 300 x 50) the loop is bound by the host's four launches
+// per iteration, not by the device; with the iteration index on the device the kernels' arguments never change, so the
+// 36 launches between two opacity refreshes are captured once and replayed with one call.
+constexpr int GRAPH_ITERATIONS = 9;
+
+static bool graph_wanted(hx_rt* rt) {
+    if (rt->use_graph < 0) {
+        // small grids only: from ~10^7 spectral half-layers on, an iteration keeps the device busy for longer than the
+        // host needs to queue the next one
+        rt->use_graph = (double)rt->X * rt->Y * rt->H * rt->C <= 6.0e6 ? 1 : 0;
+        if (const char* e = getenv("HELIOS_RT_GRAPH")) rt->use_graph = atoi(e) != 0 ? 1 : 0;   // tuning knob
+    }
+    // not while the event profiler brackets every launch, not with the per-iteration host decisions of the time-stepped
+    // kappa refresh (computation.py:921-923)
+    return rt->use_graph == 1 && !rt->profiling && !rt->matrix && !(rt->entr_kappa && rt->cols[0].physical_tstep != 0);
+}
+
+static int build_iteration_graph(hx_rt* rt) {
+    hx_context* ctx = rt->ctx;
+    if (rt->iter_graph) {
+        (void)hipGraphExecDestroy(rt->iter_graph);
+        rt->iter_graph = nullptr;
+    }
+    HX_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int n = 0; n < GRAPH_ITERATIONS && !rc; n++) rc = rt_step_kernels(rt, 1, 1, false);   // (the index comes from the device)
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (rc || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        rt->use_graph = 0;   // this batch iterates launch by launch
+        (void)hipGetLastError();
+        return rc;
+    }
+    const hipError_t ei = hipGraphInstantiate(&rt->iter_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) {
+        rt->iter_graph = nullptr;
+        rt->use_graph = 0;
+        (void)hipGetLastError();
+        return 0;
+    }
+    rt->graph_stale = false;
+    return 0;
+}
+
 int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    for (int n = 0; n < nsteps; n++) {
-        int rc = hx_rt_step(rt, itervalue + n, 1);
+    for (int n = 0; n < nsteps;) {
+        const int it = itervalue + n;
+        if (it % 10 == 1 && nsteps - n >= GRAPH_ITERATIONS && rt->refreshed && graph_wanted(rt)) {
+            if (rt->graph_stale || !rt->iter_graph) {
+                int rc = build_iteration_graph(rt);
+                if (rc) return rc;
+            }
+            if (rt->iter_graph) {
+                int rc = sync_iteration_counter(rt, it);
+                if (rc) return rc;
+                HX_HIP(rt->ctx, hipGraphLaunch(rt->iter_graph, rt->ctx->stream));
+                rt->iter_dev_expected = it + GRAPH_ITERATIONS;
+                n += GRAPH_ITERATIONS;
+                continue;
+            }
+        }
+        int rc = hx_rt_step(rt, it, 1);
         if (rc) return rc;
+        n++;
     }
     return 0;
 }
@@ -1429,6 +1526,7 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
 
 int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     const std::string n(name);
     if (n == "keep_down") {
         if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "keep_down expects one int32");

@@ -46,6 +46,7 @@ struct KArgs {
     const TPIndex *tp_lay, *tp_int;  // [C][I] fractional table indices of the levels
     int ntemp, npress, from_table;
     unsigned long long* diag;  // hx_context::diag when the batch runs with debug = 1, else nullptr
+    int* iter_dev;             // [0] index of the next iteration, [1] index of the iteration under way (k_rt_nodes)
 };
 
 // the subset k_rt_flux needs (a leaner argument block keeps its SGPR pressure -- and with it the VGPR
@@ -82,6 +83,13 @@ __host__ __device__ __forceinline__ size_t plane_off(int r, int lane, int ROWS) 
 __global__ void __launch_bounds__(256) k_rt_nodes(KArgs a) {
     __shared__ double tile[32][33];
     const int col = blockIdx.z;
+    // first kernel of every iteration: the iteration counter moves on (one thread of the launch; before the `done` test,
+    // so that it counts launches, not live columns)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && a.iter_dev != nullptr) {
+        const int cur = a.iter_dev[0];
+        a.iter_dev[1] = cur;
+        a.iter_dev[0] = cur + 1;
+    }
     if (a.done[col]) return;
     const int NN = a.H + 3;
     const double* T = a.T_lay + (size_t)col * (a.L + 1);
@@ -964,6 +972,7 @@ struct TotalsBArgs {
     int step_temperature;
     int* done_w;
     int* iters_done;
+    const int* iter_dev;  // the iteration index on the device (see KArgs); nullptr: rt.itervalue
     size_t sL, sL1, sI;
 };
 
@@ -1004,8 +1013,10 @@ __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
     __syncthreads();
     if (!q.step_temperature) return;
     const hx_rt_column cp = a.colpar[col];
-    if (q.rt.itervalue < cp.foreplay) return;
+    const int itervalue = q.iter_dev != nullptr ? q.iter_dev[1] : q.rt.itervalue;
+    if (itervalue < cp.foreplay) return;
     RadTempArgs r = q.rt;
+    r.itervalue = itervalue;
     r.F_down_tot = down;
     r.F_net = net;
     r.F_net_diff += (size_t)col * L;

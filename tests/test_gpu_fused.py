@@ -375,3 +375,42 @@ def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kerne
     assert not comp._fused_supported(Q())
     Q.nlayer = 512
     assert comp._fused_supported(Q())
+
+
+@pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2)])
+def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, name, ncol, monkeypatch):
+    """hx_rt_run replays the nine iterations between two opacity refreshes as ONE hipGraph where launches bound the loop
+    (small grids; HELIOS_RT_GRAPH forces it either way): the iteration index comes from the device, so the captured
+    kernels carry the same arguments every time.  Same kernels, same order, same arguments: the same bits -- after 47
+    iterations in one call (refreshes, four graph replays, a tail of single steps), after a second call that continues
+    from there, and for a batch whose columns differ."""
+    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    T = [c0.T_lay * (1.0 + 0.02 * k) for k in range(ncol)] if ncol > 1 else None
+    from helios_amd.rt import batch_from_case
+
+    def run(graph):
+        monkeypatch.setenv("HELIOS_RT_GRAPH", graph)
+        rt = batch_from_case(ctx, c0, ncol=ncol)
+        try:
+            if T is not None:
+                for k, Tk in enumerate(T):
+                    rt.set_temperatures(k, Tk)
+            rt.build_planck_table(1 if c0.T_star > 10 else 0)
+            rt.run(0, 47)
+            first = [{k: rt.get(k, col) for k in ("T_lay", "F_net", "F_up_band", "delta_t_prefactor", "abort")} for col in range(ncol)]
+            rt.run(47, 24)              # starts mid-decade: single steps up to the refresh, then a replay
+            rt.set_convergence_limit(-1, 1e-3)   # an argument changes: the graph is captured again
+            rt.run(71, 30)
+            second = [{k: rt.get(k, col) for k in ("T_lay", "F_net", "F_up_band", "delta_t_prefactor", "abort", "iters_done")}
+                      for col in range(ncol)]
+            return first, second
+        finally:
+            rt.close()
+    a1, a2 = run("1")
+    b1, b2 = run("0")
+    for got, want in ((a1, b1), (a2, b2)):
+        for col in range(ncol):
+            for k in want[col]:
+                np.testing.assert_array_equal(got[col][k], want[col][k], err_msg="%s column %d" % (k, col))
+    if ncol > 1:
+        assert np.abs(a1[0]["T_lay"] - a1[ncol - 1]["T_lay"]).max() > 1.0
