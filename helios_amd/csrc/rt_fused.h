@@ -137,12 +137,6 @@ struct hx_rt {
     // iteration, moves it to iter_dev[1] and increments): the kernels of an iteration then have the SAME arguments every
     // time, and the nine refresh-free iterations between two opacity refreshes are replayed as one hipGraph where the
     // launches, not the GPU, bound the loop (small grids: hx_rt_run)
-    // small grids (launch-bound iterations): the node Planck values are evaluated in k_rt_flux's prologue and the two levels
-    // of the wavelength totals share one launch -- two launches per iteration instead of four (rt_step_kernels)
-    bool flux_inline_now = false;  // the next launch of k_rt_flux evaluates the nodes itself
-    int fuse_small = -1;           // -1: decide from the grid size (HELIOS_RT_FUSE_SMALL=0|1 overrides), 0 / 1
-    void* inline_nodes = nullptr;  // device copy of hx::InlineNodes
-    int* totals_ticket = nullptr;  // [C] arrival counters of k_rt_totals_ab
     int* iter_dev = nullptr;
     int iter_dev_expected = -1;    // what iter_dev[0] holds as far as the host knows (-1: unknown)
     hipGraphExec_t iter_graph = nullptr;

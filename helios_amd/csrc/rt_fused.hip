@@ -240,7 +240,6 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.F_up_band_n = a.F_up_band_n;
     f.coef_col = a.coef_col; f.flux_col = a.flux_col;
     f.done = a.done;
-    f.inl = rt->flux_inline_now ? (const InlineNodes*)rt->inline_nodes : nullptr;
     const bool generic = rt->generic_scans;
     if (g.k == 16 && !generic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 16>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
@@ -370,7 +369,6 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->C = dims->ncol;
     rt->have_albedo.assign(dims->ncol, 0);
     RT_ALLOC(rt->iter_dev, 2);
-    RT_ALLOC(rt->totals_ticket, dims->ncol);
     // computation.py:531-537: 3*scat+1 sweeps per iteration, 1000*scat+1 in the post-processing run type
     rt->nsweep = (flags->singlewalk ? 1000 : 3) * (flags->scat ? 1 : 0) + 1;
 #ifdef HX_PROFILING
@@ -981,75 +979,20 @@ static int spectral_fluxes(hx_rt* rt, const KArgs& a) {
     return rt->f.debug == 1 ? count_negative_fluxes(rt) : 0;
 }
 
-// Small grids: an iteration is a few microseconds of device work behind four launches of about seven microseconds of host
-// time each -- the loop is bound by the launches.  There the node Planck values are evaluated in k_rt_flux's prologue (a
-// few hundred scattered table reads per bin: affordable exactly where the grid is small) and both levels of the totals
-// share one launch: two launches per iteration, the same arithmetic in the same order.
-static bool fuse_small_wanted(hx_rt* rt) {
-    if (rt->fuse_small < 0) {
-        rt->fuse_small = ((double)rt->X * rt->Y * rt->H * rt->C <= 6.0e6 && rt->nchunk <= 64 && !rt->matrix) ? 1 : 0;
-        if (const char* e = getenv("HELIOS_RT_FUSE_SMALL")) rt->fuse_small = (atoi(e) != 0 && !rt->matrix) ? 1 : 0;   // tuning knob
-        if (rt->fuse_small) {
-            InlineNodes ni;
-            ni.T_lay = rt->T_lay; ni.planck_grid = rt->planck_grid; ni.Bstar = rt->Bstar;
-            ni.T_int = rt->T_int; ni.Bn = rt->Bn; ni.iter_dev = rt->iter_dev;
-            ni.dim = rt->d.plancktable_dim; ni.step = rt->d.plancktable_step;
-            void* p = nullptr;
-            if (hipMalloc(&p, sizeof(ni)) != hipSuccess || h2d(rt, p, &ni, sizeof(ni)) != 0) {
-                rt->fuse_small = 0;
-            } else {
-                rt->allocs.push_back(p);
-                rt->inline_nodes = p;
-            }
-        }
-    }
-    return rt->fuse_small == 1;
-}
-
-static void fill_totals_b_args(hx_rt* rt, TotalsBArgs& q, const KArgs& a, int itervalue, int step_temperature) {
-    q.a = a;
-    memset(&q.rt, 0, sizeof(q.rt));
-    q.rt.F_net_diff = rt->F_net_diff;
-    q.rt.tlay = rt->T_lay;
-    q.rt.play = rt->p_lay;
-    q.rt.pint = rt->p_int;
-    q.rt.abrt = rt->abort_flags;
-    q.rt.T_store = rt->T_store;
-    q.rt.deltat_prefactor = rt->prefactor;
-    q.rt.F_add_heat_lay = rt->F_add_heat_lay;
-    q.rt.F_add_heat_sum = rt->F_add_heat_sum;
-    q.rt.F_smooth = rt->F_smooth;
-    q.rt.F_smooth_sum = rt->F_smooth_sum;
-    q.rt.c_p_lay = rt->c_p_lay;
-    q.rt.conv_count = rt->conv_count;
-    q.rt.itervalue = itervalue;
-    q.rt.nlayer = rt->L;
-    q.rt.smooth = rt->f.smooth;
-    q.rt.dim = rt->d.plancktable_dim;
-    q.rt.step = rt->d.plancktable_step;
-    q.step_temperature = step_temperature;
-    q.done_w = rt->done;
-    q.iters_done = rt->iters_done;
-    q.iter_dev = rt->iter_dev;
-}
-
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
     hx_context* ctx = rt->ctx;
     KArgs a = make_args(rt);
-    const bool fuse = fuse_small_wanted(rt);
-    if (!nodes_done && !fuse) {
+    if (!nodes_done) {
         ProfScope ps(rt, "rt_nodes");
         dim3 grid(hx_cdiv(rt->X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
         k_rt_nodes<<<grid, 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
     }
     {
-        rt->flux_inline_now = fuse && !nodes_done;   // (behind a refresh the nodes are there already)
         int rc = spectral_fluxes(rt, a);
-        rt->flux_inline_now = false;
         if (rc) return rc;
     }
-    if (!fuse) {
+    {
         ProfScope ps(rt, "rt_totals_a");
         k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
@@ -1059,11 +1002,33 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         if (rc) return rc;
     }
     {
-        ProfScope ps(rt, fuse ? "rt_totals_ab" : "rt_totals_b");
+        ProfScope ps(rt, "rt_totals_b");
         TotalsBArgs q;
-        fill_totals_b_args(rt, q, a, itervalue, step_temperature);
-        if (fuse) k_rt_totals_ab<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(q, rt->totals_ticket);
-        else k_rt_totals_b<<<rt->C, 1024, 0, ctx->stream>>>(q);
+        q.a = a;
+        memset(&q.rt, 0, sizeof(q.rt));
+        q.rt.F_net_diff = rt->F_net_diff;
+        q.rt.tlay = rt->T_lay;
+        q.rt.play = rt->p_lay;
+        q.rt.pint = rt->p_int;
+        q.rt.abrt = rt->abort_flags;
+        q.rt.T_store = rt->T_store;
+        q.rt.deltat_prefactor = rt->prefactor;
+        q.rt.F_add_heat_lay = rt->F_add_heat_lay;
+        q.rt.F_add_heat_sum = rt->F_add_heat_sum;
+        q.rt.F_smooth = rt->F_smooth;
+        q.rt.F_smooth_sum = rt->F_smooth_sum;
+        q.rt.c_p_lay = rt->c_p_lay;
+        q.rt.conv_count = rt->conv_count;
+        q.rt.itervalue = itervalue;
+        q.rt.nlayer = rt->L;
+        q.rt.smooth = rt->f.smooth;
+        q.rt.dim = rt->d.plancktable_dim;
+        q.rt.step = rt->d.plancktable_step;
+        q.step_temperature = step_temperature;
+        q.done_w = rt->done;
+        q.iters_done = rt->iters_done;
+        q.iter_dev = rt->iter_dev;
+        k_rt_totals_b<<<rt->C, 1024, 0, ctx->stream>>>(q);
         HX_LAUNCH_CHECK(ctx);
     }
     return 0;

@@ -51,15 +51,6 @@ struct KArgs {
 
 // the subset k_rt_flux needs (a leaner argument block keeps its SGPR pressure -- and with it the VGPR
 // count, which sits at the 256-register / 2-waves-per-SIMD edge -- down)
-// what k_rt_flux needs to evaluate the node Planck values itself (small grids: one launch less per iteration); behind ONE
-// pointer, so that the large-grid kernels' argument block -- and register count -- stays what it was
-struct InlineNodes {
-    const double *T_lay, *planck_grid, *Bstar;
-    double *T_int, *Bn;
-    int* iter_dev;
-    int dim, step;
-};
-
 struct FluxArgs {
     int X, Y, L, I, H;
     int k, nxb, ypb, nparts, G, NW;
@@ -70,7 +61,6 @@ struct FluxArgs {
     double *Utile, *Dtile, *U0, *F_down_band_n, *F_up_band_n;
     size_t coef_col, flux_col;
     const int* done;
-    const InlineNodes* inl;  // nullptr: the node values come from Bn (k_rt_nodes has run)
 };
 
 __device__ __forceinline__ double interface_T(const double* T, int i, int L) {
@@ -86,18 +76,6 @@ __device__ __forceinline__ double interface_T(const double* T, int i, int L) {
 __host__ __device__ __forceinline__ size_t plane_off(int r, int lane, int ROWS) {
     (void)ROWS;
     return (size_t)r * 64 + lane;
-}
-
-// Planck function of bin x at node n of a column (n in [0, H+3): nodes 0..H, then H+1 = stellar row, H+2 = surface)
-__device__ __forceinline__ double node_planck(const double* T, const double* planck_grid, const double* Bstar_col, int n, int x,
-                                              int X, int L, int H, int iso, int dim, int step) {
-    if (n == H + 1) return Bstar_col[x];
-    double Tn;
-    if (n == H + 2) Tn = T[L];
-    else if (iso) Tn = T[min(n, L - 1)];  // isothermal layers: "node" n = layer n (slot H is not used)
-    else if (n & 1) Tn = T[(n - 1) >> 1];
-    else Tn = interface_T(T, n >> 1, L);
-    return planck_lookup(planck_grid, Tn, x, X, dim, step);
 }
 
 // ---- per iteration: interface temperatures + Planck function at every node ------------------
@@ -122,8 +100,20 @@ __global__ void __launch_bounds__(256) k_rt_nodes(KArgs a) {
             a.T_int[(size_t)col * a.I + i] = interface_T(T, i, a.L);
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, x = x0 + tx;
-        if (n < NN && x < a.X)
-            tile[r][tx] = node_planck(T, a.planck_grid, a.Bstar + (size_t)col * a.X, n, x, a.X, a.L, a.H, a.iso, a.dim, a.step);
+        if (n < NN && x < a.X) {
+            double v;
+            if (n == a.H + 1) {
+                v = a.Bstar[(size_t)col * a.X + x];
+            } else {
+                double Tn;
+                if (n == a.H + 2) Tn = T[a.L];
+                else if (a.iso) Tn = T[min(n, a.L - 1)];  // isothermal layers: "node" n = layer n (slot H is not used)
+                else if (n & 1) Tn = T[(n - 1) >> 1];
+                else Tn = interface_T(T, n >> 1, a.L);
+                v = planck_lookup(a.planck_grid, Tn, x, a.X, a.dim, a.step);
+            }
+            tile[r][tx] = v;
+        }
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -662,13 +652,6 @@ template <int ROWS, int K = 0>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = blockIdx.y;
-    // (small grids: this is the first kernel of the iteration -- the iteration counter moves on here, see k_rt_nodes)
-    if (a.inl != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        int* it = a.inl->iter_dev;
-        const int cur = it[0];
-        it[1] = cur;
-        it[0] = cur + 1;
-    }
     if (a.done[col]) return;
     const int bx = blockIdx.x;
     const int NN = a.H + 3, I = a.I;
@@ -679,28 +662,9 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     const size_t nc = (size_t)a.Y * a.X;
     const int k = K ? K : a.k;
 
-    if (a.inl != nullptr) {
-        // the work of k_rt_nodes for this workgroup's bins (same arithmetic): two table rows per node, straight from the
-        // Planck table -- a few hundred scattered 8-byte reads per bin, affordable exactly where the grid is small --
-        // and the rows of Bn that hx_rt_get and the convection loop expect
-        const InlineNodes ni = *a.inl;
-        const double* T = ni.T_lay + (size_t)col * (a.L + 1);
-        if (bx == 0)
-            for (int i = threadIdx.x; i < I; i += blockDim.x) ni.T_int[(size_t)col * I + i] = interface_T(T, i, a.L);
-        for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
-            const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
-            double v = 0.0;
-            if (x < a.X) {
-                v = node_planck(T, ni.planck_grid, ni.Bstar + (size_t)col * a.X, n, x, a.X, a.L, a.H, a.iso, ni.dim, ni.step);
-                ni.Bn[((size_t)col * a.X + x) * NN + n] = v;
-            }
-            sB[t] = v;
-        }
-    } else {
-        for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
-            const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
-            sB[t] = x < a.X ? a.Bn[((size_t)col * a.X + x) * NN + n] : 0.0;
-        }
+    for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
+        const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
+        sB[t] = x < a.X ? a.Bn[((size_t)col * a.X + x) * NN + n] : 0.0;
     }
     for (int t = threadIdx.x; t < a.nxb * 2 * I; t += blockDim.x) acc[t] = 0.0;
     __syncthreads();
@@ -1080,116 +1044,6 @@ __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
     __syncthreads();
     if (threadIdx.x == 0 && *r.conv_count == L + 1) {
         q.done_w[col] = 1;  // the reference leaves radiation_loop once every flag is set
-        q.iters_done[col] = r.itervalue + 1;
-    }
-}
-
-// ---- small grids: both levels of the wavelength totals and the temperature step in ONE launch -------------------------
-// grid (nchunk, C), 256 threads.  Every workgroup forms its chunk's partial sums (k_rt_totals_a's loop); the workgroup that
-// arrives last at the column's ticket adds the partials up and takes the temperature step (k_rt_totals_b's body, the same
-// four-segment tree -- a thread per (direction, interface) slot walks the four segments one after the other).  Same
-// additions in the same order as the two kernels: the same bits.  The fences order the partials against the ticket at
-// device scope (the workgroups run on different XCDs).
-__global__ void __launch_bounds__(256) k_rt_totals_ab(TotalsBArgs q, int* ticket) {
-    const KArgs& a = q.a;
-    const int col = blockIdx.y, chunk = blockIdx.x;
-    if (a.done[col]) return;
-    const int I = a.I, L = a.L;
-    {
-        const int per = (a.X + a.nchunk - 1) / a.nchunk;
-        const int x0 = chunk * per, x1 = min(a.X, x0 + per);
-        const double* __restrict__ fdir = a.F_dir_band_n + (size_t)col * a.X * I;
-        const double* __restrict__ dl = a.deltawave;
-        for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
-            const int dir = t / I, i = t - dir * I;
-            const double* __restrict__ band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
-            double acc = 0.0;
-            for (int xb = x0; xb < x1; xb += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int x = min(xb + u, x1 - 1);
-                    const double f = fdir[(size_t)x * I + i], b = band[(size_t)x * I + i];
-                    v[u] = dir == 0 ? f + b : b;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (xb + u < x1) acc += v[u] * dl[xb + u];
-            }
-            a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
-        }
-    }
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int arrived = atomicAdd(ticket + col, 1);
-        s_last = arrived == a.nchunk - 1 ? 1 : 0;
-        if (s_last) ticket[col] = 0;   // ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    double* up = a.F_up_tot + (size_t)col * I;
-    double* down = a.F_down_tot + (size_t)col * I;
-    double* net = a.F_net + (size_t)col * I;
-    const int cper = (a.nchunk + 3) / 4;
-    for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
-        const double* part = a.tot_part + ((size_t)col * a.nchunk * 2) * I + t;
-        double seg[4];
-#pragma unroll
-        for (int sgm = 0; sgm < 4; sgm++) {
-            const int c0 = sgm * cper, c1 = min(a.nchunk, c0 + cper);
-            double s = 0.0;
-            for (int cb = c0; cb < c1; cb += 8) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(part + (size_t)min(cb + u, max(c1 - 1, 0)) * 2 * I);
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (cb + u < c1) s += v[u];
-            }
-            seg[sgm] = s;
-        }
-        const double tot = ((seg[0] + seg[1]) + seg[2]) + seg[3];
-        if (t < I) down[t] = tot; else up[t - I] = tot;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < I; i += blockDim.x) net[i] = up[i] - down[i];
-    __syncthreads();
-    if (!q.step_temperature) return;
-    const hx_rt_column cp = a.colpar[col];
-    const int itervalue = q.iter_dev != nullptr ? q.iter_dev[1] : q.rt.itervalue;
-    if (itervalue < cp.foreplay) return;
-    RadTempArgs r = q.rt;
-    r.itervalue = itervalue;
-    r.F_down_tot = down;
-    r.F_net = net;
-    r.F_net_diff += (size_t)col * L;
-    r.tlay += (size_t)col * (L + 1);
-    r.play += (size_t)col * L;
-    r.pint += (size_t)col * I;
-    r.abrt += (size_t)col * (L + 1);
-    r.T_store += (size_t)col * (L + 1);
-    r.deltat_prefactor += (size_t)col * (L + 1);
-    r.F_add_heat_lay += (size_t)col * L;
-    r.F_add_heat_sum += (size_t)col * L;
-    r.F_smooth += (size_t)col * L;
-    r.F_smooth_sum += (size_t)col * L;
-    r.c_p_lay += (size_t)col * L;
-    r.meanmolmass_lay = a.mmm_lay + (size_t)col * I;
-    r.conv_count += col;
-    r.foreplay = cp.foreplay;
-    r.g = cp.g;
-    r.physical_tstep = cp.physical_tstep;
-    r.local_limit = cp.rad_convergence_limit;
-    r.adapt_interval = cp.adapt_interval;
-    r.F_intern = cp.F_intern;
-    r.no_atmo = cp.no_atmo;
-    rad_temp_step(r, threadIdx.x, blockDim.x);
-    __syncthreads();
-    if (threadIdx.x == 0 && *r.conv_count == L + 1) {
-        q.done_w[col] = 1;
         q.iters_done[col] = r.itervalue + 1;
     }
 }

@@ -388,9 +388,8 @@ def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, na
     T = [c0.T_lay * (1.0 + 0.02 * k) for k in range(ncol)] if ncol > 1 else None
     from helios_amd.rt import batch_from_case
 
-    def run(graph, fuse="0"):
+    def run(graph):
         monkeypatch.setenv("HELIOS_RT_GRAPH", graph)
-        monkeypatch.setenv("HELIOS_RT_FUSE_SMALL", fuse)
         rt = batch_from_case(ctx, c0, ncol=ncol)
         try:
             if T is not None:
@@ -407,16 +406,11 @@ def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, na
             return first, second
         finally:
             rt.close()
+    a1, a2 = run("1")
     b1, b2 = run("0")
-    # ... and with the small-grid form of the iteration -- node Planck values evaluated in k_rt_flux's prologue, both levels
-    # of the wavelength totals and the temperature step in one launch (HELIOS_RT_FUSE_SMALL): two launches per iteration
-    # instead of four, the same additions in the same order
-    for graph, fuse in (("1", "0"), ("0", "1"), ("1", "1")):
-        a1, a2 = run(graph, fuse)
-        for got, want in ((a1, b1), (a2, b2)):
-            for col in range(ncol):
-                for k in want[col]:
-                    np.testing.assert_array_equal(got[col][k], want[col][k],
-                                                  err_msg="%s column %d (graph %s, fused %s)" % (k, col, graph, fuse))
+    for got, want in ((a1, b1), (a2, b2)):
+        for col in range(ncol):
+            for k in want[col]:
+                np.testing.assert_array_equal(got[col][k], want[col][k], err_msg="%s column %d" % (k, col))
     if ncol > 1:
         assert np.abs(a1[0]["T_lay"] - a1[ncol - 1]["T_lay"]).max() > 1.0
