@@ -20,7 +20,7 @@ GROUPS_=(
 DBS=()
 i=0
 for G in "${GROUPS_[@]}"; do
-  rocprofv3 --pmc $G --kernel-trace -d $O/sq_$i -o $WL -- python3 bench.py --workload $WL --steps 10 --warmup 5 --no-cpu-baseline --profile-steps 0 --secondary none > $O/sq_$i.log 2>&1
+  rocprofv3 --pmc $G --kernel-trace -d $O/sq_$i -o $WL -- python3 bench.py --workload $WL --steps 10 --warmup 5 --no-cpu-baseline --profile-steps 0 --secondary none --live-counters off > $O/sq_$i.log 2>&1
   DB=$(find $O/sq_$i -name "*.db" | head -1)
   [ -n "$DB" ] && DBS+=($DB) || { echo "group $i failed: $G"; tail -5 $O/sq_$i.log; }
   i=$((i+1))

@@ -44,4 +44,8 @@ python3 bench.py --phase convection --workload c5 --steps 20 --warmup 10 --no-cp
 # eight ranks on the one GPU of this box through the gloo hook: the multi-rank path incl. the config-4 share as `secondary`
 HELIOS_BENCH_BACKEND=gloo python3 bench.py --gpus 8 --workload c2small --steps 20 --warmup 10 --secondary c4small --no-cpu-baseline > $O/bench_8ranks_one_gpu_gloo.json 2>> $O/bench.err
 for K in generic ktable dominated; do for S in q32 bitonic rank; do HELIOS_RO_SORT=$S python3 tools/ro_bench.py --kind $K --reps 3; done; done > $O/ro_bench.txt 2>&1
+# shader counters of the mixing kernel: in the species loop of config 3 and on problems that all take the network
+bash tools/pmc_sq.sh $TAG c3 > /dev/null 2>&1
+bash tools/pmc_cmd.sh ${TAG}_ro python3 tools/ro_bench.py --kind ktable > /dev/null 2>&1
+cp $R/gpurun_out/${TAG}_ro/pmc_sq.txt $O/ro_bench_pmc_sq.txt
 tail -c 400 $O/bench_n1.json
