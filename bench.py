@@ -154,6 +154,18 @@ def sweep_column(c, gi):
     return dict(g=g, a=a, F_intern=pc.SIGMA_SB * T_intern ** 4, T_start=max(T_eff, 500.0))
 
 
+_TABLES = {}
+
+
+def _room_for(nbytes):
+    """keep generated tables only where the host has four times their size to spare"""
+    try:
+        import psutil
+        return psutil.virtual_memory().available > 4 * nbytes
+    except Exception:
+        return False
+
+
 def make_batch(ctx, c, ncol, first_column=0, sweep=False):
     from helios_amd.rt import batch_from_case
     sp = c.species
@@ -161,10 +173,18 @@ def make_batch(ctx, c, ncol, first_column=0, sweep=False):
     rt = batch_from_case(ctx, c, ncol=ncol, nspecies=len(sp) if sp else 0, columns=cols)
     if sp:
         from helios_amd import synthetic as syn
+        shape = (c.nbin, c.ny, c.ntemp, c.npress)
+        if _TABLES.get("shape") != shape:       # the synthetic k-tables of the previous workload, kept while the shape stays
+            _TABLES.clear()                     # (config 3 and config 4 share theirs, config 5's two loops theirs)
+            _TABLES["shape"] = shape
         for k, s_ in enumerate(sp):
             tab = s_["pretab"]
             if isinstance(tab, str):
-                tab = syn.ktable(np.random.default_rng(s_["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+                tab = _TABLES.get(s_["table_seed"])
+                if tab is None:
+                    tab = syn.ktable(np.random.default_rng(s_["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+                    if _room_for(tab.nbytes * len(sp)):
+                        _TABLES[s_["table_seed"]] = tab
             rt.set_species(k, tab, s_["scat"], s_["weight"], is_h2o=0, is_cia=0, in_mu=1)
             del tab
         vl = np.array([np.full(c.nlayer, s_["vmr"]) for s_ in sp])
