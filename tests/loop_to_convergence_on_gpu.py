@@ -247,6 +247,9 @@ def main(argv=None):
     ap.add_argument("--relax", default="10000,20000", help="iteration counts at which the criterion is relaxed tenfold "
                                                            "(the reference's default, param.dat:116)")
     ap.add_argument("--skip-reference", action="store_true", help="library only (to look for a suitable column)")
+    ap.add_argument("--reference-twice", action="store_true",
+                    help="run the reference's loop a second time and report how far its two runs are apart (its flux "
+                         "quadrature adds with atomics in arbitrary order)")
     ap.add_argument("--out", default="")
     a = ap.parse_args(argv)
     lib = oracle.refgpu
@@ -295,9 +298,6 @@ def main(argv=None):
                                      "unstable_layers_at_entry": ours["conv_unstable_at_entry"]})
     if not a.skip_reference:
         theirs = run_reference(lib, c0, d_tabs, vl, vi, ours["grid"], a.max_iterations, a.convection, relax)
-        for t in d_tabs:
-            if t is not None:
-                t.free()
         out["reference_kernels_on_this_gpu"] = {"radiation_loop_iterations": theirs["n_rad"], "left_the_loop": theirs["rad_exit"],
                                                 "seconds": theirs["rad_seconds"]}
         out["same_iteration_count"] = ours["n_rad"] == theirs["n_rad"]
@@ -310,6 +310,17 @@ def main(argv=None):
                 for k in sorted(set(ours["rad_snaps"]) & set(theirs["rad_snaps"]) - {"end"})},
             "end states (each side where it left the loop)": compare_snap(ours["rad_snaps"]["end"], theirs["rad_snaps"]["end"]),
         }
+        if a.reference_twice:
+            again = run_reference(lib, c0, d_tabs, vl, vi, ours["grid"], a.max_iterations, False, relax)
+            out["reference_against_itself"] = {
+                "radiation_loop_iterations": [theirs["n_rad"], again["n_rad"]],
+                "first_iteration_with_different_abort_flags": first_difference(again["rad_rec"]["abort"], theirs["rad_rec"]["abort"]),
+                "first_iteration_with_different_time_step_prefactors": first_difference(again["rad_rec"]["prefactor"],
+                                                                                        theirs["rad_rec"]["prefactor"]),
+                "snapshots (second run vs first run, maximum relative difference)": {
+                    str(k): compare_snap(again["rad_snaps"][k], theirs["rad_snaps"][k])
+                    for k in sorted(set(again["rad_snaps"]) & set(theirs["rad_snaps"]) - {"end"})},
+                "end states": compare_snap(again["rad_snaps"]["end"], theirs["rad_snaps"]["end"])}
         if a.convection:
             out["reference_kernels_on_this_gpu"].update({"convection_loop_iterations": theirs["n_conv"],
                                                          "convection_seconds": theirs["conv_seconds"]})
@@ -332,6 +343,9 @@ def main(argv=None):
                                                                                                   theirs["conv_snaps"][k]) for k in both},
                 "end states (each side where it left the loop)": csnap(ours["conv_snaps"]["end"], theirs["conv_snaps"]["end"]),
             }
+    for t in d_tabs:
+        if t is not None:
+            t.free()
     text = json.dumps(out, indent=1)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
