@@ -1,4 +1,7 @@
 #!/bin/bash
+# (round 4 experiment, kept for the record: ab/contract.so was the library with `#pragma clang fp contract(fast)` inside slab_coeffs*,
+#  E_factor and the row loop of k_rt_coef -- the HX_COEF_CONTRACT macro of commit "Random overlap: the abscissae ... contraction measured
+#  and not kept"; the macro is no longer in the tree)
 # coefficient kernel with / without FMA contraction, alternating on one box:  scratch/ab_coef.sh
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
