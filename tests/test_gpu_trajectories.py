@@ -1,12 +1,14 @@
 """Whole runs at size against the reference's kernels on the same GPU, with the trajectory recorded on both sides
 (tests/loop_to_convergence_on_gpu.py): BASELINE config 1 as named (300 x 50, no scattering) and config 2's physics at
-1000 bins x 50 layers, each to radiative equilibrium.  Near the fixed point a layer's flux divergence is at the rounding
-level of the wavelength totals (the reference sums them with atomics in arbitrary order), and the pseudo-time step
-amplifies it (dT ~ |dF|^0.1, kernels.cu:2694-2698): the discrete decisions of two correct implementations -- which
-iteration sets a layer's convergence flag, which adaptation interval shrinks its step -- part long before the loop ends,
-and the trajectories meet again at the equilibrium.  Asserted: both runs leave the loop converged after (nearly) the same
-number of iterations, and the END STATES agree to the north star's 1e-6 -- temperatures, total fluxes, emission spectrum;
-the net flux (a small difference of the totals) on the scale of the totals."""
+1000 bins x 50 layers, each to radiative equilibrium.  Where a layer has no physical flux divergence (the deep layers of
+the isothermal start profile, every layer near the fixed point) F_net[i] - F_net[i+1] is the rounding residue of the
+wavelength totals, which differs between two orders of the same additions (the reference's atomics, the library's fixed
+tree), and the pseudo-time step amplifies it (dT ~ |dF|^0.1, kernels.cu:2694-2698): discrete decisions of two correct
+implementations -- which iteration sets a layer's convergence flag, which adaptation interval shrinks its step -- can part
+before the loop ends, and the trajectories meet again at the equilibrium (DESIGN.md section 2 has the measured numbers,
+also for the reference against itself).  Asserted: both runs leave the loop converged after (nearly) the same number of
+iterations, and the END STATES agree to the north star's 1e-6 -- temperatures, total fluxes, emission spectrum; the first
+flux solve to rounding."""
 import os
 import sys
 
@@ -40,6 +42,5 @@ def test_whole_run_trajectory_vs_the_reference_on_the_gpu(argv):
     assert end["F_up_tot"] < 1e-6 and end["F_down_tot"] < 1e-6, end
     assert end["emission spectrum (of its maximum)"] < 1e-6, end
     assert end["abort flags set"][0] == end["abort flags set"][1] == out["nlayer"] + 1
-    # where the discrete states first differ is recorded, not asserted: it is the reference's own rounding noise that
-    # decides it
+    # where the discrete states first differ is recorded, not asserted: rounding residues decide it
     assert "first_iteration_with_different_abort_flags" in r and "first_iteration_with_different_time_step_prefactors" in r
