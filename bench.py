@@ -175,15 +175,16 @@ def make_batch(ctx, c, ncol, first_column=0, sweep=False):
         from helios_amd import synthetic as syn
         shape = (c.nbin, c.ny, c.ntemp, c.npress)
         if _TABLES.get("shape") != shape:       # the synthetic k-tables of the previous workload, kept while the shape stays
-            _TABLES.clear()                     # (config 3 and config 4 share theirs, config 5's two loops theirs)
-            _TABLES["shape"] = shape
+            on = _TABLES.get("enabled")         # (config 3 and config 4 share theirs, config 5's two loops theirs; single-rank
+            _TABLES.clear()                     # runs only: eight ranks would each hold 19 GB of host memory)
+            _TABLES["shape"], _TABLES["enabled"] = shape, on
         for k, s_ in enumerate(sp):
             tab = s_["pretab"]
             if isinstance(tab, str):
                 tab = _TABLES.get(s_["table_seed"])
                 if tab is None:
                     tab = syn.ktable(np.random.default_rng(s_["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
-                    if _room_for(tab.nbytes * len(sp)):
+                    if _TABLES.get("enabled") and _room_for(tab.nbytes * len(sp)):
                         _TABLES[s_["table_seed"]] = tab
             rt.set_species(k, tab, s_["scat"], s_["weight"], is_h2o=0, is_cia=0, in_mu=1)
             del tab
@@ -330,7 +331,8 @@ def live_counters(workload, counters=("FETCH_SIZE", "WRITE_SIZE"), ncol=1):
                    "--columns-per-gpu", str(int(ncol))]
             env = dict(os.environ, TMPDIR=tmp)
             try:
-                p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=600)
+                p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True,
+                                   timeout=900 if WORKLOADS[workload].get("nspecies") else 240)
             except Exception:
                 return None
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
@@ -681,6 +683,7 @@ def main():
         else:
             dist.init_process_group(backend)
     ranks = Ranks(dist, world, rank, coll_device)
+    _TABLES["enabled"] = world == 1 and len(secondary) > 1
 
     from helios_amd.device import Context
     seed = 20240 + 2
