@@ -60,8 +60,13 @@ constexpr int PAD = 511;
 // point q: A[PRE_Y + q], B[PRE_Y + q] = abscissae of the two ranks; the 64 bits of A[PRE_C + q] = LDS byte offsets of their
 // cells' table entries (per rank: op entry | ip entry << 16; 0: the walk ran out of sums, :3379-3396); the bits of
 // B[PRE_C] = Gauss points moved on by the reference's walk (:3383-3387) per problem.
-constexpr int PRE_Y = 452, PRE_C = 480;
-static_assert(NY * NY - 1 + (NY * NY - 1) / 8 + 1 < PRE_Y && PRE_Y + NY <= PRE_C && PRE_C + NY <= PAD, "free cells of the images");
+constexpr int PRE_Y = 470, PRE_C = 490;
+// The network's positions 0 ... 15 hold LOW padding (it sorts in front of every sum), so that the left half of the network
+// -- rows 0 ... 11 of the tableau, see run_lane -- is exactly 256 positions: rank w sits at position RANK0 + w.
+constexpr int RANK0 = 16;
+constexpr int LOWPAD = 510;   // cell of the low padding: (-inf, 0); PAD holds (inf, 0)
+static_assert(RANK0 + NY * NY - 1 + (RANK0 + NY * NY - 1) / 8 + 1 < PRE_Y && PRE_Y + NY <= PRE_C && PRE_C + NY <= LOWPAD,
+              "free cells of the images");
 
 constexpr int NTAB_O = 21, NTAB_I = 28;  // table entries per curve: 20 Gauss points, then constants for the padding slots
 
@@ -75,7 +80,8 @@ struct Shared {
     // branch or a select (inf + inf = inf, 0 * 0 = 0)
     // (A and B first: their byte offsets inside the struct are then multiples of 512 and fold into the offset fields of the
     // paired 64-byte-strided LDS instructions instead of costing an addition per access)
-    double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded rank: sorted sum / abscissa
+    double A[LDS_N], B[LDS_N];  // by fill position: pair sum / weight; later by padded position: sorted sum / abscissa
+    Pair oplow[4];              // op[-4 ... -1]: (-inf, 0), what the low padding in front of a column piece reads
     Pair op[NTAB_O], ip[NTAB_I];
     double gy[NY];
 };
@@ -88,7 +94,9 @@ struct Lane {
     unsigned fix, var;     // LDS byte offsets (from the start of Shared) of the fixed entry and of slot 0's varying entry
     unsigned e0step;       // padded fill position 21 i + j of slot 0 | its step per slot (1 along a row, 21 down a column) << 16
     unsigned ij;           // i | j << 8 of slot 0 | (1 << 16 if i steps, 1 << 24 if j steps): the crossing case's fill positions
-    unsigned padlo, padhi; // all ones where the slots 0-3 / 4-7 are padding
+    // padding: a key of the slots 0-3 is (key & aklo) | oklo -- (~0, 0) for sums, (~0, ~0) for high padding, (0, LOWPAD) for
+    // low padding -- and one of the slots 4-7 is key | padhi (all ones where they are high padding)
+    unsigned aklo, oklo, padhi;
 };
 
 struct Counters {
@@ -96,30 +104,42 @@ struct Counters {
 };
 
 // The run layout.  K[i][j] = outer[i] + inner[j] of two ascending curves ascends along every row and every column, so
-// the 400 sums can be dealt out to the network as 28 runs of 16 positions that are ALREADY ascending -- and then the first
-// ten steps of the 45-step bitonic network (which only sort inside blocks of 16) have nothing to do:
-//     runs  0-19: row i = run, columns 0-15            runs 20-23: column 16 + (run - 20), rows 0-15
-//     runs 24-27: row 16 + (run - 24), columns 16-19, then 12 pads      runs 28-31: pads
+// the 400 sums can be dealt out to the network as runs of 16 positions that are ALREADY ascending -- and then the first
+// ten steps of the 45-step bitonic network (which only sort inside blocks of 16) have nothing to do.  The blocks of 16
+// (block = lane / 2) are arranged so that the rows 0 ... 11 of the tableau fill the LEFT half of the network exactly and
+// the rows 12 ... 19 sit in the right half:
+//     blocks  0-11: row i = block, columns 0-15          blocks 12-15: 4 x low padding, then column 16 + (block - 12), rows 0-11
+//     blocks 16-23: row i = block - 4, columns 0-15      blocks 24-27: column 16 + (block - 24), rows 12-19, then 8 x high padding
+//     blocks 28-31: high padding
+// Where row 11 ends below the start of row 12 (half of the problems that need the network at all: k-distributions are
+// steep at their upper end) the two halves are sorted lists that follow each other, and the last of the five merge
+// phases -- 9 of the 35 steps -- has nothing to do either (mix: `split_apart`).  Low padding sorts to the positions
+// 0 ... 15 in either case: rank w sits at position RANK0 + w.
 // (400 sums cannot be cut into fewer than 20 ascending chains -- the anti-diagonal is an antichain -- so runs of 32 are
 // out of reach.)  Keys inside a run ascend too: equal quantised sums are ordered by fill position, and both fill orders
-// of the reference (:3332-3365) ascend along rows and along columns.  Position p = 8 lane + s: run = lane / 2.
+// of the reference (:3332-3365) ascend along rows and along columns.  Position p = 8 lane + s.
 __device__ __forceinline__ void run_lane(Lane& ln, int lane) {
     const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
-    const int run = lane >> 1, idx0 = 8 * (lane & 1);
-    int i = NY, j = NY, di = 0, dj = 0;   // default: padding everywhere (constant entries)
-    ln.padlo = ln.padhi = 0xFFFFFFFFu;
-    if (run < 20) { i = run; j = idx0; dj = 1; ln.padlo = ln.padhi = 0u; }                       // row i, columns idx0 ...
-    else if (run < 24) { i = idx0; j = 16 + (run - 20); di = 1; ln.padlo = ln.padhi = 0u; }       // column j, rows idx0 ...
-    else if (run < 28 && idx0 == 0) { i = 16 + (run - 24); j = 16; dj = 1; ln.padlo = 0u; }       // corner row: 4 cells + pads
+    const int blk = lane >> 1, idx0 = 8 * (lane & 1);
+    int i = NY, j = NY, di = 0, dj = 0;   // default: high padding everywhere (constant entries)
+    ln.aklo = 0xFFFFFFFFu;
+    ln.oklo = ln.padhi = 0xFFFFFFFFu;
+    if (blk < 12) { i = blk; j = idx0; dj = 1; ln.oklo = ln.padhi = 0u; }                          // row i, columns idx0 ...
+    else if (blk < 16) {                                                                           // column j, rows 0 ... 11 behind
+        j = 16 + (blk - 12); i = idx0 - 4; di = 1; ln.oklo = ln.padhi = 0u;                        // four positions of low padding
+        if (idx0 == 0) { ln.aklo = 0u; ln.oklo = (unsigned)LOWPAD; }
+    }
+    else if (blk < 24) { i = 12 + (blk - 16); j = idx0; dj = 1; ln.oklo = ln.padhi = 0u; }         // row i, columns idx0 ...
+    else if (blk < 28 && idx0 == 0) { j = 16 + (blk - 24); i = 12; di = 1; ln.oklo = ln.padhi = 0u; }   // column j, rows 12 ... 19
     if (di) {  // the column's entry is the fixed operand
         ln.fix = IP + PS * j;
-        ln.var = OP + PS * i;
+        ln.var = OP + PS * i;     // (i = -4: the four low entries in front of op)
     } else {
         ln.fix = OP + PS * i;
         ln.var = IP + PS * j;
     }
-    ln.e0step = (unsigned)(ROW_PITCH * i + j) | (unsigned)(di ? ROW_PITCH : 1) << 16;
-    ln.ij = (unsigned)i | (unsigned)j << 8 | (unsigned)di << 16 | (unsigned)dj << 24;
+    ln.e0step = (unsigned)((ROW_PITCH * i + j) & 0xFFFF) | (unsigned)(di ? ROW_PITCH : 1) << 16;
+    ln.ij = (unsigned)(i & 0xFF) | (unsigned)j << 8 | (unsigned)di << 16 | (unsigned)dj << 24;
 }
 
 __device__ __forceinline__ void prepare_presorted(Shared& sh, int lane);
@@ -139,9 +159,15 @@ __device__ __forceinline__ void init(Shared& sh, Lane& ln, int lane, const doubl
 #pragma unroll
     for (int t = 0; t < 3; t++) ln.c[t] = (lane >> t) & 1 ? 0xFFFFFFFFu : 0u;
     run_lane(ln, lane);
+    if (lane < 4) {
+        sh.oplow[lane].v = -__builtin_inf();
+        sh.oplow[lane].hw = 0.0;
+    }
     if (lane == 0) {
         sh.A[PAD] = __builtin_inf();
         sh.B[PAD] = 0.0;
+        sh.A[LOWPAD] = -__builtin_inf();
+        sh.B[LOWPAD] = 0.0;
     }
     prepare_presorted(sh, lane);
 }
@@ -272,7 +298,8 @@ __device__ __forceinline__ void sort512(Keys& v, int lane, const Lane& ln) {
 }
 
 // the same network entered behind its tenth step: every block of 16 positions (two lanes) is already ascending
-__device__ __forceinline__ void sort512_from_runs16(Keys& v, int lane, const Lane& ln) {
+// `halves_apart` (wave-uniform): every key of the left half is below every key of the right half -- the last merge phase is skipped
+__device__ __forceinline__ void sort512_from_runs16(Keys& v, int lane, const Lane& ln, bool halves_apart) {
 #define RO_LANE_TAIL lane_step<4>(v); lane_step<2>(v); lane_step<1>(v);
     cross_step<3, true>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
     cross_step<7, true>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
@@ -281,9 +308,11 @@ __device__ __forceinline__ void sort512_from_runs16(Keys& v, int lane, const Lan
     cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
     cross_step<31, true>(v, lane, ln); cross_step<8, false>(v, lane, ln); cross_step<4, false>(v, lane, ln);
     cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln); RO_LANE_TAIL
-    cross_step<63, true>(v, lane, ln); cross_step<16, false>(v, lane, ln); cross_step<8, false>(v, lane, ln);
-    cross_step<4, false>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
-    RO_LANE_TAIL
+    if (!halves_apart) {
+        cross_step<63, true>(v, lane, ln); cross_step<16, false>(v, lane, ln); cross_step<8, false>(v, lane, ln);
+        cross_step<4, false>(v, lane, ln); cross_step<2, false>(v, lane, ln); cross_step<1, false>(v, lane, ln);
+        RO_LANE_TAIL
+    }
 #undef RO_LANE_TAIL
 }
 
@@ -335,16 +364,17 @@ __device__ __forceinline__ void put_abscissae(Shared& sh, int lane, const double
     const double y_first = fma(0.5, g[0], run);
     const double y_next = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(y_first), 0x130, 0xF, 0xF, false),
                                            __builtin_amdgcn_update_dpp(0, __double2loint(y_first), 0x130, 0xF, 0xF, false));  // wave_shl:1
+    // the lanes that hold ranks: positions RANK0 ... RANK0 + 399, whole lanes (both bounds are multiples of 8)
+    const bool mine = SLOTS * lane >= RANK0 && SLOTS * lane < RANK0 + N;
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
-        const int w = SLOTS * lane + r;
-        if (w < N) {
-            if (WITH_SUMS) sh.A[9 * lane + r] = K[r];  // = padded(w)
+        if (mine) {
+            if (WITH_SUMS) sh.A[9 * lane + r] = K[r];  // = padded(position)
             sh.B[9 * lane + r] = fma(0.5, g[r], run);  // = run + 0.5 g bit for bit (0.5 g is exact): one instruction
         }
         run += g[r];
     }
-    if (SLOTS * lane < N) sh.B[9 * lane + SLOTS] = y_next;  // (lane 49: the padding's abscissa, the total weight, above every Gauss point)
+    if (mine) sh.B[9 * lane + SLOTS] = y_next;  // (last lane: the high padding's abscissa, the total weight, above every Gauss point)
 }
 
 // re-binning (:3379-3396): the rank w >= 1 whose abscissa is the first above Gauss point `lane`'s (returned in yq), at most
@@ -354,11 +384,13 @@ __device__ __forceinline__ int locate(Shared& sh, int lane, double& yq, unsigned
     yq = 0.0;
     if (lane < NY) {
         yq = sh.gy[lane];
-        // lower bound over the padded indices 1 ... 449 (w = 1 ... 399 and the duplicates) with lengths known at compile
-        // time: ten dependent LDS reads at immediate offsets from one running byte offset -- compare, add, select per step
-        constexpr int NP = padded(N - 1) + 1;   // 449
+        // lower bound over the padded positions of the ranks 1 ... 399 and the duplicates between them, with lengths known
+        // at compile time: ten dependent LDS reads at immediate offsets from one running byte offset -- compare, add,
+        // select per step
+        constexpr int P0 = padded(RANK0 + 1);                       // rank 1
+        constexpr int NP = padded(RANK0 + N - 1) + 1 - P0 + 1;      // ... rank 399 and the duplicate behind it
         const char* Bb = (const char*)sh.B;
-        unsigned pb = 8;
+        unsigned pb = 8 * P0;
 #pragma unroll
         for (int len = NP; len > 1; len -= len / 2) {
             const int half = len / 2;
@@ -366,8 +398,9 @@ __device__ __forceinline__ int locate(Shared& sh, int lane, double& yq, unsigned
         }
         pb += *(const double*)(Bb + pb) > yq ? 0u : 8u;
         const unsigned pi = pb >> 3;
-        w = (int)(pi - (__umul24(pi, 7282u) >> 16));     // padded index -> rank: minus pi / 9 (exact below 512); a duplicate cell
-                                                // 9 l + 8 gives 8 l + 8, the rank it stands for
+        // padded index -> position: minus pi / 9 (exact below 512; a duplicate cell 9 l + 8 gives 8 l + 8, the position it
+        // stands for) -> rank
+        w = (int)(pi - (__umul24(pi, 7282u) >> 16)) - RANK0;
     }
     // a Gauss point that falls into the interval of its predecessor takes the next one (the reference's walk advances w
     // before it looks at the next point, and reports a malfunction, :3383-3387): w'_q = max over j <= q of (w_j + q - j)
@@ -393,9 +426,9 @@ __device__ __forceinline__ void prepare_presorted(Shared& sh, int lane) {
     double K[SLOTS], g[SLOTS];
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
-        const int w = SLOTS * lane + r;
+        const int w = SLOTS * lane + r - RANK0;   // the rank at this position
         K[r] = 0.0;
-        g[r] = w < N ? sh.op[w / NY].hw * sh.ip[w % NY].hw : 0.0;
+        g[r] = (w >= 0 && w < N) ? sh.op[w / NY].hw * sh.ip[w % NY].hw : 0.0;
     }
     double csum = 0.0;
 #pragma unroll
@@ -409,8 +442,8 @@ __device__ __forceinline__ void prepare_presorted(Shared& sh, int lane) {
     double y0 = 0.0, y1 = 0.0;
     unsigned long long cells = 0ull;
     if (lane < NY && wq < N) {
-        y0 = sh.B[padded(wq - 1)];
-        y1 = sh.B[padded(wq)];
+        y0 = sh.B[padded(RANK0 + wq - 1)];
+        y1 = sh.B[padded(RANK0 + wq)];
         const unsigned c0 = (OP + PS * ((wq - 1) / NY)) | (IP + PS * ((wq - 1) % NY)) << 16;
         const unsigned c1 = (OP + PS * (wq / NY)) | (IP + PS * (wq % NY)) << 16;
         cells = (unsigned long long)c1 << 32 | c0;
@@ -436,10 +469,10 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
     const char* inner = (const char*)sh.ip;
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
-        const int e = 64 * r + lane;
-        double K = __builtin_inf(), g = 0.0;
-        unsigned key = 0xFFFFFE00u | (unsigned)PAD;
-        if (r < 6 || (r == 6 && lane < N - 6 * 64)) {  // e < 400: every lane for r < 6, 16 lanes for r = 6, none for r = 7
+        // position 64 r + lane: RANK0 positions of low padding, the sums in fill order, high padding
+        const int e = 64 * r + lane - RANK0;
+        unsigned key = e < 0 ? (unsigned)LOWPAD : 0xFFFFFE00u | (unsigned)PAD;
+        if (e >= 0 && e < N) {
             int aq = 16 * (e / 20), ar = 16 * (e % 20);  // byte offsets of op[e / 20], ip[e % 20]
             if (CROSSING) {  // the curves cross: two fill regions (:3332-3365)
                 const bool first = e < nfirst;
@@ -451,19 +484,16 @@ __device__ __forceinline__ void fill(Shared& sh, const Lane& ln, int lane, Keys&
                 ar = 16 * (first ? rem : q);
             }
             const Pair po = *(const Pair*)(outer + aq), pi = *(const Pair*)(inner + ar);
-            K = po.v + pi.v;
-            g = po.hw * pi.hw;
+            const double K = po.v + pi.v;
             int dh = __double2hiint(K) - hmin;
             if (!MONOTONE) dh = max(dh, 0);
             unsigned q23 = sh_bits >= 32 ? (unsigned)dh >> (sh_bits - 32)
                                          : __builtin_amdgcn_alignbit((unsigned)dh, (unsigned)__double2loint(K), sh_bits);
-            if (!MONOTONE) q23 = min(q23, 0x7FFFFFu);
+            if (!MONOTONE) q23 = min(max(q23, 1u), 0x7FFFFFu);
             key = q23 << 9 | (unsigned)e;
+            sh.A[e] = K;
+            sh.B[e] = po.hw * pi.hw;
         }
-        // (padding positions share the cell PAD and the all-ones key: the cells above the sums belong to prepare_presorted)
-        const int cell = (r < 6 || (r == 6 && lane < N - 6 * 64)) ? e : PAD;
-        sh.A[cell] = K;
-        sh.B[cell] = g;
         v.k[r] = key;
     }
 }
@@ -479,24 +509,29 @@ __device__ __forceinline__ void fill_runs(Shared& sh, const Lane& ln, Keys& v, i
     unsigned fix = ln.fix, var = ln.var, e0step = ln.e0step;
     asm volatile("" : "+v"(fix), "+v"(var), "+v"(e0step));
     const Pair F = *(const Pair*)(base + fix);
-    const unsigned e0 = e0step & 0xFFFF, estep = e0step >> 16;
+    const int e0 = (int)(short)(e0step & 0xFFFF);   // (negative where the lane starts with low padding)
+    const unsigned estep = e0step >> 16;
+    // padding has no entry of its own in the images (the cells PAD and LOWPAD hold its values since init)
+    const bool sums_lo = ln.oklo == 0u, sums_hi = ln.padhi == 0u;
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
         const Pair V = *(const Pair*)(base + var + (unsigned)sizeof(Pair) * r);
-        const double K = F.v + V.v;      // pads: inf
-        const double g = F.hw * V.hw;    // pads: 0
-        unsigned e = e0 + estep * r;     // index of the LDS images and tie-break of the key
+        const double K = F.v + V.v;      // padding: inf, -inf
+        const double g = F.hw * V.hw;    // padding: 0
+        unsigned e = (unsigned)(e0 + (int)estep * r);     // index of the LDS images and tie-break of the key
         if (CROSSING) {
-            const unsigned i = (ln.ij & 0xFF) + ((ln.ij >> 16) & 1) * r, j = ((ln.ij >> 8) & 0xFF) + (ln.ij >> 24) * r;
-            e = (int)j < yx ? j + __umul24(yx, i) : i + 20 * j;
+            const int i = (int)(signed char)(ln.ij & 0xFF) + (int)((ln.ij >> 16) & 1) * r;
+            const int j = (int)((ln.ij >> 8) & 0xFF) + (int)(ln.ij >> 24) * r;
+            e = (unsigned)(j < yx ? j + yx * i : i + 20 * j);
         }
-        const unsigned pad = r < SLOTS / 2 ? ln.padlo : ln.padhi;
         const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
         const unsigned q23 = HI ? dh >> (sh_bits - 32) : __builtin_amdgcn_alignbit(dh, (unsigned)__double2loint(K), sh_bits);
-        v.k[r] = (q23 << 9 | e) | pad;                       // pads: all ones
-        const unsigned at = ((e << 3) | pad) & (8 * PAD);   // pads: their common cell, which holds (inf, 0) anyway
-        *(double*)((char*)sh.A + at) = K;
-        *(double*)((char*)sh.B + at) = g;
+        const unsigned key = q23 << 9 | e;
+        v.k[r] = r < SLOTS / 2 ? (key & ln.aklo) | ln.oklo : key | ln.padhi;   // high padding: all ones; low padding: LOWPAD
+        if (r < SLOTS / 2 ? sums_lo : sums_hi) {
+            *(double*)((char*)sh.A + (e << 3)) = K;
+            *(double*)((char*)sh.B + (e << 3)) = g;
+        }
     }
 }
 
@@ -516,19 +551,26 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     // last crossing of the two curves (:3321-3329); are both k-distributions (ascending)?
     // ... and do the rows of the tableau overlap?  If row i ends below the start of row i + 1 for every i, the sums are
     // ascending in fill order (without a crossing: e = 20 i + j) and nothing has to be sorted
-    bool cross = false, down = false, over = false;
+    bool cross = false, down = false, over = false, touch = false;
     if (lane >= 1 && lane < NY) {
         const double po = sh.op[lane - 1].v, pi = sh.ip[lane - 1].v;
         const double pm = mix_first ? po : pi, pa = mix_first ? pi : po;
         cross = (my_mix > my_add) != (pm > pa);
         down = my_mix < pm || my_add < pa;
         const double mo = mix_first ? my_mix : my_add;  // outer[lane]
-        over = po + (mix_first ? a19 : m19) > mo + (mix_first ? a0 : m0);
+        const double row_end = po + (mix_first ? a19 : m19), next_start = mo + (mix_first ? a0 : m0);
+        over = row_end > next_start;
+        touch = row_end >= next_start;
     }
     const unsigned long long cmask = __ballot(cross);
     const int yx = cmask ? 63 - __clzll((long long)cmask) : NY;
     const bool monotone = __ballot(down) == 0;
-    const bool rows_apart = __ballot(over) == 0;
+    const unsigned long long overlaps = __ballot(over);
+    const bool rows_apart = overlaps == 0;
+    // row 11 ends below the start of row 12: the two halves of the network's run layout are sorted lists that follow each
+    // other (run_lane)
+    // (strictly below: with a crossing the reference's fill order does not follow the rows, and equal sums keep fill order)
+    const bool halves_apart = ((__ballot(touch) >> 12) & 1ull) == 0;
     double kmin = m0 + a0, kmax = m19 + a19;
     if (!monotone) {  // the extreme sums are not at the corners of the tableau
         double mn1 = sh.op[0].v, mx1 = mn1, mn2 = sh.ip[0].v, mx2 = mn2;
@@ -540,12 +582,17 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
         kmin = mn1 + mn2;
         kmax = mx1 + mx2;
     }
-    // key scale (wave-uniform): (bits(K) - (hi32(Kmin) << 32)) >> sh fits 23 bits for every K <= Kmax
-    const int hmin = __builtin_amdgcn_readfirstlane(__double2hiint(kmin));
-    const unsigned long long dmax =
-        ((unsigned long long)(unsigned)(__builtin_amdgcn_readfirstlane(__double2hiint(kmax)) - hmin) << 32) |
+    // key scale (wave-uniform): q = (bits(K) - (hmin << 32)) >> sh with 1 <= q < 2^23 for Kmin <= K <= Kmax (q = 0 is the
+    // low padding's): hmin lies one unit of q or more below hi32(Kmin)
+    const int hk = __builtin_amdgcn_readfirstlane(__double2hiint(kmin));
+    const unsigned long long span =
+        ((unsigned long long)(unsigned)(__builtin_amdgcn_readfirstlane(__double2hiint(kmax)) - hk) << 32) |
         (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(kmax));
-    const int bl = dmax ? 64 - __clzll((long long)dmax) : 0;
+    const int bl0 = span ? 64 - __clzll((long long)span) : 0;
+    const int bias = 1 << max(0, bl0 - 23 - 31);                       // in units of 2^32: >= 2^sh once sh is settled below
+    const int hmin = hk - bias;
+    const unsigned long long dmax = span + ((unsigned long long)(unsigned)bias << 32);
+    const int bl = 64 - __clzll((long long)dmax);
     const int sh_bits = bl > 23 ? bl - 23 : 0;
     RO_MARK("fill");
     if (monotone && yx == NY && rows_apart) {
@@ -581,7 +628,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
             RO_MARK("network");
             asm volatile("" : "+v"(lv));  // what the network derives from the lane id (exchange addresses, bits 3-5) is
                                           // rebuilt per problem and does not sit in registers between the problems
-            sort512_from_runs16(v, lv, ln);
+            sort512_from_runs16(v, lv, ln, halves_apart);
         } else {  // a curve that is not a k-distribution: positions in fill order, the whole network
             if (yx == NY) fill<false, false>(sh, ln, lane, v, yx, hmin, sh_bits);
             else fill<false, true>(sh, ln, lane, v, yx, hmin, sh_bits);
@@ -638,7 +685,7 @@ __device__ __forceinline__ double mix(Shared& sh, const Lane& ln, int lane, doub
     RO_MARK("interpolate");
     double out = my_mix;  // w = 400: the walk ran out of sums, the reference leaves the entry as it was
     if (lane < NY && wq < N) {
-        const int i0 = padded(wq - 1), i1 = padded(wq);
+        const int i0 = padded(RANK0 + wq - 1), i1 = padded(RANK0 + wq);
         out = (sh.A[i0] * (sh.B[i1] - yq) + sh.A[i1] * (yq - sh.B[i0])) / (sh.B[i1] - sh.B[i0]);
     }
     RO_MARK("end");

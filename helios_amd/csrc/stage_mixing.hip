@@ -305,17 +305,18 @@ k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ o
         // cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376): lane-contiguous
         // chunks of 8 (the slots of a lane in the sorting networks, so that all three variants add in the same
         // order and agree bit for bit) + wave exclusive scan
+        // (rank w at position ro::RANK0 + w, as in the default kernel's network: the wave scan then adds in the same order)
         double g[BT_PER_LANE], csum = 0.0;
         for (int r = 0; r < BT_PER_LANE; r++) {
-            const int w = lane * BT_PER_LANE + r;
-            g[r] = w < RO_N ? s_Y[w] : 0.0;
+            const int w = lane * BT_PER_LANE + r - ro::RANK0;
+            g[r] = (w >= 0 && w < RO_N) ? s_Y[w] : 0.0;
             csum += g[r];
         }
         double run = ro::wave_inclusive_sum(csum) - csum;
         __syncthreads();
         for (int r = 0; r < BT_PER_LANE; r++) {
-            const int w = lane * BT_PER_LANE + r;
-            if (w < RO_N) s_Y[w] = run + 0.5 * g[r];
+            const int w = lane * BT_PER_LANE + r - ro::RANK0;
+            if (w >= 0 && w < RO_N) s_Y[w] = run + 0.5 * g[r];
             run += g[r];
         }
         __syncthreads();
