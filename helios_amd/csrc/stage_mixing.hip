@@ -136,7 +136,7 @@ __device__ __forceinline__ void bt_sort(BtSlots& v, int lane) {
 }
 
 template <bool BITONIC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITONIC ? 4 : 1)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BITONIC ? 3 : 1)))
 k_add_to_mixed_opac(const double* __restrict__ vmr, const double* __restrict__ opac_spec,
                     double* __restrict__ opac_wg, const double* __restrict__ meanmolmass,
                     const double* __restrict__ gauss_weight, const double* __restrict__ gauss_y,
