@@ -698,10 +698,16 @@ def main():
     line["env_knobs"] = knobs
     # what the collective layer itself reports: the backend of the process group and the number of ranks it connected
     # ("nccl" is RCCL on ROCm; the gloo hook of the single-GPU tests says so here)
+    def rccl_version():
+        try:
+            v = torch.cuda.nccl.version()
+            return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:      # (the line must not depend on this accessor)
+            return "unavailable: %s" % type(e).__name__
     line["process_group"] = None if dist is None else {
         "backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()),
         "rccl_world": int(dist.get_world_size()) if str(dist.get_backend()) == "nccl" else None,
-        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if str(dist.get_backend()) == "nccl" else None,
+        "rccl_version": rccl_version() if str(dist.get_backend()) == "nccl" else None,
         "ranks_seen_by_all_gather": len(ranks.gather_scalars(float(rank)))}
     # the other configurations, measured live in this run on every rank (weak scaling like the headline)
     sec = {}
