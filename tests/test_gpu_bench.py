@@ -77,6 +77,9 @@ def test_rccl_gathers_the_spectra_with_one_rank():
             "assert np.array_equal(out, a[[1, 2, 0]]), out\n"
             "out = gather_spectra(a, dist, device='cuda')\n"
             "assert np.array_equal(out, a)\n"
+            "t = torch.arange(12.0, dtype=torch.float64, device='cuda').reshape(3, 4)\n"      # a tensor that lives on the GPU already
+            "out = gather_spectra(t, dist, device='cuda', columns=[2, 0, 1])\n"
+            "assert np.array_equal(out, a[[1, 2, 0]]), out\n"
             "print('backend', dist.get_backend())\n"
             "dist.destroy_process_group()\n")
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
