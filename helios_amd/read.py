@@ -4,9 +4,11 @@ Counterpart of the reference's `Read` (source/read.py).  Option names, defaults 
 follow param.dat / read.py:210-988; every option can be overridden on the command line
 with the reference's single-dash flags (`-number_of_layers 50`).  File formats:
 
-  * opacity tables / stellar spectra: the reference reads HDF5 through h5py (read.py:1041-1103,
-    :1195-1236).  h5py is optional here; the same dataset names are also accepted from a `.npz` archive
-    (numpy), which is what the synthetic-table generator writes.
+  * opacity tables / scattering cross-sections / stellar spectra: the reference reads HDF5 through h5py
+    (read.py:1041-1103, :1195-1236, :1639-1640).  Here: through h5py where it is installed, otherwise through the
+    HDF5 C library itself (helios_amd/hdf5_lite.py, ctypes on libhdf5 >= 1.10); pinned on real h5py-written files
+    against the reference's own reader (tests/golden/reader/hdf5/, tests/test_read_hdf5.py).  The same dataset
+    names are also accepted from a `.npz` archive (numpy), which is what the synthetic-table generator writes.
   * `opacity mixing = synthetic` (extension): build the seeded synthetic tables of SURVEY.md 8(d)
     in memory -- used by bench.py and the tests, since the real tables cannot be downloaded here.
 """
@@ -134,6 +136,46 @@ class Species(object):
         self.scat_cross_sect_pretab = None    # [nbin]
         self.scat_cross_sect_layer = []       # tiled to [nbin * nlayer] (read.py:1642-1645)
         self.scat_cross_sect_interface = []
+
+
+class _Table(object):
+    """`name in table`, `table[name]` -> numpy array, for .npz archives and HDF5 files (the reference: `h5py.File(name,
+    "r")` + `file[name][:]`, source/read.py:1044-1101)"""
+
+    def __init__(self, path):
+        self.path = str(path)
+        self._npz = self._h5 = None
+        if self.path.endswith(".npz"):
+            self._npz = dict(np.load(self.path))
+            return
+        if not os.path.exists(self.path):
+            raise IOError("Unable to open file (no such file: %s)" % self.path)
+        try:
+            import h5py
+            self._h5 = h5py.File(self.path, "r")
+        except ImportError:
+            from . import hdf5_lite
+            if not hdf5_lite.available():
+                raise IOError("neither h5py nor an HDF5 library is installed: convert %s to .npz (same dataset names), "
+                              "install h5py or point HELIOS_HDF5_LIB at a libhdf5.so" % self.path)
+            self._h5 = hdf5_lite.File(self.path, "r")
+
+    def __contains__(self, name):
+        if self._npz is not None:
+            return name in self._npz
+        try:
+            obj = self._h5[name]
+        except (KeyError, ValueError):
+            return False
+        return not hasattr(obj, "keys")      # a group is not a dataset
+
+    def __getitem__(self, name):
+        if self._npz is not None:
+            return self._npz[name]
+        return np.asarray(self._h5[name][()])
+
+    def keys(self):
+        return list(self._npz.keys()) if self._npz is not None else list(self._h5.keys())
 
 
 class Read(object):
@@ -346,15 +388,11 @@ class Read(object):
     # ---------------------------------------------------------------------------------------------
     @staticmethod
     def _open_table(path):
-        """dataset-name -> array mapping of an HDF5 (needs h5py) or .npz opacity/star file"""
-        if path.endswith(".npz"):
-            return dict(np.load(path))
-        try:
-            import h5py
-        except ImportError:
-            raise IOError("h5py is not installed: convert %s to .npz (same dataset names) or install h5py" % path)
-        with h5py.File(path, "r") as f:
-            return {k: f[k][()] for k in f.keys()}
+        """dataset-name -> array mapping of an HDF5 or .npz opacity / star file.  HDF5 through h5py where it is installed,
+        otherwise through the HDF5 C library (helios_amd/hdf5_lite.py).  Datasets are read when asked for, nested paths
+        ("/r50_kdistr/phoenix/gj1214", the reference's `dataset in stellar spectrum file`) are taken as h5py takes
+        them."""
+        return _Table(path)
 
     def read_opac_file(self, quant, path, type="premixed", read_grid_parameters=False):
         """one opacity container as written by the reference's k-table tool (read.py:1041-1103): `kpoints` (or

@@ -244,6 +244,46 @@ def test_run_helios_on_the_fly_from_files(tmp_path):
     assert abs(hs.global_energy_imbalance(a)) < 1e-3
 
 
+def test_run_helios_on_the_fly_from_hdf5_files(tmp_path):
+    """the same run with every opacity container as a real HDF5 file (gzip-compressed, written through the HDF5 C
+    library) and the stellar spectrum from a nested data set of an HDF5 file: the readers go through libhdf5 (no h5py
+    in the image) and the run is the .npz run bit for bit"""
+    from helios_amd import hdf5_lite
+    if not hdf5_lite.available():
+        pytest.skip("no libhdf5 on this host")
+    wd = str(tmp_path)
+    _host_golden_module().write_species_inputs(wd, nbin=14, ny=20, sorted_k=True)
+    star = 10.0 ** np.random.default_rng(4).uniform(5.0, 7.0, 14)
+    np.savez(os.path.join(wd, "star.npz"), **{"r50_kdistr/phoenix/teststar": star})
+    hdf5_lite.write(os.path.join(wd, "star.h5"), {"r50_kdistr/phoenix/teststar": star, "r50_kdistr/lambda": np.arange(14.0)})
+
+    def argv(star_file, out):
+        return ["-parameter_file", "/nonexistent", "-opacity_mixing", "on-the-fly",
+                "-path_to_species_file", os.path.join(wd, "species.dat"),
+                "-file_with_vertical_mixing_ratios", os.path.join(wd, "vmr.txt"),
+                "-directory_with_fastchem_files", os.path.join(wd, "chem") + "/",
+                "-directory_with_opacity_files", os.path.join(wd, "opac") + "/",
+                "-stellar_spectral_model", "file", "-path_to_stellar_spectrum_file", os.path.join(wd, star_file),
+                "-dataset_in_stellar_spectrum_file", "/r50_kdistr/phoenix/teststar",
+                "-number_of_layers", "18", "-maximum_number_of_iterations", "20000", "-name", out,
+                "-output_directory", wd + "/", "-radiative_equilibrium_criterion", "1e-4",
+                "-convective_adjustment", "no", "-toa_pressure", "1e0", "-boa_pressure", "1e8"]
+
+    a = _run_driver(argv("star.npz", "npz"), True)
+    opac = os.path.join(wd, "opac")
+    for f in sorted(os.listdir(opac)):
+        if f.endswith(".npz"):
+            hdf5_lite.write(os.path.join(opac, f[:-4] + ".h5"), dict(np.load(os.path.join(opac, f))), compression=4)
+            os.remove(os.path.join(opac, f))
+    assert all(f.endswith(".h5") for f in os.listdir(opac)) and open(os.path.join(opac, "scat_cross_sections.h5"), "rb").read(4) == b"\x89HDF"
+    b = _run_driver(argv("star.h5", "h5"), True)
+    assert int(a.real_star) == 1 and int(b.real_star) == 1
+    assert int(a.iter_value) == int(b.iter_value) and int(a.iter_value) > 3
+    np.testing.assert_array_equal(a.starflux, b.starflux)
+    np.testing.assert_array_equal(a.T_lay, b.T_lay)
+    np.testing.assert_array_equal(a.F_up_band, b.F_up_band)
+
+
 def test_run_helios_with_additional_heating(tmp_path):
     """a heating-density file (e.g. UV heating of the upper atmosphere): per-stage loop, flux refreshed from the layer
     heights every 10th iteration; in equilibrium the atmosphere radiates the extra energy away"""
