@@ -77,6 +77,9 @@ struct hx_rt {
     int coef_tpb = 4;  // k_rt_coef: tiles (wavefronts) per workgroup
     hipError_t shmem_rc = hipSuccess;
     bool cloud_lds = true;       // k_rt_coef stages the clouds' half-layer terms in LDS when they fit (HELIOS_RT_CLOUD_LDS)
+    bool serpentine = false;     // k_rt_flux walks its grid back and forth from launch to launch (HELIOS_RT_SERPENTINE)
+    unsigned flux_launches = 0;
+    double state_cache_mb = 0;   // MiB of up-flux state the tail of a k_rt_flux launch leaves in the Infinity Cache
     bool generic_scans = false;  // k_rt_flux with the runtime-k scans also where k = 16 or 32 (HELIOS_RT_GENERIC_SCANS)
     bool conv_shmem_raised = false;  // dynamic-LDS limit of the convection kernels lifted (deep atmospheres)
     bool coef_shmem_raised = false;  // k_rt_coef's dynamic-LDS limit lifted above 64 KiB (deep atmospheres)

@@ -240,6 +240,17 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.F_up_band_n = a.F_up_band_n;
     f.coef_col = a.coef_col; f.flux_col = a.flux_col;
     f.done = a.done;
+    // Serpentine order over the iterations: the workgroups of an odd launch take the tiles from the far end, so the
+    // tiles the previous launch touched last -- still in the 256 MiB Infinity Cache -- are the ones this launch asks
+    // for first.  Same bits (workgroups are independent).
+    f.reverse = rt->serpentine ? (rt->flux_launches++ & 1) : 0;
+    f.cache_state_from = INT_MAX;
+    if (rt->serpentine && rt->state_cache_mb > 0) {
+        const double per_wg = (double)g.nparts * g.NW * ROWS * 64 * sizeof(double);
+        const long long total = (long long)g.nblk_x * rt->C;
+        const long long keep = (long long)(rt->state_cache_mb * 1048576.0 / per_wg);
+        f.cache_state_from = (int)std::max(0LL, total - keep);
+    }
     const bool generic = rt->generic_scans;
     if (g.k == 16 && !generic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 16>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
@@ -386,6 +397,22 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));    // (16 tiles per workgroup at k = 64: measured, no faster)
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
+    {
+        // The up-flux state is the one array a k_rt_flux launch writes and the next one reads.  Where it is larger than
+        // the 256 MiB Infinity Cache but the arrays of the small kernels in between (node Planck values, band fluxes) are
+        // not, the launches walk the grid back and forth and the workgroups dispatched last keep 240 MiB of state in the
+        // cache (write-through stores instead of non-temporal ones): the next launch starts with exactly those tiles and
+        // neither reads them from HBM nor -- the cache is write-back -- have they been written there.  Same-box A/B at
+        // BASELINE config 2: k_rt_flux 0.322 -> 0.299 ms, the step 0.405 -> 0.389 ms (profiles/r04_ab_state_cache.txt);
+        // four columns per batch or config 5's grid: no gain (the arrays in between displace the state), small grids:
+        // the write-through stores cost 1.6 us per launch -- hence the two conditions.
+        const double state_mb = (double)rt->C * rt->g.flux_elems_per_col * sizeof(double) / 1048576.0;
+        const double between_mb = (double)rt->C * rt->X * ((rt->H + 3) + 4.0 * rt->I) * sizeof(double) / 1048576.0;
+        rt->serpentine = state_mb >= 64.0 && between_mb <= 64.0;
+        rt->state_cache_mb = rt->serpentine ? 240.0 : 0.0;
+    }
+    if (const char* e = getenv("HELIOS_RT_SERPENTINE")) rt->serpentine = atoi(e) != 0;                   // tuning knobs:
+    if (const char* e = getenv("HELIOS_RT_STATE_CACHE_MB")) rt->state_cache_mb = atof(e);                // same results
     rt->species.resize(dims->nspecies > 0 ? dims->nspecies : 0);
     int rc = set_flux_shmem_limits(rt);
     if (rc) return rc;

@@ -55,6 +55,8 @@ struct FluxArgs {
     int X, Y, L, I, H;
     int k, nxb, ypb, nparts, G, NW;
     int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane, iso, debug_skip;
+    int reverse;           // walk the grid from its far end (see launch_flux)
+    int cache_state_from;  // dispatch index from which the state stores stay cached
     double Kconst;
     const hx_rt_column* colpar;
     const double *Bn, *coef, *U0_in, *boaK, *Fdir0, *surf_albedo, *gauss_w;
@@ -651,9 +653,11 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 template <int ROWS, int K = 0>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
-    const int col = blockIdx.y;
+    const int col = a.reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
     if (a.done[col]) return;
-    const int bx = blockIdx.x;
+    const int bx = a.reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+    // the workgroups this launch dispatches last leave their up-flux state in the Infinity Cache for the next launch
+    const bool keep_state_cached = (int)(blockIdx.y * gridDim.x + blockIdx.x) >= a.cache_state_from;
     const int NN = a.H + 3, I = a.I;
     double* sB = smem;                               // [nxb][NN]  Planck function at the nodes
     double* acc = sB + (size_t)a.nxb * NN;           // [nxb][2][I] band fluxes being accumulated
@@ -816,7 +820,11 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             if (!(debug_skip & 2)) {
                 double* ut = a.Utile + col * a.flux_col + eoff;
 #pragma unroll
-                for (int r = 0; r < ROWS; r++) __builtin_nontemporal_store(Uo[r], ut + r * 64);
+                for (int r = 0; r < ROWS; r++) {
+                    // (write-through store that leaves the line in the Infinity Cache: agent scope = `sc1`; see launch_flux)
+                    if (keep_state_cached) __hip_atomic_store(ut + r * 64, Uo[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else __builtin_nontemporal_store(Uo[r], ut + r * 64);
+                }
             }
             if (a.keep_down) {
                 double* dtile = a.Dtile + col * a.flux_col + eoff;

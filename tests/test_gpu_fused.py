@@ -414,3 +414,38 @@ def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, na
                 np.testing.assert_array_equal(got[col][k], want[col][k], err_msg="%s column %d" % (k, col))
     if ncol > 1:
         assert np.abs(a1[0]["T_lay"] - a1[ncol - 1]["T_lay"]).max() > 1.0
+
+
+@pytest.mark.parametrize("name,ncol,mb", [("L50", 1, "0.05"), ("clouds_g0", 3, "0.2"), ("L100", 2, "1000")])
+def test_back_and_forth_launch_order_with_cached_state_is_the_same_run(ctx, name, ncol, mb, monkeypatch):
+    """k_rt_flux walking its grid from the far end on every other launch, the workgroups dispatched last keeping their
+    up-flux state in the Infinity Cache through write-through stores (what a batch of BASELINE config 2's size does by
+    itself; HELIOS_RT_SERPENTINE / HELIOS_RT_STATE_CACHE_MB force it here, with a cached share of part of the grid, of
+    a few workgroups and of everything): workgroups are independent, so the run is the same bit for bit -- launch by
+    launch and through the graph replay, whose captured launches carry alternating directions."""
+    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    T = [c0.T_lay * (1.0 + 0.02 * k) for k in range(ncol)] if ncol > 1 else None
+    from helios_amd.rt import batch_from_case
+
+    def run(serpentine, graph):
+        monkeypatch.setenv("HELIOS_RT_SERPENTINE", serpentine)
+        monkeypatch.setenv("HELIOS_RT_STATE_CACHE_MB", mb if serpentine == "1" else "0")
+        monkeypatch.setenv("HELIOS_RT_GRAPH", graph)
+        rt = batch_from_case(ctx, c0, ncol=ncol)
+        try:
+            if T is not None:
+                for k, Tk in enumerate(T):
+                    rt.set_temperatures(k, Tk)
+            rt.build_planck_table(1 if c0.T_star > 10 else 0)
+            rt.run(0, 33)
+            return [{k: rt.get(k, col) for k in ("T_lay", "F_net", "F_up_band", "F_down_band", "delta_t_prefactor", "abort")}
+                    for col in range(ncol)]
+        finally:
+            rt.close()
+    want = run("0", "0")
+    for graph in ("0", "1"):
+        got = run("1", graph)
+        for col in range(ncol):
+            for k in want[col]:
+                np.testing.assert_array_equal(got[col][k], want[col][k], err_msg="%s column %d graph %s" % (k, col, graph))
+
