@@ -571,6 +571,7 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
     assert spec.shape == (ncol * world, c.nbin)
 
     total_cols = ncol * world
+    flux_policy = rt.get("flux_launch_policy")
     out = {
         "value": steps / dt * c.nbin * c.nlayer * total_cols, "unit": "bin*layer*iterations/s",
         "steps": steps, "warmup": warmup, "device_warmup_iterations": device_warmup, "ms_per_step": dt / steps * 1e3,
@@ -578,7 +579,10 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
                    "species": len(c.species) if c.species else 0,
                    "opacity_table_TP_grid": [c.ntemp, c.npress], "columns_per_gpu": ncol,
                    "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 3 * c.scat + 1,
-                   "loop": phase, "parallelism": "columns sharded, %d per GPU" % ncol},
+                   "loop": phase, "parallelism": "columns sharded, %d per GPU" % ncol,
+                   # what the batch chose for k_rt_flux: launches walking the grid back and forth,
+                   # MiB of up-flux state the tail of a launch leaves in the Infinity Cache
+                   "flux_launch_policy": {"back_and_forth": bool(flux_policy[0]), "state_cached_mib": float(flux_policy[1])}},
         "iterations_per_s_per_column": steps / dt,
         "stream_event_ms_per_step": ev_ms / steps,
         "per_rank_ms_per_step": rank_ms,

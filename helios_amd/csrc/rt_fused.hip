@@ -1478,6 +1478,12 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
         return get_plain(rt, (n == "vmr_lay" ? rt->vmr_lay : rt->vmr_int) + c * S * I, S * I * 8, out, out_bytes);
     }
     if (n == "iters_done") return get_plain(rt, rt->iters_done + c, 4, out, out_bytes);
+    if (n == "flux_launch_policy") {   // host-side: {launch order back and forth (0/1), MiB of up-flux state kept cached}
+        HX_REQUIRE(rt->ctx, out_bytes == 2 * sizeof(double), HX_E_ARG, "flux_launch_policy is two doubles");
+        const double v[2] = {rt->serpentine ? 1.0 : 0.0, rt->serpentine ? rt->state_cache_mb : 0.0};
+        memcpy(out, v, sizeof(v));
+        return 0;
+    }
     if (n == "planck_grid")
         return get_plain(rt, rt->planck_grid, (size_t)(rt->d.plancktable_dim + 1) * X * 8, out, out_bytes);
     if (n == "done") return get_plain(rt, rt->done + c, 4, out, out_bytes);

@@ -316,7 +316,10 @@ int hx_add_to_mixed_scat(hx_context* ctx, const double* vmr, const double* scat_
  *   hx_rt_step              one iteration (computation.py:856-857, :880-888, :926-932): T_int, Planck
  *                           interpolation, (3*scat+1) two-stream sweeps, quadrature, totals, temperature
  *                           step, per-column convergence count -- no host round trip
- *   hx_rt_get / hx_rt_export_* read results back in the REFERENCE's layouts
+ *   hx_rt_get / hx_rt_export_* read results back in the REFERENCE's layouts (hx_rt_get also: "flux_launch_policy",
+ *                           two doubles -- whether the flux kernel's launches walk the grid back and forth and how
+ *                           many MiB of up-flux state a launch leaves in the Infinity Cache; a choice of the batch,
+ *                           HELIOS_RT_SERPENTINE / HELIOS_RT_STATE_CACHE_MB override it, results do not depend on it)
  */
 typedef struct hx_rt_dims {
     int32_t nbin, ny, nlayer, ncol;

@@ -38,6 +38,25 @@ def test_bench_single_rank_contract():
     assert ss["iterations"] == 200 and ss["from_iteration"] == 0 and ss["refreshes"] == 20 and ss["value"] > 0
     assert line["env_knobs"] == {} and line["secondary"] is None and line["process_group"] is None
     assert "scaling_series_n1" not in line and "single_gpu_same_workload" not in line
+    # a small grid keeps the front-to-back launch order and non-temporal state stores
+    assert line["config"]["flux_launch_policy"] == {"back_and_forth": False, "state_cached_mib": 0.0}
+
+
+def test_headline_batch_keeps_its_state_in_the_infinity_cache():
+    """BASELINE config 2's batch (one column: 333 MB of up-flux state, 49 MB of node and band arrays) switches the
+    back-and-forth launch order with 240 MiB of cached state on by itself; four columns per batch (the arrays of the
+    kernels in between would displace the state) do not"""
+    common = ["--steps", "10", "--warmup", "10", "--no-cpu-baseline", "--secondary", "none", "--live-counters", "off",
+              "--profile-steps", "0"]
+    p = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = _last_json(p.stdout)
+    assert line["config"]["nbin"] == 10000 and line["config"]["columns_per_gpu"] == 1
+    assert line["config"]["flux_launch_policy"] == {"back_and_forth": True, "state_cached_mib": 240.0}
+    p = subprocess.run([sys.executable, "bench.py", "--columns-per-gpu", "4"] + common, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert _last_json(p.stdout)["config"]["flux_launch_policy"] == {"back_and_forth": False, "state_cached_mib": 0.0}
 
 
 def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
