@@ -457,6 +457,37 @@ def test_config2_full_size_all_bins_vs_the_reference_on_the_gpu(ctx):
     _premixed_column_vs_reference(ctx, c0)
 
 
+def test_config2_full_size_cached_state_and_launch_order_do_not_change_the_run(ctx, monkeypatch):
+    """the headline batch chooses the back-and-forth launch order with 240 MiB of up-flux state left in the Infinity
+    Cache by itself; 23 iterations -- launches in both directions, three refreshes -- are the run
+    with front-to-back launches and non-temporal stores bit for bit"""
+    import bench
+    from helios_amd.rt import batch_from_case
+    c0 = bench.build_case(bench.WORKLOADS["c2"], 20242)
+    c0.T_lay = 900.0 + 600.0 * (np.log10(np.append(c0.p_lay, c0.p_lay[0])) + 1.0) / 10.0
+
+    def run(force_off):
+        if force_off:
+            monkeypatch.setenv("HELIOS_RT_SERPENTINE", "0")
+        else:
+            monkeypatch.delenv("HELIOS_RT_SERPENTINE", raising=False)
+        monkeypatch.delenv("HELIOS_RT_STATE_CACHE_MB", raising=False)
+        rt = batch_from_case(ctx, c0, ncol=1)
+        try:
+            policy = rt.get("flux_launch_policy")
+            rt.build_planck_table(1)
+            rt.run(0, 23)
+            return policy, {k: rt.get(k) for k in ("T_lay", "F_net", "F_up_band", "F_down_band", "delta_t_prefactor")}
+        finally:
+            rt.close()
+    p_on, on = run(False)
+    p_off, off = run(True)
+    assert list(p_on) == [1.0, 240.0] and list(p_off) == [0.0, 0.0]
+    for k in off:
+        np.testing.assert_array_equal(on[k], off[k], err_msg=k)
+    assert np.abs(on["T_lay"] - c0.T_lay).max() > 1.0
+
+
 def test_config5_full_size_all_bins_vs_the_reference_on_the_gpu(ctx):
     """30 000 bins x 200 layers, two cloud decks, g0, I2S correction, surface albedo and the direct beam: the same
     comparison with the reference's kernels on this GPU, every bin"""
