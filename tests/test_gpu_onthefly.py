@@ -284,6 +284,34 @@ def test_run_helios_on_the_fly_from_hdf5_files(tmp_path):
     np.testing.assert_array_equal(a.F_up_band, b.F_up_band)
 
 
+def test_run_helios_premixed_from_a_real_h5py_file(tmp_path):
+    """`opacity mixing = premixed` with the k-table container of tests/golden/reader/hdf5/ -- written by h5py 3.3.0 as the
+    reference's k-table tool writes it (variable-length string datasets and all) -- through helios.py: the same run as
+    from an .npz archive of the same datasets, bit for bit"""
+    from helios_amd import hdf5_lite
+    if not hdf5_lite.available():
+        pytest.skip("no libhdf5 on this host")
+    h5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reader", "hdf5", "premixed_opac_kdistr.h5")
+    with hdf5_lite.File(h5) as f:
+        names = [k for k in f.keys() if k not in ("included molecules", "FastChem path", "units")]
+        np.savez(str(tmp_path / "premixed.npz"), **{k: f[k][()] for k in names})
+
+    def run(table, name):
+        argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "premixed", "-path_to_opacity_file", table,
+                "-number_of_layers", "20", "-maximum_number_of_iterations", "20000", "-name", name,
+                "-output_directory", str(tmp_path) + "/", "-convective_adjustment", "no", "-toa_pressure", "1e1",
+                "-boa_pressure", "1e7", "-radiative_equilibrium_criterion", "1e-3"]
+        return _run_driver(argv, True)
+    a = run(h5, "h5")
+    b = run(str(tmp_path / "premixed.npz"), "npz")
+    assert int(a.nbin) == 6 and int(a.ny) == 20 and int(a.ntemp) == 3 and int(a.npress) == 4
+    assert int(a.iter_value) == int(b.iter_value) and int(a.iter_value) >= 10
+    np.testing.assert_array_equal(a.opac_k, b.opac_k)
+    np.testing.assert_array_equal(a.T_lay, b.T_lay)
+    np.testing.assert_array_equal(a.F_up_band, b.F_up_band)
+    assert np.all(np.isfinite(a.T_lay)) and np.all(np.isfinite(a.F_up_band))
+
+
 def test_run_helios_with_additional_heating(tmp_path):
     """a heating-density file (e.g. UV heating of the upper atmosphere): per-stage loop, flux refreshed from the layer
     heights every 10th iteration; in equilibrium the atmosphere radiates the extra energy away"""
