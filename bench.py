@@ -55,6 +55,9 @@ WORKLOADS = {
     "c5premixed": dict(nbin=30000, nlayer=200, ny=20, ntemp=12, npress=10, clouds=2, albedo=0.1, scat_corr=1, g_0=0.1,
                        desc="config 5's shape with a premixed table: 30 000 bins x 200 layers, I2S correction, two cloud "
                             "decks, surface albedo, no beam (round 1-2's c5)"),
+    "c2beam": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, dir_beam=1, albedo=0.1,
+                   desc="config 2's grid with the direct stellar beam and a surface albedo (five coefficient planes, "
+                        "13 rows per lane)"),
     "c5small": dict(nbin=600, nlayer=200, ny=20, ntemp=6, npress=5, nspecies=6, clouds=2, albedo="smoothed", scat_corr=1,
                     g_0=0.3, dir_beam=1, desc="config 5's physics at 600 bins x 200 layers x 6 species (quick check)"),
     "c4": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=64, sweep=True,

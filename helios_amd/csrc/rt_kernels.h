@@ -650,6 +650,9 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 // (k = 32 / ROWS = 7 held to 128 VGPRs for four wavefronts per SIMD through amdgpu_waves_per_eu spills 49 dwords inside
 // the sweeps: 0.62 ms against 0.42 ms at its natural 169 registers and 0.40 ms for k = 16 -- not done.)
 // K: lanes per spectral point when known at compile time (16, 32, 64: the scans are straight-line DPP code), 0: a.k
+#ifndef HX_BEAM_GROUP
+#define HX_BEAM_GROUP 4
+#endif
 template <int ROWS, int K = 0>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
@@ -716,10 +719,29 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             su[r] = upc * Bt + vpc * Bb;
         }
         if (a.dir_beam == 1) {
+            // The rows of the two beam planes are requested in groups that are in flight together, and only then added: left
+            // to the scheduler, the loads came out as ONE register pair loaded and added once per row -- 14 (7 rows) or 26
+            // (13 rows) dependent memory round trips per tile; k_rt_flux<7, 64> took 3.70 instead of 3.40 ms per launch at
+            // config 5 (whether it happened depended on unrelated code: round 3's build had the 14 in flight together).
+            // Up to 8 rows per lane all at once; 13 rows in groups of BEAM_GROUP (the register file is full there).
+            constexpr int BEAM_GROUP = ROWS <= 8 ? ROWS : HX_BEAM_GROUP;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                sd[r] += __builtin_nontemporal_load(ctile + (a.pl_dd * ROWS + r) * 64);
-                su[r] += __builtin_nontemporal_load(ctile + ((a.pl_dd + 1) * ROWS + r) * 64);
+            for (int r0 = 0; r0 < ROWS; r0 += BEAM_GROUP) {
+                double bd[BEAM_GROUP], bu[BEAM_GROUP];
+#pragma unroll
+                for (int u = 0; u < BEAM_GROUP; u++)
+                    if (r0 + u < ROWS) {
+                        bd[u] = __builtin_nontemporal_load(ctile + (a.pl_dd * ROWS + r0 + u) * 64);
+                        bu[u] = __builtin_nontemporal_load(ctile + ((a.pl_dd + 1) * ROWS + r0 + u) * 64);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < BEAM_GROUP; u++)
+                    if (r0 + u < ROWS) {
+                        sd[r0 + u] += bd[u];
+                        su[r0 + u] += bu[u];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const double rs = cp.R_star / cp.a;
