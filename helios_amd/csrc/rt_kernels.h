@@ -494,10 +494,14 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 const int l0 = run * per, l1 = min(nlev, l0 + per);
                 int ktd = -1, ktu = -1, kpd = -1, kpu = -1;
                 double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+                // (the cell of the next level is requested while this level's corners are on their way: the look-up was a
+                // chain of two dependent requests per level)
+                TPIndex knext = tp[min(l0, nlev - 1)];
                 for (int lev = l0; lev < l1; lev++) {
                     double v = 0.0;
+                    const TPIndex k = knext;
+                    knext = tp[min(lev + 1, nlev - 1)];
                     if (cq >= 0) {
-                        const TPIndex k = tp[lev];
                         if (k.tdown != ktd || k.tup != ktu || k.pdown != kpd || k.pup != kpu) {
                             const double* t0 = a.ktable + (size_t)cq + st * k.tdown;
                             const double* t1 = a.ktable + (size_t)cq + st * k.tup;
