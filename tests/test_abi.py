@@ -129,6 +129,25 @@ def test_no_selected_flux_kernel_keeps_registers_in_scratch():
     assert spilling and not (spilling & seen)
 
 
+def test_no_flux_kernel_serialises_its_tile_loads():
+    """round 4 found the loads of the two direct-beam planes of k_rt_flux compiled into ONE register pair that is loaded,
+    waited for and added once per row -- 14 to 26 dependent memory round trips per tile, 9 to 23 % of the kernel -- and
+    whether the compiler did so depended on unrelated code.  The disassembly of the library's code objects is held to it:
+    no instantiation loads more than six times into the same destination (rows requested in groups leave three to six)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("code_object_notes", os.path.join(ROOT, "tools", "code_object_notes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dest = mod.load_destinations(name_filter="k_rt_flux<")
+    assert len(dest) >= 4 * 16
+    worst = {n: max(c.values()) for n, c in dest.items() if c}
+    assert len(worst) == len(dest)
+    assert max(worst.values()) <= 6, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    # rows x 7 tile loads (three to six coefficient planes, the state) are all there
+    rows = int([n for n in dest if "k_rt_flux<13, 16>" in n][0].split("<")[1].split(",")[0])
+    assert sum(dest[[n for n in dest if "k_rt_flux<13, 16>" in n][0]].values()) >= 7 * rows
+
+
 def test_only_the_unselected_flux_tilings_use_scratch():
     """every other kernel of the library -- the species loop with random overlap, the coefficient kernel, all per-stage
     kernels -- runs without a private segment (k_rt_mix_species kept 7 VGPRs in scratch in round 2: 2.1 GB of stores per

@@ -73,6 +73,33 @@ def kernel_notes(path=None):
     return kernels
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def load_destinations(path=None, name_filter="k_rt_flux"):
+    """{demangled kernel name: {destination register (pair): number of global loads into it}} from the disassembly of
+    the library's gfx950 code objects.  Many loads into ONE register pair are loads the compiler serialised -- each has
+    to be waited for before the next can be issued (round 4: the direct-beam planes of k_rt_flux)"""
+    from collections import Counter
+    path = path or os.path.join(ROOT, "helios_amd", "libhelios_hip.so")
+    out = {}
+    for _triple, elf in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as tf:
+            tf.write(elf)
+            tf.flush()
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", tf.name], capture_output=True, text=True,
+                                 check=True).stdout
+        for block in re.split(r"\n(?=[0-9a-f]+ <)", txt):
+            m = re.match(r"[0-9a-f]+ <([^>]+)>:", block)
+            if not m:
+                continue
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+            if name_filter not in name:
+                continue
+            out[name] = dict(Counter(re.findall(r"global_load_dword(?:x2|x3|x4)?\s+(v\[?\d+(?::\d+)?\]?),", block)))
+    return out
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     flt = sys.argv[sys.argv.index("--filter") + 1] if "--filter" in sys.argv else ""
