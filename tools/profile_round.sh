@@ -40,6 +40,7 @@ python3 bench.py --columns-per-gpu 4 --steps 50 --no-cpu-baseline --secondary no
 python3 bench.py --phase convection --steps 100 --no-cpu-baseline > $O/c2_bench_convection_loop.json 2>> $O/bench.err
 python3 bench.py --workload c5 --steps 20 --warmup 10 > $O/c5_bench.json 2>> $O/bench.err
 python3 bench.py --workload c5premixed --steps 30 --warmup 10 --no-cpu-baseline > $O/c5premixed_bench.json 2>> $O/bench.err
+python3 bench.py --workload c2beam --steps 50 --warmup 10 --no-cpu-baseline --secondary none > $O/c2beam_bench.json 2>> $O/bench.err
 python3 bench.py --phase convection --workload c5 --steps 20 --warmup 10 --no-cpu-baseline --secondary none --live-counters off > $O/c5_bench_convection_loop.json 2>> $O/bench.err
 # eight ranks on the one GPU of this box through the gloo hook: the multi-rank path incl. the config-4 share as `secondary`
 HELIOS_BENCH_BACKEND=gloo python3 bench.py --gpus 8 --workload c2small --steps 20 --warmup 10 --secondary c4small --no-cpu-baseline > $O/bench_8ranks_one_gpu_gloo.json 2>> $O/bench.err
