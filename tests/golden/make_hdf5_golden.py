@@ -72,6 +72,11 @@ def tables(rng):
                         "original/phoenix/gj1214/flux": 10.0 ** rng.uniform(2, 8, 31),
                         "original/phoenix/gj1214/lambda": np.linspace(1e-5, 1e-2, 31),
                         "r20_kdistr/phoenix/gj1214": 10.0 ** rng.uniform(2, 8, nbin + 2)}
+    # storage types other tools choose: single precision, big-endian, 32-bit and unsigned 8-bit integers, a chunked 2-D
+    # single-precision table -- h5py hands every one of them to the reference as numbers; the readers take fp64 / int64
+    files["dtypes.h5"] = {"f4": rng.random(11).astype("<f4"), "f8_be": rng.random(5).astype(">f8"),
+                          "i4": rng.integers(-9, 9, 7).astype("<i4"), "u1": rng.integers(0, 255, 6).astype("u1"),
+                          "table_f4": rng.random((4, 6)).astype("<f4"), "i8_be": rng.integers(-2 ** 40, 2 ** 40, 3).astype(">i8")}
     return files
 
 
@@ -81,7 +86,9 @@ def write_files(files):
     for fname, d in files.items():
         with h5py.File(os.path.join(OUT, fname), "w") as f:
             for k, v in d.items():
-                if fname == "BBB_opac_ip.h5" and k == "kpoints":
+                if fname == "dtypes.h5" and k == "table_f4":
+                    f.create_dataset(k, data=v, chunks=(2, 3), compression="gzip")
+                elif fname == "BBB_opac_ip.h5" and k == "kpoints":
                     f.create_dataset(k, data=v, chunks=(97,), compression="gzip", compression_opts=4, shuffle=True)
                 else:
                     f.create_dataset(k, data=v)      # nested names make the intermediate groups
@@ -180,6 +187,13 @@ def main():
     except OverflowError:
         raised = "OverflowError"
     exp["star_wrong_length/raised"] = np.array(raised)
+
+    # what h5py itself returns for the storage-type file, as float64 / int64
+    import h5py
+    with h5py.File(os.path.join(OUT, "dtypes.h5"), "r") as f:
+        for k in f.keys():
+            v = f[k][()]
+            exp["dtypes/" + k] = v.astype(np.float64 if v.dtype.kind == "f" else np.int64)
 
     np.savez(os.path.join(OUT, "expected.npz"), **exp)
 

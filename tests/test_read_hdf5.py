@@ -248,6 +248,25 @@ def test_stellar_spectrum_by_nested_path(no_h5py):
 
 
 @needs_hdf5
+def test_storage_types_other_tools_choose(no_h5py):
+    """single precision, big-endian doubles and integers, 32-bit and unsigned 8-bit integers, a chunked + compressed 2-D
+    single-precision table, all written by h5py: the readers hand out fp64 / int64 with the values h5py itself returns"""
+    from helios_amd.read import _Table
+    t = _Table(os.path.join(H5, "dtypes.h5"))
+    exp = _expected("dtypes")
+    assert sorted(exp) == ["f4", "f8_be", "i4", "i8_be", "table_f4", "u1"] and sorted(t.keys()) == sorted(exp)
+    for k, v in exp.items():
+        got = np.asarray(t[k])
+        assert got.shape == v.shape, k
+        np.testing.assert_array_equal(got.astype(v.dtype), v, err_msg=k)
+    if no_h5py == "libhdf5":
+        with hdf5_lite.File(os.path.join(H5, "dtypes.h5")) as f:
+            assert f["f4"][()].dtype == np.float64 and f["table_f4"][()].dtype == np.float64 and f["table_f4"].shape == (4, 6)
+            assert f["i4"][()].dtype == np.int64 and f["u1"][()].dtype == np.int64 and f["i8_be"][()].dtype == np.int64
+            assert abs(int(f["i8_be"][()][0])) > 2 ** 31 or abs(int(f["i8_be"][()][1])) > 2 ** 31 or abs(int(f["i8_be"][()][2])) > 2 ** 31
+
+
+@needs_hdf5
 def test_writer_round_trip_and_h5dump(tmp_path, no_h5py):
     rng = np.random.default_rng(8)
     d = {"kpoints": rng.random(240), "grid/deep/er": rng.random((3, 4)), "count": np.arange(5), "scalar": np.float64(2.5),
