@@ -30,10 +30,29 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+def _cpu_baseline_will_run(argv, env):
+    """only the N = 1 process that times the CPU oracle at the end"""
+    if int(env.get("WORLD_SIZE", "1")) != 1 or "--no-cpu-baseline" in argv:
+        return False
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv) and argv[i + 1] != "1":
+            return False
+        if a.startswith("--gpus=") and a != "--gpus=1":
+            return False
+    return True
+
+
 # the CPU baseline's OpenMP threads stay on the cores they start on, packed onto neighbouring cores (one NUMA domain for the
-# thread counts that win): read by the OpenMP runtime when it is loaded, so set before anything loads it
-os.environ.setdefault("OMP_PROC_BIND", "close")
-os.environ.setdefault("OMP_PLACES", "cores")
+# thread counts that win): read by the OpenMP runtime when it is loaded, so set before anything loads it -- and ONLY in the
+# process that runs the baseline: with binding on, the runtime pins the initial thread to place 0, i.e. the N ranks of a
+# multi-GPU run (and every rocprofv3 child pass) would issue their launches from one and the same core
+_OMP_SET_HERE = []
+if _cpu_baseline_will_run(sys.argv[1:], os.environ):
+    for _k, _v in (("OMP_PROC_BIND", "close"), ("OMP_PLACES", "cores")):
+        if _k not in os.environ:
+            os.environ[_k] = _v
+            _OMP_SET_HERE.append(_k)
 
 import numpy as np  # noqa: E402
 
@@ -41,8 +60,6 @@ WORKLOADS = {
     # name: (nbin, nlayer, ny, ntemp, npress)
     "c2": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20,
                desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
-    "c2beam": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, dir_beam=1, albedo=0.1,
-                   desc="config 2's shape with the direct beam and a reflecting surface (five coefficient planes)"),
     "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20, scat=0,
                desc="BASELINE config 1: single column, 300 bins x 50 layers, premixed, no scattering"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
@@ -333,6 +350,8 @@ def live_counters(workload, counters=("FETCH_SIZE", "WRITE_SIZE"), ncol=1):
                    "--profile-steps", "0", "--secondary", "none", "--live-counters", "off", "--device-warmup-ms", "0",
                    "--columns-per-gpu", str(int(ncol))]
             env = dict(os.environ, TMPDIR=tmp)
+            for k in _OMP_SET_HERE:       # the binding is the CPU baseline's, not the profiled children's
+                env.pop(k, None)
             try:
                 p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True,
                                    timeout=900 if WORKLOADS[workload].get("nspecies") else 240)

@@ -9,7 +9,9 @@ import os
 from ._cproto import parse_prototypes, bind
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhelios_hip.so")
+# HELIOS_HIP_LIB: another build of the same library (same-box A/B measurements select their variant with it instead of
+# copying over the in-tree file); the product loads the in-tree library
+LIB_PATH = os.environ.get("HELIOS_HIP_LIB") or os.path.join(_HERE, "libhelios_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "helios_hip.h")
 
 _lib = None

@@ -457,9 +457,16 @@ class Compute(object):
                                is_h2o=2 if (sp.scattering == "yes" and sp.name == "H2O") else 0,
                                is_cia=1 if "CIA" in sp.name else 0, in_mu=1 if hsfunc._counts_for_mu(sp) else 0)
                 # calculate_vmr_for_all_species on the device: a FastChem species hands over its (T, P) table once and its
-                # profile is interpolated from the device's temperatures at every refresh (host_functions.py:874-910)
-                if getattr(sp, "source_for_vmr", "") == "FastChem" and getattr(sp, "vmr_pretab", None) is not None:
-                    rt.set_species_vmr_table(s, np.asarray(sp.vmr_pretab, np.float64).reshape(-1))
+                # profile is interpolated from the device's temperatures at every refresh (host_functions.py:874-910).
+                # One table per COLUMN: the Stores of a sweep each read their own FastChem directory (read.py:577-606)
+                if getattr(sp, "source_for_vmr", "") == "FastChem":
+                    for c, qc in enumerate(quants):
+                        spc = qc.species_list[s]
+                        if getattr(spc, "source_for_vmr", "") != "FastChem" or getattr(spc, "vmr_pretab", None) is None:
+                            raise ValueError("make_rt_batch: species %r is FastChem-tabulated in column 0 but not in column %d; "
+                                             "columns of one batch share the species list and the kind of their mixing ratios"
+                                             % (getattr(sp, "name", s), c))
+                        rt.set_column_vmr_table(c, s, np.asarray(spc.vmr_pretab, np.float64).reshape(-1))
         else:
             rt.set_premixed_tables(q.opac_k, q.opac_scat_cross, q.opac_meanmass)
         if self._kappa_from_table(q):

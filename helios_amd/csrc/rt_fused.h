@@ -28,7 +28,7 @@ struct TileGeom {
 struct Species {
     double* pretab = nullptr;      // device, [t][p][x][y] flat (reference order), or null
     double* scat_cross = nullptr;  // device [nbin], or null
-    double* vmr_tab = nullptr;     // device [ntemp][npress] mixing ratios on the opacity grid (hx_rt_set_species_vmr_table), or null
+    double* vmr_tab = nullptr;     // device [column][ntemp][npress] mixing ratios on the opacity grid (hx_rt_set_column_vmr_table), or null
     bool vmr_from_tab = false;
     double weight = 0.0;
     int is_h2o = 0, is_cia = 0, in_mu = 1;

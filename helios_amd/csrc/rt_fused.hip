@@ -570,21 +570,37 @@ int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const doub
     return 0;
 }
 
+static int for_cols(hx_rt* rt, int col, int* c0, int* c1);
+
 // calculate_vmr_for_all_species on the device (host_functions.py:874-910): a species whose mixing ratio is tabulated on the
 // opacity tables' (T, P) grid -- vmr_pretab[p + npress * t], what read.py keeps per FastChem species -- follows the
-// temperatures of every refresh without a host step.  NULL: back to the profiles of hx_rt_set_column_vmr.
-int hx_rt_set_species_vmr_table(hx_rt* rt, int s, const double* vmr_pretab) {
+// temperatures of every refresh without a host step.  One table per COLUMN (a sweep over FastChem directories -- metallicity,
+// C/O -- gives every column its own chemistry, read.py:577-606); col < 0 hands the same table to all columns.  NULL (any
+// col): the species goes back to the profiles of hx_rt_set_column_vmr in every column.
+int hx_rt_set_column_vmr_table(hx_rt* rt, int col, int s, const double* vmr_pretab) {
     if (!rt) return HX_E_ARG;
     rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
     HX_REQUIRE(rt->ctx, rt->d.ntemp >= 2 && rt->d.npress >= 2, HX_E_ARG, "a mixing-ratio table needs at least 2 x 2 nodes");
+    int c0, c1;
+    int rc = for_cols(rt, col, &c0, &c1);
+    if (rc) return rc;
     Species& sp = rt->species[s];
-    sp.vmr_from_tab = vmr_pretab != nullptr;
     rt->species_dev_stale = true;
-    if (!vmr_pretab) return 0;
+    if (!vmr_pretab) {
+        sp.vmr_from_tab = false;
+        return 0;
+    }
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
-    if (!sp.vmr_tab) RT_ALLOC(sp.vmr_tab, ntp);
-    return h2d(rt, sp.vmr_tab, vmr_pretab, ntp * 8);
+    // (zero-initialised: a column that is never given a table of its own reads zeros -- its species is absent)
+    if (!sp.vmr_tab) RT_ALLOC(sp.vmr_tab, ntp * rt->C);
+    sp.vmr_from_tab = true;
+    for (int c = c0; c < c1 && !rc; c++) rc = h2d(rt, sp.vmr_tab + ntp * c, vmr_pretab, ntp * 8);
+    return rc;
+}
+
+int hx_rt_set_species_vmr_table(hx_rt* rt, int s, const double* vmr_pretab) {
+    return hx_rt_set_column_vmr_table(rt, -1, s, vmr_pretab);
 }
 
 static int for_cols(hx_rt* rt, int col, int* c0, int* c1) {
@@ -1291,7 +1307,9 @@ static bool graph_wanted(hx_rt* rt) {
     }
     // not while the event profiler brackets every launch, not with the per-iteration host decisions of the time-stepped
     // kappa refresh (computation.py:921-923)
-    return rt->use_graph == 1 && !rt->profiling && !rt->matrix && !(rt->entr_kappa && rt->cols[0].physical_tstep != 0);
+    bool time_stepped = false;   // any column of the batch
+    for (const auto& c : rt->cols) time_stepped = time_stepped || c.physical_tstep != 0;
+    return rt->use_graph == 1 && !rt->profiling && !rt->matrix && !(rt->entr_kappa && time_stepped);
 }
 
 static int build_iteration_graph(hx_rt* rt) {
@@ -1307,9 +1325,11 @@ static int build_iteration_graph(hx_rt* rt) {
     const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
-        rt->use_graph = 0;   // this batch iterates launch by launch
+        // this batch iterates launch by launch from here on: hx_rt_run goes on through hx_rt_step, where a launch that
+        // really fails fails again, outside a capture and with its own message
+        rt->use_graph = 0;
         (void)hipGetLastError();
-        return rc;
+        return 0;
     }
     const hipError_t ei = hipGraphInstantiate(&rt->iter_graph, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);

@@ -24,7 +24,8 @@ namespace hx {
 struct SpeciesDev {
     const double* pretab;      // [t][p][x][y] flat (reference order) or null
     const double* scat_cross;  // [x] or null
-    const double* vmr_tab;     // mixing ratio on the opacity tables' (T, P) grid, [p + npress * t], or null: profile given by the host
+    const double* vmr_tab;     // mixing ratio on the opacity tables' (T, P) grid, one table per column: [column][p + npress * t],
+                               // or null: profile given by the host
     double weight;             // molar weight
     int absorbing, scattering, is_h2o, ro, in_mu, pad;
 };
@@ -83,7 +84,9 @@ __global__ void k_rt_species_prep(MixArgs a) {
         // calculate_vmr_for_all_species (host_functions.py:874-901) for the species that come with a (T, P) table: the
         // profile follows the temperatures of this refresh, on the device
         for (int s = 0; s < a.S; s++)
-            if (a.sp[s].vmr_tab) vmr[(size_t)s * a.I + i] = vmr_from_table(a.sp[s].vmr_tab, T, P, a.ktemp, a.ntemp, a.kpress, a.npress);
+            if (a.sp[s].vmr_tab)
+                vmr[(size_t)s * a.I + i] = vmr_from_table(a.sp[s].vmr_tab + (size_t)col * a.ntemp * a.npress, T, P, a.ktemp, a.ntemp,
+                                                          a.kpress, a.npress);
         double num = 0.0, tot = 0.0;  // host_functions.py:927-959
         for (int s = 0; s < a.S; s++)
             if (a.sp[s].in_mu) {
@@ -112,8 +115,8 @@ __global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, doub
     double* vmr = vmr_lay + (size_t)col * S * I;
     for (int s = 0; s < S; s++)
         if (sp[s].vmr_tab)
-            vmr[(size_t)s * I + i] = vmr_from_table(sp[s].vmr_tab, T_lay[(size_t)col * (L + 1) + i], p_lay[(size_t)col * L + i],
-                                                    ktemp, ntemp, kpress, npress);
+            vmr[(size_t)s * I + i] = vmr_from_table(sp[s].vmr_tab + (size_t)col * ntemp * npress, T_lay[(size_t)col * (L + 1) + i],
+                                                    p_lay[(size_t)col * L + i], ktemp, ntemp, kpress, npress);
     double num = 0.0, tot = 0.0;
     for (int s = 0; s < S; s++)
         if (sp[s].in_mu) {

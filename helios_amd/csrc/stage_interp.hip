@@ -9,51 +9,100 @@ using namespace hx;
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// Planck table: tab[x + r*nbin] = (D/dlambda) * sum_{n=1}^{199} [Phi_n(y_top) - Phi_n(y_bot)]
-// (kernels.cu:95-105, :362-416).  One thread per (x, row); x fastest.
+// Planck table: tab[x + r*nbin] = (D/dlambda) * sum_{n=1}^{199} [Phi_n(y_top) - Phi_n(y_bot)],
+//     Phi_n(y) = exp(-n y) (y^3/n + 3 y^2/n^2 + 6 y/n^3 + 6/n^4)
+// (kernels.cu:95-105, :362-416).  8 001 rows x nbin bins x 199 terms, each with two `exp` and eight
+// divisions in the reference's formula: 70 ms at 10 000 bins, 200 ms at 30 000 -- set-up time a run pays before its first
+// iteration.  Same values bit for bit, a quarter of the instructions:
+//   * a bin's upper edge is its neighbour's lower edge and y(edge, T) is the same expression for both, so Phi_n is evaluated
+//     once per EDGE -- lane l of a wavefront holds edge x0 + l, the 63 bins x0 ... x0 + 62 take their second value from the
+//     next lane (DPP wave_shl:1; one edge per wavefront is evaluated twice);
+//   * a / n^k with the correctly rounded reciprocal r = RN(1 / n^k) from a table (wave-uniform: scalar loads): q = RN(a r),
+//     q' = fma(fma(-q, n^k, a), r, q) is the correctly rounded quotient (Markstein's theorem: r correctly rounded, q within
+//     one ulp) -- three instructions instead of the division's scale / reciprocal / Newton / fix-up sequence.  On the CPU the
+//     whole table of config 2's grid and the test grids: not one entry differs from the divisions;
+//   * exp(-n y) underflows to exactly 0 beyond n y = 745.2, for that n and every later one: a wavefront whose edges have all
+//     reached it leaves the loop (short wavelengths / low temperatures: most of the table's rows).
+// A multiply-recurrence for exp(-n y) (re-anchored or in double-double) is NOT used: at 10 000 bins the Rayleigh-Jeans corner
+// of the table cancels eleven digits inside the formula and the entries move by 1e-4 relative -- the table's own noise, but
+// two hundred times the tolerance the table is held to against the reference.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double planck_term(int n, double y1, double y2) {
-    const double dn = n;
-    return exp(-dn * y2) * ((y2 * y2 * y2) / dn + 3.0 * (y2 * y2) / (dn * dn) +
-                            6.0 * y2 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn)) -
-           exp(-dn * y1) * ((y1 * y1 * y1) / dn + 3.0 * (y1 * y1) / (dn * dn) +
-                            6.0 * y1 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn));
+struct PlanckSeriesTable {
+    double d[200][4];  // n, n^2, n^3, n^4 (exact)
+    double r[200][4];  // their reciprocals, correctly rounded (host division)
+};
+__constant__ PlanckSeriesTable c_planck_series;
+
+__device__ __forceinline__ double quotient(double a, double d, double r) {
+    const double q = a * r;
+    return fma(fma(-q, d, a), r, q);
 }
+
+__device__ __forceinline__ double next_lane(double v) {  // the value of lane + 1 (lane 63: its own, unused)
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int PLANCK_BINS_PER_WAVE = 63, PLANCK_WAVES = 4;
 
 __device__ __forceinline__ void planck_row_entry(double* __restrict__ grid, const double* __restrict__ lambda_edge,
                                                  const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T,
                                                  int step) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = (blockIdx.x * PLANCK_WAVES + wave) * PLANCK_BINS_PER_WAVE + lane;   // this lane's edge, and its bin
     const int r = blockIdx.y;
-    if (x >= nbin) return;
+    if (x - lane >= nbin) return;   // (whole wavefronts only: the lanes exchange values below)
     const double T = (r < nrow_T) ? (double)(r * step + 1) : Tstar;
+    const bool bin = lane < PLANCK_BINS_PER_WAVE && x < nbin;
     double acc = 0.0;
     if (T > 0.01) {
         const double kh = HX_KBOLTZMANN / HX_HCONST;
         const double D = 2.0 * (kh * kh * kh * HX_KBOLTZMANN * (T * T * T * T)) / (HX_CSPEED * HX_CSPEED);
-        double y_top = HX_HCONST * HX_CSPEED / (lambda_edge[x + 1] * HX_KBOLTZMANN * T);
-        double y_bot = HX_HCONST * HX_CSPEED / (lambda_edge[x] * HX_KBOLTZMANN * T);
-        if (y_bot < y_top) {
-            const double s = y_top;
-            y_top = y_bot;
-            y_bot = s;
+        const double y = x <= nbin ? HX_HCONST * HX_CSPEED / (lambda_edge[x] * HX_KBOLTZMANN * T) : 1e6;  // (beyond the grid: e = 0)
+        // the reference orders the two edges of a bin so that y_top < y_bot (:399-403) and sums D * (Phi(y_top) - Phi(y_bot))
+        const bool mine_is_bot = !(y < next_lane(y));
+        const double y2 = y * y, y3 = y2 * y, a2 = 3.0 * y2, a1 = 6.0 * y;
+        for (int n = 1; n < 200; n++) {
+            const double dn = c_planck_series.d[n][0];
+            const double e = exp(-dn * y);
+            if (__ballot(e != 0.0) == 0ull) break;   // every later term of every bin of this wavefront is 0 - 0
+            const double phi = e * (quotient(y3, dn, c_planck_series.r[n][0]) + quotient(a2, c_planck_series.d[n][1], c_planck_series.r[n][1]) +
+                                    quotient(a1, c_planck_series.d[n][2], c_planck_series.r[n][2]) +
+                                    quotient(6.0, c_planck_series.d[n][3], c_planck_series.r[n][3]));
+            const double other = next_lane(phi);
+            acc += D * (mine_is_bot ? other - phi : phi - other);
         }
-        for (int n = 1; n < 200; n++) acc += D * planck_term(n, y_bot, y_top);
     }
-    grid[x + (size_t)r * nbin] = acc / dlambda[x];
+    if (bin) grid[x + (size_t)r * nbin] = acc / dlambda[x];
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * PLANCK_WAVES)
 k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
               const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T, int step) {
     planck_row_entry(grid, lambda_edge, dlambda, nbin, Tstar, nrow_T, step);
 }
 
 // one row at the stellar temperature (a name of its own, so that kernel statistics do not average it with the table)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * PLANCK_WAVES)
 k_planck_star_row(double* __restrict__ row, const double* __restrict__ lambda_edge,
                   const double* __restrict__ dlambda, int nbin, double Tstar) {
     planck_row_entry(row, lambda_edge, dlambda, nbin, Tstar, 0, 1);
+}
+
+int upload_planck_series(hx_context* ctx) {
+    static const PlanckSeriesTable tab = [] {
+        PlanckSeriesTable t{};
+        for (int n = 1; n < 200; n++) {
+            const double dn = n;
+            t.d[n][0] = dn; t.d[n][1] = dn * dn; t.d[n][2] = dn * dn * dn; t.d[n][3] = dn * dn * dn * dn;
+            for (int k = 0; k < 4; k++) t.r[n][k] = 1.0 / t.d[n][k];
+        }
+        return t;
+    }();
+    // (per call: the symbol belongs to the device that is current, a few KB on the stream)
+    HX_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_planck_series), &tab, sizeof(tab), 0, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
 }
 
 // incident-energy correction (kernels.cu:420-468): ONE block sums dlambda*F over all bins in a
@@ -166,9 +215,11 @@ int hx_plancktable(hx_context* ctx, double* planck_grid, const double* lambda_ed
                    const double* deltalambda, int nwave, double Tstar, int dim, int step) {
     HX_REQUIRE(ctx, nwave > 0 && dim >= 10 && step > 0, HX_E_ARG, "bad dimensions");
     const int nrow_T = 10 * (dim / 10);  // the reference fills rows in ten launches of dim/10
-    dim3 grid(hx_cdiv(nwave, 256), nrow_T + 1);
-    k_plancktable<<<grid, 256, 0, ctx->stream>>>(planck_grid, lambda_edge, deltalambda, nwave, Tstar,
-                                                 nrow_T, step);
+    int rc = upload_planck_series(ctx);
+    if (rc) return rc;
+    dim3 grid(hx_cdiv(nwave, PLANCK_BINS_PER_WAVE * PLANCK_WAVES), nrow_T + 1);
+    k_plancktable<<<grid, 64 * PLANCK_WAVES, 0, ctx->stream>>>(planck_grid, lambda_edge, deltalambda, nwave, Tstar,
+                                                             nrow_T, step);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -176,7 +227,10 @@ int hx_plancktable(hx_context* ctx, double* planck_grid, const double* lambda_ed
 // internal (not part of the C-ABI): the stellar row only, for per-column stars of a batch
 int hx_internal_planck_star_row(hx_context* ctx, double* row, const double* lambda_edge,
                                 const double* deltalambda, int nwave, double Tstar) {
-    k_planck_star_row<<<dim3(hx_cdiv(nwave, 256), 1), 256, 0, ctx->stream>>>(row, lambda_edge, deltalambda, nwave, Tstar);
+    int rc = upload_planck_series(ctx);
+    if (rc) return rc;
+    k_planck_star_row<<<dim3(hx_cdiv(nwave, PLANCK_BINS_PER_WAVE * PLANCK_WAVES), 1), 64 * PLANCK_WAVES, 0, ctx->stream>>>(
+        row, lambda_edge, deltalambda, nwave, Tstar);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -68,7 +68,11 @@ def _load():
             continue
         lib._version = (maj.value, mnr.value, rel.value)
         lib._path = cand
-        _declare(lib)
+        try:
+            _declare(lib)
+        except (AttributeError, ValueError) as e:    # a build that lacks a symbol this module needs: try the next candidate
+            errors.append("%s: %s" % (cand, e))
+            continue
         lib.H5Eset_auto2(_hid(0), None, None)    # errors are reported through return codes, not printed
         _lib = lib
         return _lib
@@ -88,7 +92,6 @@ def _declare(lib):
         "H5Sget_simple_extent_npoints": (C.c_int64, [_hid]),
         "H5Dread": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
         "H5Dwrite": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
-        "H5Dvlen_reclaim": (C.c_int, [_hid, _hid, _hid, C.c_void_p]),
         "H5Screate_simple": (_hid, [C.c_int, C.POINTER(_hsize), C.POINTER(_hsize)]), "H5Screate": (_hid, [C.c_int]),
         "H5Dcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid, _hid]),
         "H5Gcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid]), "H5Gclose": (C.c_int, [_hid]),
@@ -102,7 +105,17 @@ def _declare(lib):
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    for g in ("H5T_NATIVE_DOUBLE_g", "H5T_NATIVE_INT64_g", "H5T_C_S1_g", "H5P_CLS_DATASET_CREATE_ID_g"):
+    # variable-length strings are handed back through H5Treclaim (1.12 on) or H5Dvlen_reclaim (deprecated there, absent from
+    # builds without the deprecated API): whichever the library has; with neither the few bytes stay with the library
+    lib._reclaim = None
+    for name in ("H5Treclaim", "H5Dvlen_reclaim"):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = C.c_int, [_hid, _hid, _hid, C.c_void_p]
+            lib._reclaim = fn
+            break
+    lib.H5Tget_sign.restype, lib.H5Tget_sign.argtypes = C.c_int, [_hid]
+    for g in ("H5T_NATIVE_DOUBLE_g", "H5T_NATIVE_INT64_g", "H5T_NATIVE_UINT64_g", "H5T_C_S1_g", "H5P_CLS_DATASET_CREATE_ID_g"):
         setattr(lib, "_" + g, _hid.in_dll(lib, g).value)
 
 
@@ -227,10 +240,16 @@ class File(object):
             npoints = int(lib.H5Sget_simple_extent_npoints(space))
             cls = lib.H5Tget_class(ftype)
             if cls == _H5T_FLOAT or cls == _H5T_INTEGER:
-                out = np.empty(shape, np.float64 if cls == _H5T_FLOAT else np.int64)
-                mem = lib._H5T_NATIVE_DOUBLE_g if cls == _H5T_FLOAT else lib._H5T_NATIVE_INT64_g
+                # unsigned 64-bit storage is read as such (through int64 its upper half would saturate silently) and handed
+                # over as int64 only where every value fits
+                wide_unsigned = cls == _H5T_INTEGER and lib.H5Tget_sign(ftype) == 0 and lib.H5Tget_size(ftype) >= 8
+                out = np.empty(shape, np.float64 if cls == _H5T_FLOAT else (np.uint64 if wide_unsigned else np.int64))
+                mem = (lib._H5T_NATIVE_DOUBLE_g if cls == _H5T_FLOAT else
+                       lib._H5T_NATIVE_UINT64_g if wide_unsigned else lib._H5T_NATIVE_INT64_g)
                 if npoints and lib.H5Dread(d, mem, _H5S_ALL, _H5S_ALL, _H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)) < 0:
                     raise IOError("cannot read dataset '%s' of %s" % (name, self._path))
+                if wide_unsigned and (not npoints or int(out.max()) <= np.iinfo(np.int64).max):
+                    out = out.astype(np.int64)
                 return out
             if cls == _H5T_STRING:
                 mem = lib.H5Tcopy(ftype)       # the file's own string type (character set, padding) serves as memory type
@@ -240,8 +259,8 @@ class File(object):
                         if npoints and lib.H5Dread(d, mem, _H5S_ALL, _H5S_ALL, _H5P_DEFAULT, ptrs) < 0:
                             raise IOError("cannot read dataset '%s' of %s" % (name, self._path))
                         vals = [ptrs[k] or b"" for k in range(npoints)]
-                        if npoints:
-                            lib.H5Dvlen_reclaim(mem, space, _H5P_DEFAULT, ptrs)
+                        if npoints and lib._reclaim is not None:
+                            lib._reclaim(mem, space, _H5P_DEFAULT, ptrs)
                     else:
                         size = int(lib.H5Tget_size(ftype))
                         raw = C.create_string_buffer(max(npoints, 1) * size)

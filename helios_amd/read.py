@@ -172,7 +172,14 @@ class _Table(object):
     def __getitem__(self, name):
         if self._npz is not None:
             return self._npz[name]
-        return np.asarray(self._h5[name][()])
+        a = np.asarray(self._h5[name][()])
+        # one dtype whichever backend read the file: h5py hands over the storage type (float32, int16, big-endian ...),
+        # hdf5_lite fp64 / int64
+        if a.dtype.kind == "f":
+            return a.astype(np.float64, copy=False)
+        if a.dtype.kind in "iu" and (a.dtype.kind == "i" or a.size == 0 or int(a.max()) <= np.iinfo(np.int64).max):
+            return a.astype(np.int64, copy=False)
+        return a
 
     def keys(self):
         return list(self._npz.keys()) if self._npz is not None else list(self._h5.keys())

@@ -110,6 +110,11 @@ class RTBatch(object):
         t = _f64(vmr_pretab)
         self._ck(self._l.hx_rt_set_species_vmr_table(self.handle, s, _dp(t)), "hx_rt_set_species_vmr_table")
 
+    def set_column_vmr_table(self, col, s, vmr_pretab):
+        """the same for ONE column of the batch (col < 0: all): columns of a sweep may come with their own chemistry"""
+        t = _f64(vmr_pretab)
+        self._ck(self._l.hx_rt_set_column_vmr_table(self.handle, int(col), s, _dp(t)), "hx_rt_set_column_vmr_table")
+
     def set_column_profile(self, col, p_lay, p_int, T_lay, surf_albedo=None, starflux=None):
         arrs = [_f64(a) for a in (p_lay, p_int, T_lay, surf_albedo, starflux)]
         self._ck(self._l.hx_rt_set_column_profile(self.handle, col, *[_dp(a) for a in arrs]),

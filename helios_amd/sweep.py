@@ -85,9 +85,13 @@ def _prepare_column(base_argv, overrides, shared):
 
 
 def _batch_signature(q):
+    # (the species list and where each species' mixing ratio comes from: a batch shares the opacity tables and hands the
+    # device one (T, P) chemistry table per column for the FastChem species -- which species those are must agree)
+    chem = tuple((str(getattr(sp, "name", "")), str(getattr(sp, "source_for_vmr", "")))
+                 for sp in (getattr(q, "species_list", None) or [])) if str(q.opacity_mixing) == "on-the-fly" else ()
     return (int(q.nbin), int(q.ny), int(q.nlayer), int(q.scat), int(q.dir_beam), int(q.clouds), int(q.scat_corr),
             int(q.smooth), int(q.convection), str(q.opacity_mixing), float(q.g_0), float(q.epsi), str(q.planet_type),
-            int(q.iso), int(q.singlewalk), str(q.flux_calc_method))
+            int(q.iso), int(q.singlewalk), str(q.flux_calc_method), chem)
 
 
 def _radiation_loop(computer, quants, rt):
@@ -97,7 +101,6 @@ def _radiation_loop(computer, quants, rt):
     ncol = len(quants)
     done = np.zeros(ncol, bool)
     iters = np.zeros(ncol, np.int64)
-    fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in q0.species_list)
     if q0.singlewalk == 1:
         # post-processing run type (computation.py:983-984, Compute.radiation_loop): ONE pass over the given T-P profiles --
         # refresh, 1000*scat+1 sweeps inside one launch of the flux kernel, quadrature -- and no temperature step
@@ -111,7 +114,9 @@ def _radiation_loop(computer, quants, rt):
         return iters
     it = 0
     while not done.all():
-        if q0.opacity_mixing == "on-the-fly" and it % 10 == 0 and (it == 0 or fastchem):
+        # once per loop, as Compute.radiation_loop does: constant and file-given profiles never change, a FastChem species'
+        # profile is re-interpolated on the device at every refresh from ITS COLUMN's (T, P) table (make_rt_batch)
+        if q0.opacity_mixing == "on-the-fly" and it == 0:
             for c in np.nonzero(~done)[0]:
                 computer._push_vmr(quants[c])
         nxt = min(it + (10 - it % 10), int(q0.max_nr_iterations) + 1)
@@ -183,7 +188,6 @@ def _convection_loop(computer, quants, rt):
             rt.set_convergence_limit(c, q.rad_convergence_limit)
     if not active.any():
         return iters
-    fastchem = any(getattr(sp, "source_for_vmr", "") == "FastChem" for sp in q0.species_list)
     running = active.copy()
     it = 0
     while running.any():
@@ -191,16 +195,9 @@ def _convection_loop(computer, quants, rt):
         for r in q0.crit_relaxation_numbers:
             if it < r < nxt:
                 nxt = int(r)
-        if q0.opacity_mixing == "on-the-fly" and it % 10 == 0 and fastchem:
-            for c in np.nonzero(running)[0]:
-                computer._push_vmr(quants[c])
-            rt.conv_adjust(it)
-            for c in np.nonzero(running)[0]:
-                computer._push_vmr(quants[c])
-            rt.conv_advance(it)
-            rt.conv_run(it + 1, nxt - it - 1)
-        else:
-            rt.conv_run(it, nxt - it)
+        # (tabulated chemistry follows the temperatures on the device, ahead of the adjustment and for the adjusted profile:
+        # k_rt_mmm_from_vmr and the refresh, computation.py:1030-1036, :1056-1061 -- no host step per decade)
+        rt.conv_run(it, nxt - it)
         computer.report_diagnostics(quants[0])
         it = nxt
         for c in np.nonzero(running)[0]:

@@ -374,6 +374,11 @@ int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const doub
  * (Species.vmr_pretab); the species' profile is then interpolated at every refresh from the device's temperatures,
  * bilinear in (T, log10 P), clamped at the table edges.  NULL returns the species to hx_rt_set_column_vmr's profiles. */
 int hx_rt_set_species_vmr_table(hx_rt* rt, int s, const double* vmr_pretab);
+/* the same per column: a parameter sweep gives every column its own chemistry (FastChem directory, metallicity, C/O --
+ * source/read.py:577-606 reads one table per species and run), so the device keeps one table per (species, column);
+ * col < 0 = all columns (what hx_rt_set_species_vmr_table does).  A column of a tabulated species that never received a
+ * table reads zeros. */
+int hx_rt_set_column_vmr_table(hx_rt* rt, int col, int s, const double* vmr_pretab);
 /* per-column host inputs; col < 0 broadcasts to all columns.  vmr_* : [nspecies][nlayer] / [nspecies][ninterface] */
 int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const double* p_int,
                              const double* T_lay, const double* surf_albedo,

@@ -158,3 +158,53 @@ def test_a_sweep_of_columns_with_tabulated_chemistry_needs_no_host_step(ctx, loo
     # the columns really differ, and the profiles really moved with the temperatures
     assert np.abs(got[0]["T_lay"] - got[7]["T_lay"]).max() > 10.0
     assert np.abs(got[0]["vmr_lay"] - got[7]["vmr_lay"]).max() > 1e-6
+
+
+def test_columns_of_one_batch_keep_their_own_chemistry_tables(ctx):
+    """a sweep over FastChem directories (metallicity, C/O): every column of a batch comes with its OWN (T, P) mixing-ratio
+    tables (hx_rt_set_column_vmr_table).  Three columns with the same start profile and different tables in one batch give,
+    column by column, what each gives alone with its table -- and not what column 0's table gives."""
+    from helios_amd.rt import batch_from_case
+    ncol, n_iter = 3, 21
+    c = cases.add_species(cases.make_case(nbin=12, nlayer=14), nspecies=3)
+    S = len(c.species)
+    rng = np.random.default_rng(11)
+    lt = (c.ktemp[None, :, None] - c.ktemp[0]) / (c.ktemp[-1] - c.ktemp[0])
+    lp = np.log10(c.kpress)[None, None, :] / 9.0
+    base = np.array([np.log10(sp["vmr"]) for sp in c.species])[:, None, None]
+    tabs = [10.0 ** (base + 0.7 * col + rng.uniform(-2, 2, (S, 1, 1)) * lt + rng.uniform(-1, 1, (S, 1, 1)) * lp)
+            for col in range(ncol)]           # "metallicity" rises with the column
+    for t in tabs:
+        t[0] = 0.8
+
+    def make(n):
+        rt = batch_from_case(ctx, c, ncol=n, nspecies=S)
+        for k, sp in enumerate(c.species):
+            rt.set_species(k, sp["pretab"], sp["scat"], sp["weight"], is_h2o=2 if sp["is_h2o"] else 0,
+                           is_cia=1 if sp["is_cia"] else 0, in_mu=0 if sp["is_cia"] else 1)
+        rt.set_column_vmr(-1, np.zeros((S, c.nlayer)), np.zeros((S, c.nlayer + 1)))
+        rt.build_planck_table(1)
+        return rt
+
+    keys = ("T_lay", "F_net", "F_up_band", "meanmolmass_lay", "vmr_lay", "vmr_int")
+    a = make(ncol)
+    try:
+        for col in range(ncol):
+            for k in range(S):
+                a.set_column_vmr_table(col, k, tabs[col][k].reshape(-1))
+        a.run(0, n_iter)
+        got = [{k: a.get(k, col) for k in keys} for col in range(ncol)]
+    finally:
+        a.close()
+    for col in range(ncol):
+        b = make(1)
+        try:
+            for k in range(S):
+                b.set_species_vmr_table(k, tabs[col][k].reshape(-1))
+            b.run(0, n_iter)
+            for k in keys:
+                np.testing.assert_array_equal(got[col][k], b.get(k, 0), err_msg="%s column %d" % (k, col))
+        finally:
+            b.close()
+    assert np.abs(got[0]["vmr_lay"] / np.maximum(got[2]["vmr_lay"], 1e-300) - 1.0).max() > 0.5
+    assert np.abs(got[0]["T_lay"] - got[2]["T_lay"]).max() > 1e-3

@@ -1,14 +1,12 @@
 #!/bin/bash
-# ro_bench through several builds, alternating:  scratch/ab_ro.sh "libs" "kinds"
+# ro_bench through several builds of the library, alternating on one box:  bash tools/ab_ro.sh "libs" "kinds"
+# (variants are ab/<name>.so, selected through HELIOS_HIP_LIB: the in-tree library is never touched)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 LIBS=${1:-"head new"}; KINDS=${2:-"generic ktable"}
-cp $R/helios_amd/libhelios_hip.so /tmp/_orig.so
 for i in 1 2; do
   for lib in $LIBS; do
-    cp $R/ab/$lib.so $R/helios_amd/libhelios_hip.so
     for kind in $KINDS; do
-      echo -n "$lib: "; python3 $R/tools/ro_bench.py --kind $kind 2>&1 | tail -1 | cut -c1-120
+      echo -n "$lib: "; HELIOS_HIP_LIB=$R/ab/$lib.so python3 $R/tools/ro_bench.py --kind $kind 2>&1 | tail -1 | cut -c1-120
     done
   done
 done
-cp /tmp/_orig.so $R/helios_amd/libhelios_hip.so

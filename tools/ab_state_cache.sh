@@ -1,4 +1,6 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04z
+#!/bin/bash
+# sweep of the up-flux state share kept in the Infinity Cache (DESIGN_HISTORY.md, round 4)
+cd ${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p gpurun_out/r04z
 run() { # S MB workload steps extra
 HELIOS_RT_SERPENTINE=$1 HELIOS_RT_STATE_CACHE_MB=$2 python3 bench.py --workload $3 --steps $4 --warmup 20 --no-cpu-baseline --secondary none --live-counters off $5 2>/dev/null | python3 -c "
 import json,sys
