@@ -16,10 +16,11 @@ scaling, no collective on the iteration path, the emission spectra gathered over
 the N = 1 member of a 1/2/4/8 series IS the single-GPU headline.  `python bench.py --gpus N` without a launcher starts
 the N ranks itself (a child `python -m torch.distributed.run ...`, before this process touches a GPU).
 
-The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly), config 4 at reduced
-width (8 of the sweep's 512 on-the-fly columns in one batch) and config 5 (30 000 x 200, 20 species on the fly, two cloud
-decks, beam, albedo, I2S) from the radiation loop and from the convection loop; at N > 1 config 4 -- each GPU's share of the 512-column sweep, 64 on-the-fly columns per GPU in
-one batch.  `steady_state_200` is the headline workload over 200
+The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly), config 4 (one GPU's
+share of the 512-column sweep: 64 on-the-fly columns in one batch -- the same shape at every N) and config 5 (30 000 x 200,
+20 species on the fly, two cloud decks, beam, albedo, I2S) from the radiation loop and from the convection loop; at N > 1
+config 4 alone.  Synthetic k-tables are formed on the device from their two factors (hx_rt_set_*_separable): a rank's
+set-up (`setup_s`) no longer depends on the host's core count.  `steady_state_200` is the headline workload over 200
 iterations from iteration 0 (20 refreshes), SURVEY.md 8(d)'s definition of the metric.
 """
 import argparse
@@ -91,13 +92,21 @@ WORKLOADS = {
                    desc="BASELINE config 5, one column, steps taken from the CONVECTION loop (convective adjustment of a deep "
                         "zone, sweeps, layer marking, equilibrium test and temperature step on the device): 30 000 bins x 200 "
                         "layers, 20 species mixed on the fly, I2S correction, two cloud decks, direct beam, surface albedo"),
+    "d64": dict(nbin=386, nlayer=105, ny=20, ntemp=120, npress=28, columns_per_gpu=64, sweep=True,
+                desc="the reference's DEFAULT grid (R = 50: 386 bins x 20 Gauss points, 105 layers, 120 x 28 (T, P) nodes; "
+                     "BASELINE.md section 1) as a batch of 64 sweep columns on one GPU, premixed table, isotropic scattering"),
+    "d64s": dict(nbin=386, nlayer=105, ny=20, ntemp=120, npress=28, columns_per_gpu=64, sweep=True, species_dat=True,
+                 desc="the reference's default grid (386 bins x 20 Gauss points, 105 layers, 120 x 28 (T, P) nodes) as a batch of 64 "
+                      "sweep columns, on-the-fly mixing of the 15 species of the reference's input/species.dat: 13 absorbers -- the "
+                      "first and the two CIA pairs correlated-k, ten by random overlap --, Rayleigh scattering by H2O (computed), "
+                      "CO2, CO, H2, He"),
     "c4x8": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=8, sweep=True,
                  desc="BASELINE config 4 at reduced width: 8 columns of the 512-column sweep (g x a x T_intern grid) in one "
                       "batch on one GPU, on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
 }
 
 
-def build_case(w, seed):
+def build_case(w, seed, full_tables=True):
     """synthetic column + premixed table; attribute names follow the reference's Store"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helios_amd import phys_const as pc
@@ -124,8 +133,16 @@ def build_case(w, seed):
     c.opac_interwave, c.opac_wave, c.opac_deltawave = syn.wavelength_grid(c.nbin)
     c.gauss_y, c.gauss_weight = syn.gauss_points(c.ny)
     c.ktemp, c.kpress = syn.tp_grid(c.ntemp, c.npress)
-    # (with species the premixed table is never read: draw the same random numbers, skip the 0.6-1 GB array)
-    c.opac_k = syn.ktable(rng, 8 if w.get("nspecies") else c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+    # the premixed table by its two factors kxy[x][y], ftp[t][p]: the device forms the 0.6-1 GB array itself
+    # (hx_rt_set_premixed_separable; the same bits as synthetic.ktable) where the caller does not need the host array
+    # (`full_tables`: tests and the CPU oracle do).
+    # (with species the premixed table is never read: draw the same random numbers, skip the array)
+    otf = bool(w.get("nspecies") or w.get("species_dat"))
+    if otf or full_tables:
+        c.opac_k = syn.ktable(rng, 8 if otf else c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+        c.opac_k_factors = None
+    else:
+        c.opac_k, c.opac_k_factors = None, syn.ktable_factors(rng, c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
     c.opac_scat_cross = syn.rayleigh_table(c.opac_wave, c.ntemp, c.npress)
     c.opac_meanmass = syn.meanmass_table(c.ntemp, c.npress)
     c.p_lay, c.p_int = syn.pressure_levels(1e9, 1e-1, c.nlayer)
@@ -146,7 +163,7 @@ def build_case(w, seed):
         c.clouds = 1            # two synthetic decks (bases at 0.1 bar and 1 mbar), SURVEY.md 8(d) config 5
         c.update(syn.cloud_arrays(c.nbin, c.nlayer, c.opac_wave, np.asarray(c.p_lay), np.asarray(c.p_int), rng))
     c.species = None
-    if w.get("nspecies"):
+    if w.get("nspecies") and not w.get("species_dat"):
         # absorbers with molar weights U(2,64) and constant VMRs log-uniform in
         # [1e-8,1e-2], plus H2/He filler (0.85/0.15) as Rayleigh scatterers; mixing method RO
         sp = []
@@ -158,6 +175,24 @@ def build_case(w, seed):
                        is_h2o=False, is_cia=False))
         sp.append(dict(weight=4.0026, vmr=0.15, pretab=None, scat=1e-28 * (1e-4 / c.opac_wave) ** 4,
                        is_h2o=False, is_cia=False))
+        c.species = sp
+    if w.get("species_dat"):
+        # the species list of the reference's input/species.dat (15 entries, in file order): eleven molecules and atoms
+        # that absorb (H2O, CO2, CO scatter as well; H2O's Rayleigh cross-section is computed, kernels.cu:3404-3440), H2 and
+        # He as scatterers only, two CIA pairs (absorbing, correlated-k by name, not part of the mean molecular mass)
+        names = ["H2O", "CO2", "CO", "CH4", "NH3", "HCN", "PH3", "C2H2", "H2S", "Na", "K", "H2", "He", "CIA_H2H2", "CIA_H2He"]
+        weights = [18.015, 44.01, 28.01, 16.04, 17.03, 27.03, 34.0, 26.04, 34.08, 22.99, 39.10, 2.016, 4.0026, 4.032, 6.019]
+        sp = []
+        for k, (nm, wt) in enumerate(zip(names, weights)):
+            absorbing, cia = nm not in ("H2", "He"), nm.startswith("CIA")
+            scat = None
+            if nm in ("CO2", "CO", "H2", "He"):
+                scat = (1e-27 if nm != "He" else 1e-28) * (1e-4 / c.opac_wave) ** 4
+            vmr = {"H2": 0.85, "He": 0.15, "CIA_H2H2": 0.72, "CIA_H2He": 0.13}.get(nm)
+            if vmr is None:
+                vmr = float(10.0 ** rng.uniform(-8.0, -3.0))
+            sp.append(dict(name=nm, weight=wt, vmr=vmr, pretab="lazy" if absorbing else None, table_seed=seed * 100 + k,
+                           scat=scat, is_h2o=nm == "H2O", is_cia=cia))
         c.species = sp
     return c
 
@@ -174,18 +209,6 @@ def sweep_column(c, gi):
     return dict(g=g, a=a, F_intern=pc.SIGMA_SB * T_intern ** 4, T_start=max(T_eff, 500.0))
 
 
-_TABLES = {}
-
-
-def _room_for(nbytes):
-    """keep generated tables only where the host has four times their size to spare"""
-    try:
-        import psutil
-        return psutil.virtual_memory().available > 4 * nbytes
-    except Exception:
-        return False
-
-
 def make_batch(ctx, c, ncol, first_column=0, sweep=False):
     from helios_amd.rt import batch_from_case
     sp = c.species
@@ -193,21 +216,16 @@ def make_batch(ctx, c, ncol, first_column=0, sweep=False):
     rt = batch_from_case(ctx, c, ncol=ncol, nspecies=len(sp) if sp else 0, columns=cols)
     if sp:
         from helios_amd import synthetic as syn
-        shape = (c.nbin, c.ny, c.ntemp, c.npress)
-        if _TABLES.get("shape") != shape:       # the synthetic k-tables of the previous workload, kept while the shape stays
-            on = _TABLES.get("enabled")         # (config 3 and config 4 share theirs, config 5's two loops theirs; single-rank
-            _TABLES.clear()                     # runs only: eight ranks would each hold 19 GB of host memory)
-            _TABLES["shape"], _TABLES["enabled"] = shape, on
         for k, s_ in enumerate(sp):
-            tab = s_["pretab"]
-            if isinstance(tab, str):
-                tab = _TABLES.get(s_["table_seed"])
-                if tab is None:
-                    tab = syn.ktable(np.random.default_rng(s_["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
-                    if _TABLES.get("enabled") and _room_for(tab.nbytes * len(sp)):
-                        _TABLES[s_["table_seed"]] = tab
-            rt.set_species(k, tab, s_["scat"], s_["weight"], is_h2o=0, is_cia=0, in_mu=1)
-            del tab
+            if isinstance(s_["pretab"], str):
+                # a synthetic k-table (0.96 GB each at C3 size) by its two factors (1.6 MB): the device forms it
+                # (hx_rt_set_species_separable) -- 20 of them cost a rank 85 core-seconds of numpy before
+                kxy, ftp = syn.ktable_factors(np.random.default_rng(s_["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+                rt.set_species_separable(k, kxy, ftp, s_["scat"], s_["weight"], is_h2o=2 if s_["is_h2o"] else 0,
+                                         is_cia=1 if s_["is_cia"] else 0, in_mu=0 if s_["is_cia"] else 1)
+            else:
+                rt.set_species(k, s_["pretab"], s_["scat"], s_["weight"], is_h2o=2 if s_["is_h2o"] else 0,
+                               is_cia=1 if s_["is_cia"] else 0, in_mu=0 if s_["is_cia"] else 1)
         vl = np.array([np.full(c.nlayer, s_["vmr"]) for s_ in sp])
         vi = np.array([np.full(c.nlayer + 1, s_["vmr"]) for s_ in sp])
         rt.set_column_vmr(-1, vl, vi)
@@ -511,8 +529,9 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
     rank, world = ranks.rank, ranks.world
     sweep = bool(w.get("sweep"))
     err = None
+    t_setup = time.perf_counter()
     try:   # everything that allocates: a batch that does not fit one rank's GPU must not leave the others in a collective
-        c = build_case(w, seed)
+        c = build_case(w, seed, full_tables=False)
         rt = make_batch(ctx, c, ncol, first_column=rank * ncol, sweep=sweep)
         # every column of a run differs: the sweep's own parameters, or a few per cent in the start profile
         T_start = [c.T_lay * (1.0 + 0.01 * (rank * ncol + i)) for i in range(ncol)]
@@ -523,6 +542,7 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
         ctx.synchronize()
     except Exception as e:
         err = e
+    setup_s = time.perf_counter() - t_setup      # synthetic inputs, tables formed on the device, uploads, the Planck table
     failed = [r for r, v in enumerate(ranks.gather_scalars(0.0 if err is None else 1.0)) if v]
     if failed:   # the same decision on every rank, before the first barrier of the measurement
         raise RuntimeError("workload %s: rank(s) %s could not set up the batch%s"
@@ -606,6 +626,7 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
                    # MiB of up-flux state the tail of a launch leaves in the Infinity Cache
                    "flux_launch_policy": {"back_and_forth": bool(flux_policy[0]), "state_cached_mib": float(flux_policy[1])}},
         "iterations_per_s_per_column": steps / dt,
+        "setup_s": setup_s, "setup_s_per_rank": ranks.gather_scalars(setup_s),
         "stream_event_ms_per_step": ev_ms / steps,
         "per_rank_ms_per_step": rank_ms,
         "rank_imbalance": (max(rank_ms) - min(rank_ms)) / max(rank_ms),
@@ -647,7 +668,7 @@ def main():
                     help="headline workload (default c2, the configuration the metric is quoted on, at every N)")
     ap.add_argument("--columns-per-gpu", type=int, default=None)
     ap.add_argument("--secondary", default="default",
-                    help="'default' (N = 1: c3,c4x8,c5,c5conv; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
+                    help="'default' (N = 1: c3,c4,c5,c5conv,d64,d64s; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
                          "the same run into the line's `secondary` block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
@@ -679,7 +700,9 @@ def main():
     warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
     ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
     if args.secondary == "default":
-        secondary = (["c3", "c4x8", "c5", "c5conv"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
+        # (config 4 with the SAME shape at every N: one GPU's share of the 512-column sweep, 64 columns in one batch)
+        # (and the regime HELIOS users run: the reference's default grid as a 64-column batch, premixed and with species.dat's list)
+        secondary = (["c3", "c4", "c5", "c5conv", "d64", "d64s"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
     else:
         secondary = [x for x in args.secondary.split(",") if x and x != "none"]
     for x in secondary:
@@ -709,7 +732,6 @@ def main():
         else:
             dist.init_process_group(backend)
     ranks = Ranks(dist, world, rank, coll_device)
-    _TABLES["enabled"] = world == 1 and len(secondary) > 1
 
     from helios_amd.device import Context
     seed = 20240 + 2

@@ -570,6 +570,66 @@ int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const doub
     return 0;
 }
 
+// Synthetic tables (bench.py, tests): kappa[t][p][x][y] = kxy[y + ny x] * ftp[p + npress t], formed on the device -- the
+// shape helios_amd/synthetic.py:ktable gives its tables (one fp64 product per entry, the same bits as its numpy form) without a
+// 0.96 GB host array per table and its PCIe copy: a rank's set-up of 20 species at config 3's size took 85 core-seconds of
+// single-threaded numpy.  The readers of real k-tables do not come here.
+__global__ void __launch_bounds__(256) k_rt_table_outer(double* __restrict__ out, const double* __restrict__ kxy,
+                                                       const double* __restrict__ ftp, size_t nxy) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nxy) __builtin_nontemporal_store(kxy[i] * ftp[blockIdx.y], out + (size_t)blockIdx.y * nxy + i);
+}
+
+static int fill_outer(hx_rt* rt, double* table, const double* kxy, const double* ftp) {
+    const size_t nxy = (size_t)rt->X * rt->Y, ntp = (size_t)rt->d.ntemp * rt->d.npress;
+    double* stage = nullptr;   // the two factors, freed right after the launch (stream order)
+    HX_HIP(rt->ctx, hipMalloc((void**)&stage, (nxy + ntp) * 8));
+    int rc = h2d(rt, stage, kxy, nxy * 8);
+    if (!rc) rc = h2d(rt, stage + nxy, ftp, ntp * 8);
+    if (!rc) {
+        k_rt_table_outer<<<dim3((unsigned)((nxy + 255) / 256), (unsigned)ntp), 256, 0, rt->ctx->stream>>>(table, stage, stage + nxy, nxy);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = hx_fail(rt->ctx, -(int)e, "k_rt_table_outer: %s", hipGetErrorString(e));
+    }
+    (void)hipStreamSynchronize(rt->ctx->stream);
+    (void)hipFree(stage);
+    return rc;
+}
+
+int hx_rt_set_species_separable(hx_rt* rt, int s, const double* kxy, const double* ftp, const double* scat_cross,
+                                double weight, int is_h2o, int is_cia, int in_mu) {
+    if (!rt) return HX_E_ARG;
+    HX_REQUIRE(rt->ctx, kxy && ftp, HX_E_ARG, "both factors of the table are needed");
+    int rc = hx_rt_set_species(rt, s, nullptr, scat_cross, weight, is_h2o, is_cia, in_mu);
+    if (rc) return rc;
+    Species& sp = rt->species[s];
+    if (!sp.pretab) RT_ALLOC(sp.pretab, (size_t)rt->d.ntemp * rt->d.npress * rt->X * rt->Y);
+    rc = fill_outer(rt, sp.pretab, kxy, ftp);
+    if (rc) return rc;
+    sp.absorbing = true;
+    rt->species_dev_stale = true;
+    return 0;
+}
+
+int hx_rt_set_premixed_separable(hx_rt* rt, const double* kxy, const double* ftp, const double* opac_scat_cross,
+                                 const double* opac_meanmass) {
+    if (!rt) return HX_E_ARG;
+    rt->graph_stale = true;
+    HX_REQUIRE(rt->ctx, rt->d.nspecies == 0, HX_E_STATE, "object was created for on-the-fly mixing");
+    HX_REQUIRE(rt->ctx, kxy && ftp && opac_scat_cross && opac_meanmass, HX_E_ARG, "null table");
+    const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
+    if (!rt->opac_k) {
+        RT_ALLOC(rt->opac_k, ntp * rt->X * rt->Y);
+        RT_ALLOC(rt->opac_scat_cross, ntp * rt->X);
+        RT_ALLOC(rt->opac_meanmass, ntp);
+    }
+    int rc = fill_outer(rt, rt->opac_k, kxy, ftp);
+    if (!rc) rc = h2d(rt, rt->opac_scat_cross, opac_scat_cross, ntp * rt->X * 8);
+    if (!rc) rc = h2d(rt, rt->opac_meanmass, opac_meanmass, ntp * 8);
+    rt->have_tables = rc == 0;
+    return rc;
+}
+
 static int for_cols(hx_rt* rt, int col, int* c0, int* c1);
 
 // calculate_vmr_for_all_species on the device (host_functions.py:874-910): a species whose mixing ratio is tabulated on the
@@ -811,7 +871,10 @@ static int refresh_species(hx_rt* rt) {
         // millisecond, so the last round of workgroups does not leave the chip half empty
         static const int waves = [] { const char* e = getenv("HELIOS_RT_MIX_WAVES"); return e ? atoi(e) : 256 * 16 * 48; }();
         const int grid = (int)std::min(npair, (long long)waves);
-        k_rt_mix_species<<<grid, 64, 0, ctx->stream>>>(m);
+        // occupancy experiment (profiles/r05_mix_occupancy.txt): bytes of unused dynamic LDS per wavefront on top of the
+        // kernel's 9.95 KB -- 16 wavefronts share a CU's 160 KB as built, +3.4 KB leaves 12, +10 KB 8.  Results unchanged.
+        static const int extra_lds = [] { const char* e = getenv("HELIOS_RT_MIX_EXTRA_LDS"); return e ? atoi(e) : 0; }();
+        k_rt_mix_species<<<grid, 64, extra_lds, ctx->stream>>>(m);
         HX_LAUNCH_CHECK(ctx);
     }
     {

@@ -536,9 +536,25 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
     double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64;
     const double nmu = -cp.mu_star;
     const bool plain = a.clouds != 1 && a.scat_corr != 1 && a.g_0 == 0.0 && a.dir_beam != 1;
+    // The beam at the nodes of this lane's half-layers.  Half-layer h spans the nodes h (bottom) and h + 1 (top) -- even
+    // nodes are interfaces (F_dir_wg), odd ones layer centres (Fc_dir_wg); isothermal: node = interface -- so the top value
+    // of one row is the bottom value of the next: ONE load per row instead of two, requested a whole row of arithmetic
+    // (divisions, exp, sqrt) before it is used.  (Loaded where they were used, the compiler sent all of a tile's beam
+    // loads through one register pair, each waited for in turn: DESIGN.md section 4, tools/code_object_notes.py.)
+    const double* Fd = a.F_dir_wg + col * wgI;
+    const double* Fc = a.Fc_dir_wg + col * wgI;
+    auto beam_at_node = [&](int n) -> double {
+        if (!(a.dir_beam == 1 && valid && n <= a.H)) return 0.0;
+        if (a.iso) return Fd[(size_t)c + nc * n];
+        return (n & 1) ? Fc[(size_t)c + nc * (n >> 1)] : Fd[(size_t)c + nc * (n >> 1)];
+    };
+    double F_here = beam_at_node(j * ROWS), F_above = beam_at_node(j * ROWS + 1);
     for (int r = 0; r < ROWS; r++) {
         const int h = j * ROWS + r;
         double alpha = 1.0, beta = 0.0, up = 0.0, vp = 0.0, dd = 0.0, du = 0.0;
+        const double Fbot = F_here, Ftop = F_above;
+        F_here = F_above;
+        F_above = beam_at_node(h + 2);      // the next row's top node: in flight during this row's arithmetic
         if (valid && h < a.H) {
             const int i = a.iso ? h : h >> 1;
             const bool lower = a.iso || (h & 1) == 0;
@@ -586,12 +602,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             up = K * u * invM;
             vp = K * v * invM;
             if (a.dir_beam == 1) {
-                // beam at node h (bottom) and h+1 (top) of this half-layer
-                const double* Fd = a.F_dir_wg + col * wgI;
-                const double* Fc = a.Fc_dir_wg + col * wgI;
-                const double Fbot = lower ? Fd[(size_t)c + nc * i] : Fc[(size_t)c + nc * i];
-                const double Ftop = a.iso ? Fd[(size_t)c + nc * (i + 1)]
-                                          : (lower ? Fc[(size_t)c + nc * i] : Fd[(size_t)c + nc * (i + 1)]);
+                // beam at node h (bottom) and h+1 (top) of this half-layer: Fbot, Ftop from above
                 const double dn = Fbot / nmu * (s.Gm * s.M + s.Gp * s.N) - Ftop / nmu * s.Gm * s.P;
                 const double upw = Ftop / nmu * (s.Gm * s.N + s.Gp * s.M) - Fbot / nmu * s.P * s.Gp;
                 dd = dmin(0.0, dn) * invM;

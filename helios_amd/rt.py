@@ -104,6 +104,16 @@ class RTBatch(object):
         self._ck(self._l.hx_rt_set_species(self.handle, s, _dp(p), _dp(q), float(weight), int(is_h2o),
                                            int(is_cia), int(in_mu)), "hx_rt_set_species")
 
+    def set_species_separable(self, s, kxy, ftp, scat_cross, weight, is_h2o=0, is_cia=0, in_mu=1):
+        """a synthetic species table kappa[t][p][x][y] = kxy[x][y] * ftp[t][p] (synthetic.ktable_factors), formed on the device"""
+        a, b, q = _f64(kxy), _f64(ftp), _f64(scat_cross)
+        self._ck(self._l.hx_rt_set_species_separable(self.handle, s, _dp(a), _dp(b), _dp(q), float(weight), int(is_h2o),
+                                                     int(is_cia), int(in_mu)), "hx_rt_set_species_separable")
+
+    def set_premixed_separable(self, kxy, ftp, opac_scat_cross, opac_meanmass):
+        arrs = [_f64(a) for a in (kxy, ftp, opac_scat_cross, opac_meanmass)]
+        self._ck(self._l.hx_rt_set_premixed_separable(self.handle, *[_dp(a) for a in arrs]), "hx_rt_set_premixed_separable")
+
     def set_species_vmr_table(self, s, vmr_pretab):
         """the species' mixing ratio on the opacity tables' (T, P) grid, [p + npress * t]: its profile follows the
         temperatures on the device at every refresh (None: back to the profiles of set_column_vmr)"""
@@ -277,7 +287,10 @@ def batch_from_case(ctx, c, ncol=1, nspecies=0, columns=None):
     try:
         rt.set_grid(c.opac_interwave, c.opac_deltawave, c.opac_wave, c.gauss_y, c.gauss_weight, c.ktemp, c.kpress)
         if nspecies == 0:
-            rt.set_premixed_tables(c.opac_k, c.opac_scat_cross, c.opac_meanmass)
+            if c.get("opac_k_factors") is not None:     # a synthetic table given by its two factors: formed on the device
+                rt.set_premixed_separable(c.opac_k_factors[0], c.opac_k_factors[1], c.opac_scat_cross, c.opac_meanmass)
+            else:
+                rt.set_premixed_tables(c.opac_k, c.opac_scat_cross, c.opac_meanmass)
         rt.set_column_profile(-1, c.p_lay, c.p_int, c.T_lay, c.surf_albedo, c.starflux)
         if c.clouds:
             rt.set_column_clouds(-1, c.abs_cross_all_clouds_lay, c.abs_cross_all_clouds_int,

@@ -45,19 +45,27 @@ def _smooth5(a):
     return np.convolve(pad, k, mode="valid")
 
 
-def ktable(rng, nbin, ny, ktemp, kpress, gauss_y):
-    """monotone-in-y synthetic k-distribution table, flat in reference order."""
+def ktable_factors(rng, nbin, ny, ktemp, kpress, gauss_y):
+    """the two factors of the synthetic k-distribution table: kxy[x][y] (flat, y fastest) and ftp[t][p] (flat, p fastest) with
+    kappa[t][p][x][y] = kxy[x][y] * ftp[t][p] -- what the device needs to form the table itself
+    (RTBatch.set_species_separable); same random draws as ktable()"""
     a = _smooth5(rng.uniform(-6.0, -1.0, nbin))
     b = rng.uniform(1.0, 4.0, nbin)
     # log10 kappa[y,x,p,t] = a(x) + 3.5 * y^b(x) + 0.3 (log10 p - 6) - 0.2 T/1000
     yx = a[None, :] + 3.5 * gauss_y[:, None] ** b[None, :]                      # [y, x]
     lp = 0.3 * (np.log10(kpress) - 6.0)                                         # [p]
     lt = -0.2 * (ktemp / 1000.0)                                                # [t]
-    out = np.empty((len(ktemp), len(kpress), nbin, ny), dtype=np.float64)       # [t][p][x][y]
-    base = 10.0 ** yx.T                                                         # [x, y]
-    for t in range(len(ktemp)):
-        for p in range(len(kpress)):
-            out[t, p] = base * 10.0 ** (lp[p] + lt[t])
+    base = np.ascontiguousarray(10.0 ** yx.T)                                   # [x, y]
+    ftp = np.array([[10.0 ** (lp[p] + lt[t]) for p in range(len(kpress))] for t in range(len(ktemp))])
+    return base.reshape(-1), ftp.reshape(-1)
+
+
+def ktable(rng, nbin, ny, ktemp, kpress, gauss_y):
+    """monotone-in-y synthetic k-distribution table, flat in reference order."""
+    base, ftp = ktable_factors(rng, nbin, ny, ktemp, kpress, gauss_y)
+    out = np.empty((len(ktemp) * len(kpress), nbin * ny), dtype=np.float64)     # [t][p][x][y]
+    for tp in range(out.shape[0]):
+        out[tp] = base * ftp[tp]
     return out.reshape(-1)
 
 

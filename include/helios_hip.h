@@ -369,6 +369,14 @@ int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opa
  * (computation.py:1343); in_mu = contributes to the mean molecular mass (host_functions.py:940) */
 int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const double* scat_cross,
                       double weight, int is_h2o, int is_cia, int in_mu);
+/* Synthetic tables (bench.py, tests; helios_amd/synthetic.py:ktable): kappa[t][p][x][y] = kxy[y + ny*x] * ftp[p + npress*t],
+ * formed on the device -- one fp64 product per entry, the same bits as the host array -- instead of a 0.96 GB host table and
+ * its copy per species.  Otherwise as hx_rt_set_species / hx_rt_set_premixed_tables (the reference reads its tables from
+ * HDF5 files, source/read.py:1041-1103; these two have no counterpart there). */
+int hx_rt_set_species_separable(hx_rt* rt, int s, const double* kxy, const double* ftp, const double* scat_cross,
+                                double weight, int is_h2o, int is_cia, int in_mu);
+int hx_rt_set_premixed_separable(hx_rt* rt, const double* kxy, const double* ftp, const double* opac_scat_cross,
+                                 const double* opac_meanmass);
 /* A6 on the device: calculate_vmr_for_all_species + interpolate_grid_to_lay_or_int (source/host_functions.py:874-910).
  * vmr_pretab[p + npress * t] on the opacity tables' (T, P) grid, as source/read.py keeps it per FastChem species
  * (Species.vmr_pretab); the species' profile is then interpolated at every refresh from the device's temperatures,

@@ -148,6 +148,23 @@ def test_no_flux_kernel_serialises_its_tile_loads():
     assert sum(dest[[n for n in dest if "k_rt_flux<13, 16>" in n][0]].values()) >= 7 * rows
 
 
+def test_no_coef_kernel_serialises_its_beam_loads():
+    """the same pattern in the refresh's coefficient kernel (round 4, found in the listing of k_rt_coef<7, 8>: ten loads of
+    the beam values into one register pair, seven into another): the beam is now read once per NODE -- a row's top value
+    is the next row's bottom value -- one row of arithmetic ahead of its use.  Every instantiation: at most eight loads
+    into one destination (the unrolled tilings share address registers, not results), config 5's tiling at most six."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("code_object_notes", os.path.join(ROOT, "tools", "code_object_notes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dest = mod.load_destinations(name_filter="k_rt_coef<")
+    assert len(dest) >= 16 * 4
+    worst = {n: max(c.values()) for n, c in dest.items() if c}
+    assert len(worst) == len(dest)
+    assert max(worst.values()) <= 8, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[[n for n in worst if "k_rt_coef<7, 8>" in n][0]] <= 6
+
+
 def test_only_the_unselected_flux_tilings_use_scratch():
     """every other kernel of the library -- the species loop with random overlap, the coefficient kernel, all per-stage
     kernels -- runs without a private segment (k_rt_mix_species kept 7 VGPRs in scratch in round 2: 2.1 GB of stores per

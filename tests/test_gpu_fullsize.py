@@ -96,18 +96,26 @@ def _compare_block(got, s, c, x0, nb, keys_wg, keys_band, rtol=1e-9):
         np.testing.assert_allclose(a, w, rtol=rtol, atol=atol, err_msg="%s bins %d.." % (k, x0))
 
 
-def _upload_species(rt, c, xs, nb):
-    """upload every species table, keep the sampled bins of each for the oracle"""
+def _upload_species(rt, c, xs, nb, separable=False):
+    """upload every species table, keep the sampled bins of each for the oracle (`separable`: the device forms the synthetic
+    tables from their two factors, hx_rt_set_species_separable; the oracle still gets slices of the host array)"""
     from helios_amd import synthetic as syn
     slices = []
     for k, sp in enumerate(c.species):
         tab = sp["pretab"]
-        if isinstance(tab, str):
+        h2o, cia = bool(sp.get("is_h2o")), bool(sp.get("is_cia"))
+        flags = dict(is_h2o=2 if h2o else 0, is_cia=1 if cia else 0, in_mu=0 if cia else 1)
+        lazy = isinstance(tab, str)
+        if lazy:
             tab = syn.ktable(np.random.default_rng(sp["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
-        rt.set_species(k, tab, sp["scat"], sp["weight"], is_h2o=0, is_cia=0, in_mu=1)
+        if lazy and separable:
+            kxy, ftp = syn.ktable_factors(np.random.default_rng(sp["table_seed"]), c.nbin, c.ny, c.ktemp, c.kpress, c.gauss_y)
+            rt.set_species_separable(k, kxy, ftp, sp["scat"], sp["weight"], **flags)
+        else:
+            rt.set_species(k, tab, sp["scat"], sp["weight"], **flags)
         sl = {x0: (_slice_table(tab, c, x0, nb) if tab is not None else None) for x0 in xs}
-        slices.append((dict(name="S%02d" % k, absorbing=tab is not None, scattering=sp["scat"] is not None, is_h2o=False,
-                            is_cia=False, weight=sp["weight"], vmr=sp["vmr"], pretab=None, scat=sp["scat"]), sl))
+        slices.append((dict(name=sp.get("name", "S%02d" % k), absorbing=tab is not None, scattering=sp["scat"] is not None or h2o,
+                            is_h2o=h2o, is_cia=cia, weight=sp["weight"], vmr=sp["vmr"], pretab=None, scat=sp["scat"]), sl))
         del tab
     vl = np.array([np.full(c.nlayer, sp["vmr"]) for sp in c.species])
     vi = np.array([np.full(c.nlayer + 1, sp["vmr"]) for sp in c.species])
@@ -260,6 +268,85 @@ def test_config4_sixteen_full_size_columns_in_one_batch_vs_oracle(ctx, port):
                            ("scat_cross_lay", "scat_cross_int", "F_up_band", "F_down_band"))
     for i in range(1, len(cols)):                     # sixteen different columns, none a copy of its neighbour
         assert np.abs(spectra[i] / spectra[i - 1] - 1.0).max() > 1e-6
+
+
+def test_default_grid_batch_with_the_species_of_species_dat_vs_oracle(ctx, port):
+    """the regime HELIOS users run (bench.py's `d64s`): the reference's default grid -- 386 bins x 20 Gauss points, 105
+    layers, 120 x 28 (T, P) nodes -- with the 15 species of its input/species.dat (H2O first: correlated-k, ten absorbers by
+    random overlap, two CIA pairs correlated-k; Rayleigh scattering by H2O (computed), CO2, CO, H2, He) as a batch of sweep
+    columns; tables formed on the device from their factors.  First refresh and flux solve of three columns against the
+    CPU oracle on sampled bins."""
+    import bench
+    from helios_amd.rt import batch_from_case
+    c = bench.build_case(bench.WORKLOADS["d64s"], 20242)
+    assert [sp["name"] for sp in c.species][:3] == ["H2O", "CO2", "CO"] and len(c.species) == 15
+    picks = [0, 63, 137, 200, 321, 448, 470, 511]
+    xs, nb = _blocks(c.nbin)
+    cols = [bench.sweep_column(c, gi) for gi in picks]
+    rt = batch_from_case(ctx, c, ncol=len(cols), nspecies=len(c.species), columns=cols)
+    try:
+        slices = _upload_species(rt, c, xs, nb, separable=True)
+        for i, cp in enumerate(cols):
+            rt.set_column_profile(i, c.p_lay, c.p_int, np.full(c.nlayer + 1, cp["T_start"]) * (1.0 + 0.004 * i),
+                                  c.surf_albedo, c.starflux)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        grid = rt.get("planck_grid")
+        checked = [0, 4, 7]
+        got = {i: {k: rt.get(k, i) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "scat_cross_int",
+                                             "F_up_band", "F_down_band", "F_up_wg", "meanmolmass_lay")} for i in checked}
+        dg = ctx.diag()
+    finally:
+        rt.close()
+    for i in checked:
+        cp = cols[i]
+        ci = cases.Case(c)
+        ci.g, ci.a, ci.F_intern = cp["g"], cp["a"], cp["F_intern"]
+        ci.T_lay = np.full(c.nlayer + 1, cp["T_start"]) * (1.0 + 0.004 * i)
+        for x0 in xs[:1] + xs[2:]:
+            b = _block_case(ci, x0, nb, slices)
+            s = _oracle_block(port, b, grid, ci, x0, nb, cases.refresh_onthefly)
+            _compare_block(got[i], s, ci, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg"),
+                           ("scat_cross_lay", "scat_cross_int", "F_up_band", "F_down_band"))
+            np.testing.assert_allclose(got[i]["meanmolmass_lay"][:c.nlayer], s.meanmolmass_lay[:c.nlayer], rtol=1e-13)
+    assert dg["ro_rebin_skipped"] == 0
+
+
+def test_default_grid_batch_premixed_table_from_its_factors_vs_oracle(ctx, port):
+    """bench.py's `d64`: the default grid with a premixed table, 64 sweep columns in ONE batch; the table is formed on the
+    device from its two factors (hx_rt_set_premixed_separable).  First refresh and flux solve of two columns against the
+    oracle (which reads the host-built table) on sampled bins."""
+    import bench
+    from helios_amd.rt import batch_from_case
+    w = bench.WORKLOADS["d64"]
+    c = bench.build_case(w, 20242)                          # with the host table, for the oracle
+    cf = bench.build_case(w, 20242, full_tables=False)      # by its factors, for the device
+    assert cf.opac_k is None and cf.opac_k_factors is not None
+    ncol = w["columns_per_gpu"]
+    xs, nb = _blocks(c.nbin)
+    cols = [bench.sweep_column(c, gi) for gi in range(ncol)]
+    rt = batch_from_case(ctx, cf, ncol=ncol, columns=cols)
+    try:
+        for i, cp in enumerate(cols):
+            rt.set_column_profile(i, c.p_lay, c.p_int, np.full(c.nlayer + 1, cp["T_start"]), c.surf_albedo, c.starflux)
+        rt.build_planck_table(1)
+        rt.run(0, 1)
+        grid = rt.get("planck_grid")
+        checked = [5, 63]
+        got = {i: {k: rt.get(k, i) for k in ("opac_wg_lay", "opac_wg_int", "scat_cross_lay", "F_up_band", "F_down_band",
+                                             "F_up_wg")} for i in checked}
+    finally:
+        rt.close()
+    for i in checked:
+        cp = cols[i]
+        ci = cases.Case(c)
+        ci.g, ci.a, ci.F_intern = cp["g"], cp["a"], cp["F_intern"]
+        ci.T_lay = np.full(c.nlayer + 1, cp["T_start"])
+        for x0 in xs:
+            b = _block_case(ci, x0, nb)
+            s = _oracle_block(port, b, grid, ci, x0, nb, cases.refresh_premixed)
+            _compare_block(got[i], s, ci, x0, nb, ("opac_wg_lay", "opac_wg_int", "F_up_wg"),
+                           ("scat_cross_lay", "F_up_band", "F_down_band"))
 
 
 def test_config5_on_the_fly_full_size_sampled_bins_vs_oracle(ctx, port):
