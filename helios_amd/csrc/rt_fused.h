@@ -21,6 +21,7 @@ struct TileGeom {
     int nblk;         // workgroups per column = nblk_x * nparts
     int nplane;       // coefficient planes per tile: alpha, beta, u' [, v'] [, dd, du]
     int has_vp, pl_vp, pl_dd;
+    int pl_rho;       // matrix method: first of its two planes
     size_t tile_rows; // ROWS
     size_t coef_elems_per_col, flux_elems_per_col;  // doubles
 };
@@ -136,6 +137,10 @@ struct hx_rt {
     bool has_heating = false;
 
     bool matrix = false;           // hx_rt_flags.matrix
+    // the matrix method as two scans on the coefficient tiles (k_rt_matrix_prep, k_rt_flux<.., true>): the default.
+    // HELIOS_RT_MATRIX=stage: the reference-shaped per-stage kernels (calc_trans_*, one Thomas elimination per thread with its
+    // work arrays in HBM) inside the loop instead, as until round 4
+    bool matrix_scan = false;
     // The iteration index lives on the device (iter_dev[0]: index of the next iteration; k_rt_nodes, the first kernel of an
     // iteration, moves it to iter_dev[1] and increments): the kernels of an iteration then have the SAME arguments every
     // time, and the nine refresh-free iterations between two opacity refreshes are replayed as one hipGraph where the

@@ -64,7 +64,7 @@ void choose_workgroup(int Y, int X, int max_threads, TileGeom& g) {
 // k_rt_flux<ROWS, K> instantiations whose code objects report vgpr_spill_count > 0 (K = 0 stands for k = 8)
 bool flux_variant_spills(int rows, int k) { return rows >= 15 || (rows == 14 && k != 16); }
 
-bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g) {
+bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g, int matrix = 0) {
     // lanes per spectral point: the fewest padded nodes, with the kernels whose scans are written for a compile-time
     // lane count (k = 16, 32, 64) preferred -- measured at 10 000 bins: 50 layers 0.172 ms (k = 16, 12 % padding) against
     // 0.210 ms (k = 8, 4 %), 60 layers 0.194 against 0.256 ms
@@ -124,6 +124,8 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
     g.pl_vp = 3;
     g.pl_dd = 3 + g.has_vp;
     g.nplane = 3 + g.has_vp + (dir_beam ? 2 : 0);
+    g.pl_rho = g.nplane;             // matrix method: rho at the rows' top nodes, 1 / (1 - beta rho_bottom) (k_rt_matrix_prep)
+    if (matrix) g.nplane += 2;
     g.tile_rows = g.ROWS;
     g.coef_elems_per_col = (size_t)g.nblk * g.NW * g.nplane * g.ROWS * 64;
     g.flux_elems_per_col = (size_t)g.nblk * g.NW * g.ROWS * 64;
@@ -139,6 +141,7 @@ KArgs make_args(hx_rt* rt) {
     a.nparts = g.nparts; a.G = g.G; a.NW = g.NW; a.nblk_x = g.nblk_x; a.nblk = g.nblk;
     a.nplane = g.nplane; a.nchunk = rt->nchunk;
     a.has_vp = g.has_vp; a.pl_vp = g.pl_vp; a.pl_dd = g.pl_dd;
+    a.matrix = rt->matrix_scan ? 1 : 0; a.pl_rho = g.pl_rho; a.trigger = rt->mx.trigger;
     a.Kconst = 2.0 * HX_PI * rt->f.epsi;
     a.scat = rt->f.scat; a.dir_beam = rt->f.dir_beam; a.clouds = rt->f.clouds;
     a.scat_corr = rt->f.scat_corr; a.nsweep = rt->nsweep; a.keep_down = rt->keep_down ? 1 : 0;
@@ -233,6 +236,7 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.debug_skip = debug_skip;
 #endif
     f.Kconst = a.Kconst;
+    f.pl_rho = a.pl_rho; f.trigger = a.trigger;
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
     f.surf_albedo = a.surf_albedo; f.gauss_w = a.gauss_w;
@@ -252,6 +256,23 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
         f.cache_state_from = (int)std::max(0LL, total - keep);
     }
     const bool generic = rt->generic_scans;
+    if (rt->matrix_scan) {   // the direct solve: no state to leave in the cache for a next launch, no launch order to alternate
+        f.reverse = 0;
+        f.cache_state_from = INT_MAX;
+        if (g.k == 16 && !generic)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 16, true>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                               rt->ctx->stream, f);
+        else if (g.k == 32 && !generic)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 32, true>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                               rt->ctx->stream, f);
+        else if (g.k == 64 && !generic)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 64, true>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                               rt->ctx->stream, f);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 0, true>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                               rt->ctx->stream, f);
+        return;
+    }
     if (g.k == 16 && !generic)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 16>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                            rt->ctx->stream, f);
@@ -323,6 +344,16 @@ void raise_flux_shmem(hx_rt* rt, int shmem) {
         e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    if (rt->matrix_scan) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    }
     rt->shmem_rc = e;
 }
 
@@ -385,7 +416,10 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
 #ifdef HX_PROFILING
     if (const char* e = getenv("HELIOS_RT_DEBUG_NSWEEP")) rt->nsweep = atoi(e);  // profiling experiments only
 #endif
-    if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g))
+    rt->matrix = flags->matrix != 0;
+    rt->matrix_scan = rt->matrix;
+    if (const char* e = getenv("HELIOS_RT_MATRIX")) rt->matrix_scan = rt->matrix && std::string(e) != "stage";
+    if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g, rt->matrix_scan ? 1 : 0))
         return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512 (1024 isothermal layers); use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
@@ -445,15 +479,16 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
         RT_ALLOC(rt->sc_spec_lay, X * I); RT_ALLOC(rt->sc_spec_int, X * I);
     }
     RT_ALLOC(rt->delta_z, C * L); RT_ALLOC(rt->z_lay, C * L);
-    rt->matrix = flags->matrix != 0;
-    if (flags->dir_beam || rt->matrix) {   // (the matrix solver reads the beam arrays unconditionally: zeros without a beam)
+    const bool stage_matrix = rt->matrix && !rt->matrix_scan;
+    if (flags->dir_beam || stage_matrix) {   // (the per-stage matrix solver reads the beam arrays unconditionally: zeros without a beam)
         RT_ALLOC(rt->dtau_u, C * nc * L); RT_ALLOC(rt->dtau_l, C * nc * L);
         RT_ALLOC(rt->F_dir_wg, C * nc * I); RT_ALLOC(rt->Fc_dir_wg, C * nc * I);
     }
     RT_ALLOC(rt->F_dir_band_n, C * X * I);
     RT_ALLOC(rt->Bn, C * X * (rt->H + 3));
-    if (rt->matrix) {
-        // `flux calculation method = matrix`: the reference's per-half-layer arrays instead of the coefficient tiles
+    if (rt->matrix_scan) RT_ALLOC(rt->mx.trigger, C * nc);
+    if (stage_matrix) {
+        // `flux calculation method = matrix` through the per-stage kernels: the reference's per-half-layer arrays instead of the coefficient tiles
         // and the persistent up-flux state (a direct solve has none)
         MatrixArrays& m = rt->mx;
         const size_t wgL = C * nc * L, halves = flags->iso ? 1 : 2;
@@ -461,7 +496,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
         if (!flags->iso)
             for (double** q : {&m.trans_l, &m.M_l, &m.N_l, &m.P_l, &m.Gp_l, &m.Gm_l, &m.w0_l}) RT_ALLOC(*q, wgL);
         RT_ALLOC(m.dtc_u, C * X * L); RT_ALLOC(m.dtc_l, C * X * L); RT_ALLOC(m.dcol_iso, C * L);
-        RT_ALLOC(m.trigger, C * nc);
+        if (!m.trigger) RT_ALLOC(m.trigger, C * nc);
         RT_ALLOC(m.F_down, C * nc * I); RT_ALLOC(m.F_up, C * nc * I);
         RT_ALLOC(m.Fc_down, C * nc * I); RT_ALLOC(m.Fc_up, C * nc * I);
         RT_ALLOC(m.pb_lay, C * X * (L + 2)); RT_ALLOC(m.pb_int, C * X * I);
@@ -693,7 +728,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
         rc |= h2d(rt, rt->p_int + c * I, p_int, I * 8);
         rc |= h2d(rt, rt->dcol_u + c * L, du.data(), L * 8);
         rc |= h2d(rt, rt->dcol_l + c * L, dl.data(), L * 8);
-        if (rt->matrix) {  // whole layers (host_functions.py:733), calc_trans_iso's delta_colmass
+        if (rt->matrix && rt->mx.dcol_iso) {  // whole layers (host_functions.py:733), calc_trans_iso's delta_colmass
             for (size_t i = 0; i < L; i++) du[i] = (p_int[i] - p_int[i + 1]) / g;
             rc |= h2d(rt, rt->mx.dcol_iso + c * L, du.data(), L * 8);
         }
@@ -998,7 +1033,8 @@ int hx_rt_refresh(hx_rt* rt) {
     // inside the kernels and keeps the state of its last real refresh.  No host round trip.
     // premixed table without the beam: the k-table look-up is fused into k_rt_coef (the beam needs the
     // materialised opacities for its optical depths); HELIOS_RT_FUSED_LOOKUP=0 switches it off
-    bool fused_lookup = rt->d.nspecies == 0 && !rt->f.dir_beam && !rt->matrix;
+    const bool stage_matrix = rt->matrix && !rt->matrix_scan;
+    bool fused_lookup = rt->d.nspecies == 0 && !rt->f.dir_beam && !stage_matrix;
     if (const char* e = getenv("HELIOS_RT_FUSED_LOOKUP")) fused_lookup = fused_lookup && atoi(e) != 0;
     rt->opac_stale = fused_lookup;
     if (rt->d.nspecies == 0) {
@@ -1033,13 +1069,13 @@ int hx_rt_refresh(hx_rt* rt) {
                                                 rt->F_add_heat_sum, L, rt->done);
         HX_LAUNCH_CHECK(ctx);
     }
-    if (rt->matrix) {
+    if (stage_matrix) {
         rc = matrix_calc_trans(rt);
         if (rc) return rc;
     }
     if (rt->f.dir_beam) {
         ProfScope ps(rt, "direct_beam");
-        if (!rt->matrix) {  // (calc_trans_* has just written the same optical depths)
+        if (!stage_matrix) {  // (calc_trans_* has just written the same optical depths)
             k_rt_dtau_halves<<<dim3(hx_cdiv((long long)nc, 256), L, C), 256, 0, ctx->stream>>>(a);
             HX_LAUNCH_CHECK(ctx);
         }
@@ -1051,12 +1087,17 @@ int hx_rt_refresh(hx_rt* rt) {
                                                                            rt->gauss_w, X, Y, I, rt->done);
         HX_LAUNCH_CHECK(ctx);
     }
-    if (!rt->matrix) {
+    if (!stage_matrix) {
         ProfScope ps(rt, "rt_coef");
         k_rt_half_bands<<<dim3(hx_cdiv(X, 32), hx_cdiv(rt->H, 32), C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
         a.from_table = fused_lookup ? 1 : 0;
         DISPATCH_ROWS(launch_coef, rt, a);
+        HX_LAUNCH_CHECK(ctx);
+    }
+    if (rt->matrix_scan) {   // the reflectivity below every node: what the direct solve needs besides the sweeps' planes
+        ProfScope ps(rt, "matrix_prep");
+        k_rt_matrix_prep<<<dim3(rt->g.nblk * rt->g.NW, C), 64, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
     }
     rt->refreshed = true;
@@ -1076,9 +1117,9 @@ static int count_negative_fluxes(hx_rt* rt) {
 
 // the spectral fluxes of one iteration: the register-resident sweeps, or one tridiagonal solve per spectral point
 static int spectral_fluxes(hx_rt* rt, const KArgs& a) {
-    if (rt->matrix) return matrix_solve(rt);
+    if (rt->matrix && !rt->matrix_scan) return matrix_solve(rt);
     {
-        ProfScope ps(rt, "rt_flux");
+        ProfScope ps(rt, rt->matrix_scan ? "matrix_solve" : "rt_flux");
         DISPATCH_ROWS(launch_flux, rt, a);
         HX_LAUNCH_CHECK(rt->ctx);
     }
@@ -1599,7 +1640,7 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
         }
         return 0;
     }
-    if (rt->matrix && (n == "F_up_wg" || n == "F_down_wg" || n == "Fc_up_wg" || n == "Fc_down_wg")) {
+    if (rt->matrix && !rt->matrix_scan && (n == "F_up_wg" || n == "F_down_wg" || n == "Fc_up_wg" || n == "Fc_down_wg")) {
         // the solver's own arrays, already in the reference's layout (centre fluxes: nlayer slabs, the rest stays zero)
         const MatrixArrays& m = rt->mx;
         if (out_bytes != nc * I * 8) return hx_fail(rt->ctx, HX_E_ARG, "hx_rt_get: wrong buffer size");

@@ -27,6 +27,8 @@ struct KArgs {
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
     int iso;                   // isothermal layers: H = L segments between the interfaces, one coefficient set per layer
     int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
+    int matrix, pl_rho;        // `flux calculation method = matrix` as a scan (k_rt_flux<.., MATRIX>): plane index of rho, then 1 / (1 - beta rho)
+    int* trigger;              // [C][Y X] scat_trigger of calc_trans_* (kernels.cu:1102, :1240), matrix method only
     double Kconst;             // 2 pi eps: source prefactor when E == 1 (scat_corr == 0)
     int dim, step;
     double epsi, epsi2, g_0, i2s, w_0_limit, w_0_scat_limit, dtau_limit;
@@ -57,6 +59,8 @@ struct FluxArgs {
     int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane, iso, debug_skip;
     int reverse;           // walk the grid from its far end (see launch_flux)
     int cache_state_from;  // dispatch index from which the state stores stay cached
+    int pl_rho;            // matrix method: plane index of rho at a row's top node; pl_rho + 1: 1 / (1 - beta rho_bottom)
+    const int* trigger;    // matrix method: scat_trigger per spectral point
     double Kconst;
     const hx_rt_column* colpar;
     const double *Bn, *coef, *U0_in, *boaK, *Fdir0, *surf_albedo, *gauss_w;
@@ -549,6 +553,41 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
         return (n & 1) ? Fc[(size_t)c + nc * (n >> 1)] : Fd[(size_t)c + nc * (n >> 1)];
     };
     double F_here = beam_at_node(j * ROWS), F_above = beam_at_node(j * ROWS + 1);
+    // `flux calculation method = matrix`: a spectral point none of whose (half-)layers scatters (w0 <= w_0_scat_limit in all
+    // of them: scat_trigger stays 0, kernels.cu:1102, :1240-1241) takes the solver's pure-absorption branch (:1969-2021,
+    // :2286-2421): F_out = T F_in + 2 pi eps P' -- the same affine form with alpha = T, beta = 0 and sources that are again
+    // u' B_near + v' B_far, so the planes serve both branches.  The trigger is a property of the whole column: the k lanes of a
+    // point vote before any of them writes a coefficient.
+    bool scatters = true;
+    if (a.matrix) {
+        bool mine = false;
+#pragma unroll 1
+        for (int r = 0; r < ROWS; r++) {
+            const int h = j * ROWS + r;
+            if (valid && h < a.H) {
+                const int i = a.iso ? h : h >> 1;
+                const bool lower = a.iso || (h & 1) == 0;
+                const int ii = lower ? i : i + 1;
+                double ray = 0.0, csc = 0.0, cab = 0.0;
+                if (a.cloud_lds) {
+                    cab = sh_cab[(size_t)h * NBX + xs];
+                    csc = sh_csc[(size_t)h * NBX + xs];
+                } else if (a.clouds == 1) {
+                    const size_t src = ((size_t)col * a.X + x) * a.H + h;
+                    cab = a.half_cab[src];
+                    csc = a.half_csc[src];
+                }
+                if (a.scat == 1) ray = sh_ray[(size_t)h * NBX + xs];
+                const double o_l = sh_lay[(size_t)i * TSP + q], o_i = a.iso ? o_l : sh_int[(size_t)ii * TSP + q];
+                const double kap = a.iso ? o_l : (lower ? (o_i + o_l) / 2.0 : (o_l + o_i) / 2.0);
+                mine = mine || single_scat_albedo(ray + csc, kap * sh_mu[h] + cab, a.w_0_limit) > a.w_0_scat_limit;
+            }
+        }
+        const unsigned long long votes = __ballot(mine);
+        const unsigned long long group = a.k >= 64 ? ~0ull : ((1ull << a.k) - 1ull) << (lane - j);
+        scatters = (votes & group) != 0ull;
+        if (valid && j == 0) a.trigger[col * nc + c] = scatters ? 1 : 0;
+    }
     for (int r = 0; r < ROWS; r++) {
         const int h = j * ROWS + r;
         double alpha = 1.0, beta = 0.0, up = 0.0, vp = 0.0, dd = 0.0, du = 0.0;
@@ -587,12 +626,26 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 const int nlim = (fabs(s.Gp) >= 1e8 ? 1 : 0) + (fabs(s.Gm) >= 1e8 ? 1 : 0);
                 if (nlim) atomicAdd(a.diag + HX_DIAG_G_LIMITED, (unsigned long long)nlim);
             }
-            const double invM = 1.0 / s.M;
+            double invM = 1.0 / s.M;
             alpha = s.P * invM;
             beta = -s.N * invM;
-            const double K = 2.0 * HX_PI * a.epsi * (1.0 - w0) / (s.E - w0);
+            double K = 2.0 * HX_PI * a.epsi * (1.0 - w0) / (s.E - w0);
             double u, v;
-            if (a.iso || dtau < a.dtau_limit) {  // isothermal source: B (N + M - P) (kernels.cu:1442, :1640-1643)
+            if (!scatters) {
+                // pure absorption (matrix method, see above): down P' = B_b - T B_t + eps (T - 1) (B_b - B_t) / dtau, up the
+                // same with the nodes exchanged (kernels.cu:2300-2316, :2376-2411); thin or isothermal: (1 - T) (B_b + B_t) / 2
+                alpha = s.trans;
+                beta = 0.0;
+                invM = 1.0;
+                K = 2.0 * HX_PI * a.epsi;
+                if (a.iso || dtau < a.dtau_limit) {
+                    u = v = (1.0 - s.trans) / 2.0;
+                } else {
+                    const double gq = a.epsi * (s.trans - 1.0) / dtau;
+                    u = 1.0 + gq;
+                    v = -s.trans - gq;
+                }
+            } else if (a.iso || dtau < a.dtau_limit) {  // isothermal source: B (N + M - P) (kernels.cu:1442, :1640-1643)
                 u = v = (s.N + s.M - s.P) / 2.0;
             } else {
                 const double qq = (plain ? a.epsi : a.epsi / (s.E * (1.0 - w0 * g0))) * (s.P - s.M + s.N) / dtau;
@@ -601,7 +654,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
             }
             up = K * u * invM;
             vp = K * v * invM;
-            if (a.dir_beam == 1) {
+            if (a.dir_beam == 1 && scatters) {
                 // beam at node h (bottom) and h+1 (top) of this half-layer: Fbot, Ftop from above
                 const double dn = Fbot / nmu * (s.Gm * s.M + s.Gp * s.N) - Ftop / nmu * s.Gm * s.P;
                 const double upw = Ftop / nmu * (s.Gm * s.N + s.Gp * s.M) - Fbot / nmu * s.P * s.Gp;
@@ -609,7 +662,7 @@ __global__ void __launch_bounds__(64 * COEF_TPB) k_rt_coef(KArgs a) {
                 du = dmin(0.0, upw) * invM;
             }
             if (h == 0) {
-                a.boaK[col * nc + c] = (1.0 - w0) / (s.E - w0);
+                a.boaK[col * nc + c] = scatters ? (1.0 - w0) / (s.E - w0) : 1.0;   // (pure absorption: (1 - A) pi B_surf, :2349)
                 a.Fdir0[col * nc + c] = a.dir_beam == 1 ? (a.F_dir_wg + col * wgI)[c] : 0.0;
             }
         }
@@ -659,6 +712,66 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
     a.dtau_l[col * wgL + k] = a.dcol_l[(size_t)col * a.L + i] * (kap_low + ray_low / mu_low);
 }
 
+// ---- per refresh, `flux calculation method = matrix`: the reflectivity of everything below a node ------------------------
+// The reference solves, per spectral point, the tridiagonal system of the down and up equations of all half-layers with the
+// two boundary conditions (kernels.cu:2109-2284) by Thomas elimination: one thread per point, c' and d' of
+// 4 L + 2 rows in two work arrays in HBM.  The same system, eliminated from the surface upwards in its physical variables:
+// with U[n] = rho_n D[n] + sigma_n at node n (at the surface rho_0 = albedo, sigma_0 = A F_dir + (1 - A) pi K B_surf),
+// half-layer h (nodes h, h + 1) gives
+//     rho_{h+1}   = beta + alpha^2 rho_h / (1 - beta rho_h)
+//     sigma_{h+1} = alpha sigma_h / (1 - beta rho_h) + s_up + alpha rho_h s_down / (1 - beta rho_h)
+//     D[h]        = (alpha D[h+1] + beta sigma_h + s_down) / (1 - beta rho_h),      U[n] = rho_n D[n] + sigma_n
+// (Thomas' c' at the even rows is -1 / rho_n: the reference carries the reciprocal form, which loses digits where the
+// atmosphere below reflects little -- its own solves differ by 1e-9 between builds, tests/test_gpu_fused.py.)  rho depends on
+// alpha, beta and the albedo only -- not on the temperatures -- so it is worked out HERE, once per refresh, and kept as two
+// more planes of the coefficient tiles: rho at every row's top node and 1 / (1 - beta rho_bottom).  Its recurrence is a
+// Moebius map, i.e. the composition of 2 x 2 matrices [[alpha^2 - beta^2, beta], [-beta, 1]]: local product of a lane's
+// rows, prefix product over the k lanes of the spectral point, then the lane's rows again from its true start value.
+// sigma and D are affine recurrences and run per iteration in k_rt_flux<ROWS, K, true> -- two scans of the kind the sweeps
+// make eight of, with c', d' in registers.  grid (tiles per column, C), one wavefront per tile.
+__global__ void __launch_bounds__(64) k_rt_matrix_prep(KArgs a) {
+    const int col = blockIdx.y, tl = blockIdx.x, lane = threadIdx.x;
+    if (a.done[col]) return;
+    const int ROWS = a.ROWS, k = a.k, j = lane & (k - 1);
+    const int wv = tl % a.NW, bx = tl / (a.NW * a.nparts);
+    const int s_local = wv * a.S + lane / k, x = bx * a.nxb + s_local / a.ypb;
+    const bool valid = s_local < a.G && x < a.X;
+    double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64 + lane;
+    const double albedo = valid ? a.surf_albedo[(size_t)col * a.X + x] : 0.0;
+    // P = M_{ROWS-1} ... M_0 of this lane's rows
+    double p11 = 1.0, p12 = 0.0, p21 = 0.0, p22 = 1.0;
+    for (int r = 0; r < ROWS; r++) {
+        const double al = ctile[(0 * ROWS + r) * 64], be = ctile[(1 * ROWS + r) * 64];
+        const double ga = fma(al, al, -(be * be));
+        const double n11 = fma(ga, p11, be * p21), n12 = fma(ga, p12, be * p22);
+        p21 = fma(-be, p11, p21);
+        p22 = fma(-be, p12, p22);
+        p11 = n11;
+        p12 = n12;
+    }
+    // inclusive prefix product over the lanes of the point (lower lanes = lower half-layers act first)
+    for (int d = 1; d < k; d <<= 1) {
+        const double q11 = __shfl_up(p11, d), q12 = __shfl_up(p12, d), q21 = __shfl_up(p21, d), q22 = __shfl_up(p22, d);
+        if (j >= d) {
+            const double n11 = fma(p11, q11, p12 * q21), n12 = fma(p11, q12, p12 * q22);
+            const double n21 = fma(p21, q11, p22 * q21), n22 = fma(p21, q12, p22 * q22);
+            // (the entries are kept near one: only their ratios matter)
+            const double sc = 1.0 / fmax(fmax(fabs(n11), fabs(n12)), fmax(fabs(n21), fabs(n22)));
+            p11 = n11 * sc; p12 = n12 * sc; p21 = n21 * sc; p22 = n22 * sc;
+        }
+    }
+    double e11 = __shfl_up(p11, 1), e12 = __shfl_up(p12, 1), e21 = __shfl_up(p21, 1), e22 = __shfl_up(p22, 1);
+    if (j == 0) { e11 = 1.0; e12 = 0.0; e21 = 0.0; e22 = 1.0; }
+    double rho = fma(e11, albedo, e12) / fma(e21, albedo, e22);
+    for (int r = 0; r < ROWS; r++) {
+        const double al = ctile[(0 * ROWS + r) * 64], be = ctile[(1 * ROWS + r) * 64];
+        const double inv = 1.0 / (1.0 - be * rho);
+        rho = fma(al * inv * al, rho, be);
+        __builtin_nontemporal_store(rho, ctile + ((size_t)a.pl_rho * ROWS + r) * 64);
+        __builtin_nontemporal_store(inv, ctile + ((size_t)(a.pl_rho + 1) * ROWS + r) * 64);
+    }
+}
+
 // ---- per iteration: all two-stream sweeps + Gauss quadrature ---------------------------------
 // grid (nblk_x, C).  A workgroup owns nxb bins and walks their ny/ypb groups of Gauss points one
 // after the other, so the Gauss sum of a bin is completed inside the workgroup (fixed order).
@@ -668,7 +781,9 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 #ifndef HX_BEAM_GROUP
 #define HX_BEAM_GROUP 4
 #endif
-template <int ROWS, int K = 0>
+// MATRIX: `flux calculation method = matrix` -- instead of the sweeps, the direct solve of the same equations by the two
+// affine scans described at k_rt_matrix_prep (no up-flux state is read: a direct solve has none)
+template <int ROWS, int K = 0, bool MATRIX = false>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = a.reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
@@ -706,7 +821,12 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             al[r] = __builtin_nontemporal_load(ctile + (0 * ROWS + r) * 64);
             be[r] = __builtin_nontemporal_load(ctile + (1 * ROWS + r) * 64);
             sd[r] = __builtin_nontemporal_load(ctile + (2 * ROWS + r) * 64);  // u' for now
-            Uo[r] = __builtin_nontemporal_load(utile + r * 64);
+            if (MATRIX) {
+                Uo[r] = __builtin_nontemporal_load(ctile + (a.pl_rho * ROWS + r) * 64);        // rho at the row's top node
+                Do[r] = __builtin_nontemporal_load(ctile + ((a.pl_rho + 1) * ROWS + r) * 64);  // 1 / (1 - beta rho_bottom)
+            } else {
+                Uo[r] = __builtin_nontemporal_load(utile + r * 64);
+            }
         }
         if (a.has_vp) {
 #pragma unroll
@@ -717,7 +837,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
         }
         double U0 = 0.0, boaK = 0.0, Fdir0 = 0.0, albedo = 0.0;
         if (m.valid && m.j == 0) {
-            U0 = a.U0[col * nc + m.sp];
+            if (!MATRIX) U0 = a.U0[col * nc + m.sp];
             boaK = a.boaK[col * nc + m.sp];
             Fdir0 = a.Fdir0[col * nc + m.sp];
             albedo = a.surf_albedo[(size_t)col * a.X + m.x];
@@ -766,6 +886,93 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
         // rows (r even, r odd) of this lane whose up-flux the reference makes positive when it is tiny: the odd nodes
         const bool odd0 = (m.j * ROWS) & 1;
         const double thr_even = (a.iso || odd0) ? 1e-100 : 0.0, thr_odd = (a.iso || !odd0) ? 1e-100 : 0.0;
+        if constexpr (MATRIX) {
+            // which values the reference makes positive: with scattering (Thomas, non-isothermal) every x < 1e-100 of the back-
+            // substitution becomes |x| (kernels.cu:2268), with isothermal layers none (:1967); in the pure-absorption sweeps tiny
+            // values do (:2329, :2351, :2418, and -- isothermal -- :1990, :2018), the up-flux at the layer centres excepted (:2394)
+            const bool scatters = m.valid ? a.trigger[col * nc + m.sp] != 0 : false;
+            const bool flip_negative = scatters && !a.iso;
+            const double tiny_d = scatters ? 0.0 : 1e-100;
+            const double tiny_u_even = scatters ? 0.0 : ((a.iso || odd0) ? 1e-100 : 0.0), tiny_u_odd = scatters ? 0.0 : ((a.iso || !odd0) ? 1e-100 : 0.0);
+            auto patch = [&](double v, double tiny) { return flip_negative ? (v < 1e-100 ? fabs(v) : v) : tiny_abs_below(v, tiny); };
+            // rho at the BOTTOM node of row r: the row below's top value (the lane below's last row; the surface albedo)
+            double rho_b = K ? below_fixed<K>(Uo[ROWS - 1]) : from_lane_below<1>(Uo[ROWS - 1], k);
+            const double alb = K ? group_first_lane<K>(albedo, m.lane) : __shfl(albedo, 0, k);
+            if (m.j == 0) rho_b = alb;
+            // per row: a = alpha / (1 - beta rho_b) -- the factor of BOTH affine recurrences --, the constant of the sigma
+            // recurrence s_up + a rho_b s_down, and what the D recurrence needs: beta / (1 - beta rho_b), s_down / (1 - beta rho_b)
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const double inv = Do[r], aa = al[r] * inv;
+                su[r] = fma(aa * rho_b, sd[r], su[r]);
+                be[r] *= inv;
+                sd[r] *= inv;
+                al[r] = aa;
+                rho_b = Uo[r];
+            }
+            // ---------------- sigma: surface -> TOA ----------------
+            double sigma0 = 0.0;
+            if (m.j == 0) sigma0 = albedo * Fdir0 + (1.0 - albedo) * HX_PI * boaK * B_surf;
+            sigma0 = K ? group_first_lane<K>(sigma0, m.lane) : __shfl(sigma0, 0, k);
+            {
+                double A = 1.0, Bc = 0.0;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    Bc = fma(al[r], Bc, su[r]);
+                    A *= al[r];
+                }
+                if (K) {
+                    scan_up_fixed<K>(A, Bc, m.j);
+                } else if (k == 32) {
+                    scan32_up(A, Bc, m.j);
+                } else {
+                    scan_step_up<1>(A, Bc, m.j, k);
+                    scan_step_up<2>(A, Bc, m.j, k);
+                    scan_step_up<4>(A, Bc, m.j, k);
+                    scan_step_up<8>(A, Bc, m.j, k);
+                    scan_step_up<16>(A, Bc, m.j, k);
+                    scan_step_up<32>(A, Bc, m.j, k);
+                }
+                double sg = K ? below_fixed<K>(fma(A, sigma0, Bc)) : from_lane_below<1>(fma(A, sigma0, Bc), k);
+                if (m.j == 0) sg = sigma0;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    sd[r] = fma(be[r], sg, sd[r]);      // constant of the D recurrence: (beta sigma_bottom + s_down) / (1 - beta rho_b)
+                    sg = fma(al[r], sg, su[r]);
+                    su[r] = sg;                         // sigma at the row's top node
+                }
+            }
+            // ---------------- D: TOA -> surface, and U = rho D + sigma ----------------
+            {
+                double A = 1.0, Bc = 0.0;
+#pragma unroll
+                for (int r = ROWS - 1; r >= 0; r--) {
+                    Bc = fma(al[r], Bc, sd[r]);
+                    A *= al[r];
+                }
+                if (K) {
+                    scan_down_fixed<K>(A, Bc, m.j, m.lane);
+                } else if (k == 32) {
+                    scan32_down(A, Bc, m.j, m.lane);
+                } else {
+                    scan_step_down<1>(A, Bc, m.j, k);
+                    scan_step_down<2>(A, Bc, m.j, k);
+                    scan_step_down<4>(A, Bc, m.j, k);
+                    scan_step_down<8>(A, Bc, m.j, k);
+                    scan_step_down<16>(A, Bc, m.j, k);
+                    scan_step_down<32>(A, Bc, m.j, k);
+                }
+                double D = K ? above_fixed<K>(fma(A, D_toa, Bc)) : from_lane_above<1>(fma(A, D_toa, Bc), k);
+                if (m.j == k - 1) D = D_toa;
+#pragma unroll
+                for (int r = ROWS - 1; r >= 0; r--) {
+                    Uo[r] = patch(fma(Uo[r], D, su[r]), (r & 1) ? tiny_u_odd : tiny_u_even);   // U at the top node, D there still in hand
+                    D = patch(fma(al[r], D, sd[r]), tiny_d);
+                    Do[r] = D;
+                }
+            }
+            if (m.j == 0) U0 = patch(fma(albedo, Do[0], sigma0), 0.0);
+        } else
         for (int sweep = 0; sweep < a.nsweep; sweep++) {
             // ---------------- down: TOA -> BOA ----------------
             {

@@ -120,9 +120,11 @@ def test_no_selected_flux_kernel_keeps_registers_in_scratch():
                 if beam and (2 - iso) * L <= 640:      # with the beam: at most 10 rows per lane wherever 64 lanes allow it
                     assert r.value <= 10, (L, iso, k.value, r.value)
     for rows, K in sorted(seen):
-        n = [v for name, v in flux.items() if "k_rt_flux<%d, %d>" % (rows, K) in name]
-        assert len(n) == 1, (rows, K)
-        assert n[0]["vgpr_spill_count"] == 0 and n[0]["private_segment_fixed_size"] == 0, (rows, K, n[0])
+        # the sweeps (`false`) and the direct solve of the matrix method (`true`) share the tiling and its selection
+        for matrix in ("false", "true"):
+            n = [v for name, v in flux.items() if "k_rt_flux<%d, %d, %s>" % (rows, K, matrix) in name]
+            assert len(n) == 1, (rows, K, matrix)
+            assert n[0]["vgpr_spill_count"] == 0 and n[0]["private_segment_fixed_size"] == 0, (rows, K, matrix, n[0])
     # and the instantiations that do spill are known to the selection
     spilling = {(int(name.split("<")[1].split(",")[0]), int(name.split(",")[1].split(">")[0]))
                 for name, v in flux.items() if v["vgpr_spill_count"] > 0}
@@ -142,10 +144,13 @@ def test_no_flux_kernel_serialises_its_tile_loads():
     assert len(dest) >= 4 * 16
     worst = {n: max(c.values()) for n, c in dest.items() if c}
     assert len(worst) == len(dest)
-    assert max(worst.values()) <= 6, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    # (the tilings of 15 and 16 rows keep part of their register image in scratch and are never selected: not held to it)
+    selectable = {n: w for n, w in worst.items() if int(n.split("<")[1].split(",")[0]) <= 14}
+    assert max(selectable.values()) <= 6, sorted(selectable.items(), key=lambda kv: -kv[1])[:5]
+    assert max(worst.values()) <= 8
     # rows x 7 tile loads (three to six coefficient planes, the state) are all there
-    rows = int([n for n in dest if "k_rt_flux<13, 16>" in n][0].split("<")[1].split(",")[0])
-    assert sum(dest[[n for n in dest if "k_rt_flux<13, 16>" in n][0]].values()) >= 7 * rows
+    rows = int([n for n in dest if "k_rt_flux<13, 16, false>" in n][0].split("<")[1].split(",")[0])
+    assert sum(dest[[n for n in dest if "k_rt_flux<13, 16, false>" in n][0]].values()) >= 7 * rows
 
 
 def test_no_coef_kernel_serialises_its_beam_loads():
