@@ -61,6 +61,9 @@ WORKLOADS = {
     # name: (nbin, nlayer, ny, ntemp, npress)
     "c2": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20,
                desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
+    "c2matrix": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, albedo=0.1, matrix=1,
+                     desc="config 2's grid with `flux calculation method = matrix` (the direct solve of the two-stream equations as "
+                          "two scans, k_rt_matrix_prep + k_rt_flux<.., true>) and a surface albedo of 0.1"),
     "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20, scat=0,
                desc="BASELINE config 1: single column, 300 bins x 50 layers, premixed, no scattering"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
@@ -155,6 +158,8 @@ def build_case(w, seed, full_tables=True):
         c.surf_albedo = syn._smooth5(rng.uniform(0.05, 0.4, c.nbin))
     elif w.get("albedo"):
         c.surf_albedo = np.full(c.nbin, float(w["albedo"]))
+    if w.get("matrix"):
+        c.flux_calc_method = "matrix"
     if w.get("scat_corr"):
         c.scat_corr, c.g_0 = 1, float(w.get("g_0", 0.1))
     if w.get("dir_beam"):
@@ -468,8 +473,8 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
     run(it0 + 9, 1)                                 # iteration index = 0 mod 10: refresh + iteration
     run(it0 + 10, min(profile_steps, 9))            # E-iterations under the event profiler
     rt.profile(False)
-    flux_ms, nflux = rt.profile_read("rt_flux")
-    prof = {k: rt.profile_read(k)[0] for k in ("rt_flux", "refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
+    flux_ms, nflux = rt.profile_read("matrix_solve" if c.get("flux_calc_method") == "matrix" else "rt_flux")
+    prof = {k: rt.profile_read(k)[0] for k in ("rt_flux", "matrix_solve", "matrix_prep", "refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
                                                "opac_interpol", "direct_beam", "rt_nodes", "rt_totals_a", "rt_totals_b")}
     t_only_ms = prof["refresh_total"]
     B_E, B_T = tm["step_algorithmic"], tm["refresh_algorithmic"]      # bytes per launch, all columns
@@ -481,7 +486,8 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
         traffic = counters.get("rt_flux_hbm_bytes_per_launch") if counters else None
         if traffic is not None:
             traffic *= ncol / float(counters.get("columns_in_the_measured_batch", 1))   # (the committed figures: one column)
-        roofline = dict(bound="hbm", kernel="k_rt_flux", achieved=achieved, peak=8000.0, unit="GB/s",
+        roofline = dict(bound="hbm", kernel="k_rt_flux<.., true> (matrix method)" if c.get("flux_calc_method") == "matrix" else "k_rt_flux",
+                        achieved=achieved, peak=8000.0, unit="GB/s",
                         frac=achieved / 8000.0, traffic=traffic, traffic_source=counter_source if traffic else None,
                         algorithmic_bytes_per_launch=B_E, actual_bytes_model_per_launch=tm["step_actual"],
                         avg_launch_ms=flux_ms, launches_timed=nflux)

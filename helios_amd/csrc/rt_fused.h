@@ -141,6 +141,8 @@ struct hx_rt {
     // HELIOS_RT_MATRIX=stage: the reference-shaped per-stage kernels (calc_trans_*, one Thomas elimination per thread with its
     // work arrays in HBM) inside the loop instead, as until round 4
     bool matrix_scan = false;
+    bool matrix_keep_state = false;   // the direct solve stores its up-fluxes too (debug = 1: the negative-flux counts read them)
+    int* zero_flags = nullptr;        // [C] zeros: the `done` flags of a launch that must cover every column
     // The iteration index lives on the device (iter_dev[0]: index of the next iteration; k_rt_nodes, the first kernel of an
     // iteration, moves it to iter_dev[1] and increments): the kernels of an iteration then have the SAME arguments every
     // time, and the nine refresh-free iterations between two opacity refreshes are replayed as one hipGraph where the

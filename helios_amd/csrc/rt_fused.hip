@@ -237,6 +237,7 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
 #endif
     f.Kconst = a.Kconst;
     f.pl_rho = a.pl_rho; f.trigger = a.trigger;
+    f.keep_up = rt->matrix_keep_state ? 1 : 0;
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
     f.surf_albedo = a.surf_albedo; f.gauss_w = a.gauss_w;
@@ -419,6 +420,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->matrix = flags->matrix != 0;
     rt->matrix_scan = rt->matrix;
     if (const char* e = getenv("HELIOS_RT_MATRIX")) rt->matrix_scan = rt->matrix && std::string(e) != "stage";
+    rt->matrix_keep_state = rt->matrix_scan && flags->debug == 1;   // count_negative_fluxes reads the up-flux tiles
     if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g, rt->matrix_scan ? 1 : 0))
         return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512 (1024 isothermal layers); use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
@@ -1123,7 +1125,7 @@ static int spectral_fluxes(hx_rt* rt, const KArgs& a) {
         DISPATCH_ROWS(launch_flux, rt, a);
         HX_LAUNCH_CHECK(rt->ctx);
     }
-    return rt->f.debug == 1 ? count_negative_fluxes(rt) : 0;
+    return rt->f.debug == 1 ? count_negative_fluxes(rt) : 0;   // (debug = 1 keeps the solve's stores on: rt_create_into)
 }
 
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
@@ -1650,10 +1652,29 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
         if (centre && rt->f.iso) return 0;
         return hx_d2h(rt->ctx, out, src + c * nc * I, nc * (centre ? L : I) * 8);
     }
+    if (rt->matrix_scan && (n == "F_up_wg" || n == "F_down_wg" || n == "Fc_up_wg" || n == "Fc_down_wg")) {
+        // The direct solve keeps no spectral fluxes between iterations (nothing reads them: the band fluxes are summed inside
+        // the kernel).  Asked for, they are the last solve's: the coefficient tiles and node Planck values it read are still in
+        // place, so the same launch -- this time with its stores, and for every column, also those whose loop has ended --
+        // reproduces them bit for bit (and rewrites the same band fluxes).
+        HX_REQUIRE(rt->ctx, rt->refreshed, HX_E_STATE, "no iteration has been run yet");
+        if (!rt->Dtile) RT_ALLOC(rt->Dtile, (size_t)rt->C * rt->g.flux_elems_per_col);
+        if (!rt->zero_flags) RT_ALLOC(rt->zero_flags, (size_t)rt->C);
+        const bool kd = rt->keep_down, ks = rt->matrix_keep_state;
+        rt->keep_down = true;
+        rt->matrix_keep_state = true;
+        KArgs a = make_args(rt);
+        a.done = rt->zero_flags;
+        DISPATCH_ROWS(launch_flux, rt, a);
+        rt->keep_down = kd;
+        rt->matrix_keep_state = ks;
+        HX_LAUNCH_CHECK(rt->ctx);
+        rt->graph_stale = true;
+    }
     if (n == "F_up_wg") return get_flux_wg(rt, col, rt->Utile, rt->U0, true, true, out, out_bytes);
     if (n == "Fc_up_wg") return get_flux_wg(rt, col, rt->Utile, nullptr, true, false, out, out_bytes);
     if (n == "F_down_wg" || n == "Fc_down_wg") {
-        HX_REQUIRE(rt->ctx, rt->keep_down && rt->Dtile, HX_E_STATE,
+        HX_REQUIRE(rt->ctx, (rt->keep_down || rt->matrix_scan) && rt->Dtile, HX_E_STATE,
                    "down-flux tiles are only kept after hx_rt_set_state(rt, col, \"keep_down\", ...)");
         int rc = get_flux_wg(rt, col, rt->Dtile, nullptr, false, n == "F_down_wg", out, out_bytes);
         if (rc || n != "F_down_wg") return rc;
@@ -1819,7 +1840,9 @@ int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* r
     // what this implementation actually moves (per column)
     const TileGeom& g = rt->g;
     const double tiles = (double)g.nblk * g.NW * 64.0 * g.ROWS * 8.0;  // one plane
-    const double flux_k = tiles * (g.nplane + 2.0 + (rt->keep_down ? 1.0 : 0.0))   // coef + U read/write
+    // (the matrix method's direct solve reads its planes -- two more than the sweeps' -- and keeps no flux state)
+    const double state_planes = rt->matrix_scan ? (rt->matrix_keep_state ? 1.0 : 0.0) : 2.0;
+    const double flux_k = tiles * (g.nplane + state_planes + (rt->keep_down ? 1.0 : 0.0))   // coef + U read/write
                           + 8.0 * X * (rt->H + 3) * 2.0                            // node Planck write+read
                           + 8.0 * X * 2.0 * (L + 1) * 2.0                          // band arrays w + r
                           + 8.0 * X * Y * 2.0;                                     // U0

@@ -57,6 +57,7 @@ struct FluxArgs {
     int X, Y, L, I, H;
     int k, nxb, ypb, nparts, G, NW;
     int dir_beam, nsweep, keep_down, has_vp, pl_vp, pl_dd, nplane, iso, debug_skip;
+    int keep_up;           // matrix method: store the up-fluxes too (the sweeps always do: their state); 0 inside the loop
     int reverse;           // walk the grid from its far end (see launch_flux)
     int cache_state_from;  // dispatch index from which the state stores stay cached
     int pl_rho;            // matrix method: plane index of rho at a row's top node; pl_rho + 1: 1 / (1 - beta rho_bottom)
@@ -1061,8 +1062,8 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
 #endif
         auto store_state = [&]() {
             const size_t eoff = e.tile * (size_t)ROWS * 64 + e.lane;
-            if (!(debug_skip & 2)) {
-                double* ut = a.Utile + col * a.flux_col + eoff;
+            if (!(debug_skip & 2) && (!MATRIX || a.keep_up)) {   // (a direct solve has no state: its spectral fluxes are
+                double* ut = a.Utile + col * a.flux_col + eoff;   //  written where somebody asks for them, hx_rt_get)
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) {
                     // (write-through store that leaves the line in the Infinity Cache: agent scope = `sc1`; see launch_flux)

@@ -260,12 +260,21 @@ def test_fused_matrix_method_vs_oracle(ctx, port, name):
     # 100 layers: the elimination over 402 unknowns amplifies last-bit differences of the temperatures it is fed -- the
     # same kernels agree with the oracle to 1e-12 on identical inputs (test_matrix_flux_solve_vs_oracle) and to 1e-9 after
     # one iteration here, 2e-7 after twelve (the reference's documentation calls the method unstable, parameters.rst:326)
+    # Round 5: the device-resident loop solves the same equations as two scans (k_rt_matrix_prep, k_rt_flux<.., true>) that
+    # carry the reflectivity of the atmosphere below a node where the reference's elimination carries its reciprocal.  The
+    # reference's down-fluxes have rounding noise of their own (tests/matrix_referee.py); after ONE iteration the spectral
+    # fluxes are therefore held, at the same 1e-9, to the extended-precision solution of the reference's system, with the
+    # reference's distance from it asserted next to it.  Everything else, and the twelve-iteration run, against the oracle.
+    import matrix_referee
     for n_iter, rtol in ((1, 1e-9), (12, 5e-6 if name == "L100" else 1e-7)):
         f, grid = fh.run_fused(ctx, c0, n_iter, with_planck_grid=True)
         o = fh.run_oracle(port, c0, n_iter, planck_grid=grid)
         nscat = int(o["scat_trigger"].sum())      # both branches of the solver: "default" mixes them
         assert nscat == 0 if name == "noscat" else nscat > 0 and (name != "default" or nscat < o["scat_trigger"].size)
-        fh.compare(f, o, c0, rtol=rtol)
+        if n_iter == 1:
+            matrix_referee.compare_first_solve(fh, f, o, c0, rtol)
+        else:
+            fh.compare(f, o, c0, rtol=rtol)
 
 
 def test_fused_matrix_method_batch_of_columns(ctx, port):

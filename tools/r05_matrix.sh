@@ -1,6 +1,6 @@
 #!/bin/bash
 # the matrix method as two scans (k_rt_matrix_prep + k_rt_flux<.., true>): its tests, then the same-box A/B against the
-# per-stage kernels of round 4 (HELIOS_RT_MATRIX=stage) at config 2's size
+# per-stage kernels of round 4 (HELIOS_RT_MATRIX=stage) at config 2's size, and the kernel's own line
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r05b
@@ -14,3 +14,13 @@ for pass in 1 2; do
 done
 } > $O/matrix_method_timing.txt 2>&1
 cat $O/matrix_method_timing.txt
+python3 bench.py --workload c2matrix --steps 100 --warmup 20 --no-cpu-baseline --secondary none > $O/c2matrix_bench.json 2> $O/c2matrix.err
+python3 - <<PY
+import json
+l=json.loads([x for x in open("$O/c2matrix_bench.json") if x.startswith("{")][-1])
+print("c2matrix", l["value"], l["ms_per_step"], l["roofline"])
+PY
+rocprofv3 --kernel-trace --stats -d $O/prof_c2matrix -o run -- python3 bench.py --workload c2matrix --steps 50 --warmup 10 --no-cpu-baseline --profile-steps 0 --secondary none --live-counters off > $O/prof_c2matrix.log 2>&1
+python3 tools/rocpd_summary.py $(find $O/prof_c2matrix -name "*.db" | head -1) > $O/c2matrix_kernel_stats.txt 2>&1
+rm -rf $O/prof_c2matrix
+head -12 $O/c2matrix_kernel_stats.txt
