@@ -63,7 +63,7 @@ WORKLOADS = {
                desc="BASELINE config 2: single column, 10 000 bins x 100 layers, premixed corr-k, isotropic scattering"),
     "c2matrix": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, albedo=0.1, matrix=1,
                      desc="config 2's grid with `flux calculation method = matrix` (the direct solve of the two-stream equations as "
-                          "two scans, k_rt_matrix_prep + k_rt_flux<.., true>) and a surface albedo of 0.1"),
+                          "three scans inside k_rt_flux<.., true>) and a surface albedo of 0.1"),
     "c1": dict(nbin=300, nlayer=50, ny=20, ntemp=30, npress=20, scat=0,
                desc="BASELINE config 1: single column, 300 bins x 50 layers, premixed, no scattering"),
     "c3": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20,
@@ -474,7 +474,7 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
     run(it0 + 10, min(profile_steps, 9))            # E-iterations under the event profiler
     rt.profile(False)
     flux_ms, nflux = rt.profile_read("matrix_solve" if c.get("flux_calc_method") == "matrix" else "rt_flux")
-    prof = {k: rt.profile_read(k)[0] for k in ("rt_flux", "matrix_solve", "matrix_prep", "refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
+    prof = {k: rt.profile_read(k)[0] for k in ("rt_flux", "matrix_solve", "refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
                                                "opac_interpol", "direct_beam", "rt_nodes", "rt_totals_a", "rt_totals_b")}
     t_only_ms = prof["refresh_total"]
     B_E, B_T = tm["step_algorithmic"], tm["refresh_algorithmic"]      # bytes per launch, all columns

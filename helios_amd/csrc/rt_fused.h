@@ -21,7 +21,6 @@ struct TileGeom {
     int nblk;         // workgroups per column = nblk_x * nparts
     int nplane;       // coefficient planes per tile: alpha, beta, u' [, v'] [, dd, du]
     int has_vp, pl_vp, pl_dd;
-    int pl_rho;       // matrix method: first of its two planes
     size_t tile_rows; // ROWS
     size_t coef_elems_per_col, flux_elems_per_col;  // doubles
 };
@@ -137,7 +136,7 @@ struct hx_rt {
     bool has_heating = false;
 
     bool matrix = false;           // hx_rt_flags.matrix
-    // the matrix method as two scans on the coefficient tiles (k_rt_matrix_prep, k_rt_flux<.., true>): the default.
+    // the matrix method as three scans on the coefficient tiles (k_rt_flux<.., true>): the default.
     // HELIOS_RT_MATRIX=stage: the reference-shaped per-stage kernels (calc_trans_*, one Thomas elimination per thread with its
     // work arrays in HBM) inside the loop instead, as until round 4
     bool matrix_scan = false;

@@ -124,8 +124,7 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
     g.pl_vp = 3;
     g.pl_dd = 3 + g.has_vp;
     g.nplane = 3 + g.has_vp + (dir_beam ? 2 : 0);
-    g.pl_rho = g.nplane;             // matrix method: rho at the rows' top nodes, 1 / (1 - beta rho_bottom) (k_rt_matrix_prep)
-    if (matrix) g.nplane += 2;
+    (void)matrix;   // (the matrix method's direct solve reads the sweeps' planes, nothing more)
     g.tile_rows = g.ROWS;
     g.coef_elems_per_col = (size_t)g.nblk * g.NW * g.nplane * g.ROWS * 64;
     g.flux_elems_per_col = (size_t)g.nblk * g.NW * g.ROWS * 64;
@@ -141,7 +140,7 @@ KArgs make_args(hx_rt* rt) {
     a.nparts = g.nparts; a.G = g.G; a.NW = g.NW; a.nblk_x = g.nblk_x; a.nblk = g.nblk;
     a.nplane = g.nplane; a.nchunk = rt->nchunk;
     a.has_vp = g.has_vp; a.pl_vp = g.pl_vp; a.pl_dd = g.pl_dd;
-    a.matrix = rt->matrix_scan ? 1 : 0; a.pl_rho = g.pl_rho; a.trigger = rt->mx.trigger;
+    a.matrix = rt->matrix_scan ? 1 : 0; a.trigger = rt->mx.trigger;
     a.Kconst = 2.0 * HX_PI * rt->f.epsi;
     a.scat = rt->f.scat; a.dir_beam = rt->f.dir_beam; a.clouds = rt->f.clouds;
     a.scat_corr = rt->f.scat_corr; a.nsweep = rt->nsweep; a.keep_down = rt->keep_down ? 1 : 0;
@@ -236,7 +235,7 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.debug_skip = debug_skip;
 #endif
     f.Kconst = a.Kconst;
-    f.pl_rho = a.pl_rho; f.trigger = a.trigger;
+    f.trigger = a.trigger;
     f.keep_up = rt->matrix_keep_state ? 1 : 0;
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
@@ -1097,11 +1096,6 @@ int hx_rt_refresh(hx_rt* rt) {
         DISPATCH_ROWS(launch_coef, rt, a);
         HX_LAUNCH_CHECK(ctx);
     }
-    if (rt->matrix_scan) {   // the reflectivity below every node: what the direct solve needs besides the sweeps' planes
-        ProfScope ps(rt, "matrix_prep");
-        k_rt_matrix_prep<<<dim3(rt->g.nblk * rt->g.NW, C), 64, 0, ctx->stream>>>(a);
-        HX_LAUNCH_CHECK(ctx);
-    }
     rt->refreshed = true;
     return 0;
 }
@@ -1840,7 +1834,7 @@ int hx_rt_traffic_model(hx_rt* rt, double* step_alg, double* step_act, double* r
     // what this implementation actually moves (per column)
     const TileGeom& g = rt->g;
     const double tiles = (double)g.nblk * g.NW * 64.0 * g.ROWS * 8.0;  // one plane
-    // (the matrix method's direct solve reads its planes -- two more than the sweeps' -- and keeps no flux state)
+    // (the matrix method's direct solve reads the same planes and keeps no flux state)
     const double state_planes = rt->matrix_scan ? (rt->matrix_keep_state ? 1.0 : 0.0) : 2.0;
     const double flux_k = tiles * (g.nplane + state_planes + (rt->keep_down ? 1.0 : 0.0))   // coef + U read/write
                           + 8.0 * X * (rt->H + 3) * 2.0                            // node Planck write+read

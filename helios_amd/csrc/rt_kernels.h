@@ -27,7 +27,7 @@ struct KArgs {
     int scat, dir_beam, clouds, scat_corr, nsweep, keep_down, real_star;
     int iso;                   // isothermal layers: H = L segments between the interfaces, one coefficient set per layer
     int has_vp, pl_vp, pl_dd;  // v' plane stored? plane indices of v' and of dd (du = dd + 1)
-    int matrix, pl_rho;        // `flux calculation method = matrix` as a scan (k_rt_flux<.., MATRIX>): plane index of rho, then 1 / (1 - beta rho)
+    int matrix;                // `flux calculation method = matrix` as scans (k_rt_flux<.., true>): k_rt_coef serves its two branches
     int* trigger;              // [C][Y X] scat_trigger of calc_trans_* (kernels.cu:1102, :1240), matrix method only
     double Kconst;             // 2 pi eps: source prefactor when E == 1 (scat_corr == 0)
     int dim, step;
@@ -60,7 +60,6 @@ struct FluxArgs {
     int keep_up;           // matrix method: store the up-fluxes too (the sweeps always do: their state); 0 inside the loop
     int reverse;           // walk the grid from its far end (see launch_flux)
     int cache_state_from;  // dispatch index from which the state stores stay cached
-    int pl_rho;            // matrix method: plane index of rho at a row's top node; pl_rho + 1: 1 / (1 - beta rho_bottom)
     const int* trigger;    // matrix method: scat_trigger per spectral point
     double Kconst;
     const hx_rt_column* colpar;
@@ -713,7 +712,7 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
     a.dtau_l[col * wgL + k] = a.dcol_l[(size_t)col * a.L + i] * (kap_low + ray_low / mu_low);
 }
 
-// ---- per refresh, `flux calculation method = matrix`: the reflectivity of everything below a node ------------------------
+// ---- `flux calculation method = matrix`: the direct solve as three scans ------------------------------------------------------
 // The reference solves, per spectral point, the tridiagonal system of the down and up equations of all half-layers with the
 // two boundary conditions (kernels.cu:2109-2284) by Thomas elimination: one thread per point, c' and d' of
 // 4 L + 2 rows in two work arrays in HBM.  The same system, eliminated from the surface upwards in its physical variables:
@@ -723,53 +722,61 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 //     sigma_{h+1} = alpha sigma_h / (1 - beta rho_h) + s_up + alpha rho_h s_down / (1 - beta rho_h)
 //     D[h]        = (alpha D[h+1] + beta sigma_h + s_down) / (1 - beta rho_h),      U[n] = rho_n D[n] + sigma_n
 // (Thomas' c' at the even rows is -1 / rho_n: the reference carries the reciprocal form, which loses digits where the
-// atmosphere below reflects little -- its own solves differ by 1e-9 between builds, tests/test_gpu_fused.py.)  rho depends on
-// alpha, beta and the albedo only -- not on the temperatures -- so it is worked out HERE, once per refresh, and kept as two
-// more planes of the coefficient tiles: rho at every row's top node and 1 / (1 - beta rho_bottom).  Its recurrence is a
-// Moebius map, i.e. the composition of 2 x 2 matrices [[alpha^2 - beta^2, beta], [-beta, 1]]: local product of a lane's
-// rows, prefix product over the k lanes of the spectral point, then the lane's rows again from its true start value.
-// sigma and D are affine recurrences and run per iteration in k_rt_flux<ROWS, K, true> -- two scans of the kind the sweeps
-// make eight of, with c', d' in registers.  grid (tiles per column, C), one wavefront per tile.
-__global__ void __launch_bounds__(64) k_rt_matrix_prep(KArgs a) {
-    const int col = blockIdx.y, tl = blockIdx.x, lane = threadIdx.x;
-    if (a.done[col]) return;
-    const int ROWS = a.ROWS, k = a.k, j = lane & (k - 1);
-    const int wv = tl % a.NW, bx = tl / (a.NW * a.nparts);
-    const int s_local = wv * a.S + lane / k, x = bx * a.nxb + s_local / a.ypb;
-    const bool valid = s_local < a.G && x < a.X;
-    double* ctile = a.coef + col * a.coef_col + (size_t)tl * a.nplane * ROWS * 64 + lane;
-    const double albedo = valid ? a.surf_albedo[(size_t)col * a.X + x] : 0.0;
-    // P = M_{ROWS-1} ... M_0 of this lane's rows
-    double p11 = 1.0, p12 = 0.0, p21 = 0.0, p22 = 1.0;
-    for (int r = 0; r < ROWS; r++) {
-        const double al = ctile[(0 * ROWS + r) * 64], be = ctile[(1 * ROWS + r) * 64];
-        const double ga = fma(al, al, -(be * be));
-        const double n11 = fma(ga, p11, be * p21), n12 = fma(ga, p12, be * p22);
-        p21 = fma(-be, p11, p21);
-        p22 = fma(-be, p12, p22);
-        p11 = n11;
-        p12 = n12;
-    }
-    // inclusive prefix product over the lanes of the point (lower lanes = lower half-layers act first)
-    for (int d = 1; d < k; d <<= 1) {
-        const double q11 = __shfl_up(p11, d), q12 = __shfl_up(p12, d), q21 = __shfl_up(p21, d), q22 = __shfl_up(p22, d);
-        if (j >= d) {
-            const double n11 = fma(p11, q11, p12 * q21), n12 = fma(p11, q12, p12 * q22);
-            const double n21 = fma(p21, q11, p22 * q21), n22 = fma(p21, q12, p22 * q22);
-            // (the entries are kept near one: only their ratios matter)
-            const double sc = 1.0 / fmax(fmax(fabs(n11), fabs(n12)), fmax(fabs(n21), fabs(n22)));
-            p11 = n11 * sc; p12 = n12 * sc; p21 = n21 * sc; p22 = n22 * sc;
+// atmosphere below reflects little -- tests/matrix_referee.py measures it against an extended-precision solve.)  rho -- the
+// reflectivity of everything below a node -- follows a Moebius map, i.e. the composition of the 2 x 2 matrices
+// [[alpha^2 - beta^2, beta], [-beta, 1]]; sigma and D are affine recurrences.  All three run on the sweeps' tiling inside
+// k_rt_flux<ROWS, K, true>: local product of a lane's rows, prefix product over the k lanes of the spectral point (DPP), the
+// lane's rows again from its true start value -- on the three coefficient planes the sweeps read, with nothing kept between
+// iterations (no flux state, no work arrays): 1.0 GB per launch at config 2 where the reference-shaped solver moved 9.
+struct Moebius {
+    double p11, p12, p21, p22;   // rho -> (p11 rho + p12) / (p21 rho + p22); only the ratios matter
+};
+// P <- P o Q (Q acts first)
+__device__ __forceinline__ void moebius_after(Moebius& P, double q11, double q12, double q21, double q22) {
+    const double n11 = fma(P.p11, q11, P.p12 * q21), n12 = fma(P.p11, q12, P.p12 * q22);
+    const double n21 = fma(P.p21, q11, P.p22 * q21), n22 = fma(P.p21, q12, P.p22 * q22);
+    P.p11 = n11; P.p12 = n12; P.p21 = n21; P.p22 = n22;
+}
+// the DPP-selected lane's value; a lane without a source inside its row reads the identity's entry (ONE: 1.0, else 0.0)
+template <int CTRL, bool ONE>
+__device__ __forceinline__ double dpp_or_identity(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = ONE ? __builtin_amdgcn_update_dpp(0x3FF00000, __double2hiint(v), CTRL, 0xf, 0xf, false)
+                       : __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ void moebius_row_neighbour(Moebius& P) {
+    moebius_after(P, dpp_or_identity<CTRL, true>(P.p11), dpp_or_identity<CTRL, false>(P.p12), dpp_or_identity<CTRL, false>(P.p21),
+                  dpp_or_identity<CTRL, true>(P.p22));
+}
+// inclusive prefix composition over the lanes of a spectral point (lower lanes = lower half-layers act first)
+template <int K>
+__device__ __forceinline__ void moebius_scan_up(Moebius& P, int j, int k) {
+    if (K) {
+        moebius_row_neighbour<0x111>(P);  // row_shr:1
+        moebius_row_neighbour<0x112>(P);
+        moebius_row_neighbour<0x114>(P);
+        moebius_row_neighbour<0x118>(P);
+        if (K == 32 || K == 64) {         // row_bcast:15 into rows 1 and 3
+            const double q11 = dpp_move<0x142, 0xa>(P.p11), q12 = dpp_move<0x142, 0xa>(P.p12), q21 = dpp_move<0x142, 0xa>(P.p21),
+                         q22 = dpp_move<0x142, 0xa>(P.p22);
+            if (j & 16) moebius_after(P, q11, q12, q21, q22);
         }
+        if (K == 64) {                    // row_bcast:31 into rows 2 and 3
+            const double q11 = dpp_move<0x143, 0xc>(P.p11), q12 = dpp_move<0x143, 0xc>(P.p12), q21 = dpp_move<0x143, 0xc>(P.p21),
+                         q22 = dpp_move<0x143, 0xc>(P.p22);
+            if (j >= 32) moebius_after(P, q11, q12, q21, q22);
+        }
+    } else {
+#define HX_MOEBIUS_STEP(N)                                                                                              \
+    if (N < k) {                                                                                                        \
+        const double q11 = from_lane_below<N>(P.p11, k), q12 = from_lane_below<N>(P.p12, k),                            \
+                     q21 = from_lane_below<N>(P.p21, k), q22 = from_lane_below<N>(P.p22, k);                            \
+        if (j >= N) moebius_after(P, q11, q12, q21, q22);                                                               \
     }
-    double e11 = __shfl_up(p11, 1), e12 = __shfl_up(p12, 1), e21 = __shfl_up(p21, 1), e22 = __shfl_up(p22, 1);
-    if (j == 0) { e11 = 1.0; e12 = 0.0; e21 = 0.0; e22 = 1.0; }
-    double rho = fma(e11, albedo, e12) / fma(e21, albedo, e22);
-    for (int r = 0; r < ROWS; r++) {
-        const double al = ctile[(0 * ROWS + r) * 64], be = ctile[(1 * ROWS + r) * 64];
-        const double inv = 1.0 / (1.0 - be * rho);
-        rho = fma(al * inv * al, rho, be);
-        __builtin_nontemporal_store(rho, ctile + ((size_t)a.pl_rho * ROWS + r) * 64);
-        __builtin_nontemporal_store(inv, ctile + ((size_t)(a.pl_rho + 1) * ROWS + r) * 64);
+        HX_MOEBIUS_STEP(1) HX_MOEBIUS_STEP(2) HX_MOEBIUS_STEP(4) HX_MOEBIUS_STEP(8) HX_MOEBIUS_STEP(16) HX_MOEBIUS_STEP(32)
+#undef HX_MOEBIUS_STEP
     }
 }
 
@@ -783,7 +790,7 @@ __global__ void __launch_bounds__(64) k_rt_matrix_prep(KArgs a) {
 #define HX_BEAM_GROUP 4
 #endif
 // MATRIX: `flux calculation method = matrix` -- instead of the sweeps, the direct solve of the same equations by the two
-// affine scans described at k_rt_matrix_prep (no up-flux state is read: a direct solve has none)
+// scans described above (`the direct solve as three scans`) (no up-flux state is read: a direct solve has none)
 template <int ROWS, int K = 0, bool MATRIX = false>
 __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
@@ -822,12 +829,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             al[r] = __builtin_nontemporal_load(ctile + (0 * ROWS + r) * 64);
             be[r] = __builtin_nontemporal_load(ctile + (1 * ROWS + r) * 64);
             sd[r] = __builtin_nontemporal_load(ctile + (2 * ROWS + r) * 64);  // u' for now
-            if (MATRIX) {
-                Uo[r] = __builtin_nontemporal_load(ctile + (a.pl_rho * ROWS + r) * 64);        // rho at the row's top node
-                Do[r] = __builtin_nontemporal_load(ctile + ((a.pl_rho + 1) * ROWS + r) * 64);  // 1 / (1 - beta rho_bottom)
-            } else {
-                Uo[r] = __builtin_nontemporal_load(utile + r * 64);
-            }
+            if (!MATRIX) Uo[r] = __builtin_nontemporal_load(utile + r * 64);
         }
         if (a.has_vp) {
 #pragma unroll
@@ -896,20 +898,41 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             const double tiny_d = scatters ? 0.0 : 1e-100;
             const double tiny_u_even = scatters ? 0.0 : ((a.iso || odd0) ? 1e-100 : 0.0), tiny_u_odd = scatters ? 0.0 : ((a.iso || !odd0) ? 1e-100 : 0.0);
             auto patch = [&](double v, double tiny) { return flip_negative ? (v < 1e-100 ? fabs(v) : v) : tiny_abs_below(v, tiny); };
-            // rho at the BOTTOM node of row r: the row below's top value (the lane below's last row; the surface albedo)
-            double rho_b = K ? below_fixed<K>(Uo[ROWS - 1]) : from_lane_below<1>(Uo[ROWS - 1], k);
-            const double alb = K ? group_first_lane<K>(albedo, m.lane) : __shfl(albedo, 0, k);
-            if (m.j == 0) rho_b = alb;
-            // per row: a = alpha / (1 - beta rho_b) -- the factor of BOTH affine recurrences --, the constant of the sigma
-            // recurrence s_up + a rho_b s_down, and what the D recurrence needs: beta / (1 - beta rho_b), s_down / (1 - beta rho_b)
+            // ---------------- rho: surface -> TOA ----------------
+            // (the tiles' padding rows and lanes hold alpha = 1, beta = 0: the identity)
+            Moebius P = {1.0, 0.0, 0.0, 1.0};
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
-                const double inv = Do[r], aa = al[r] * inv;
-                su[r] = fma(aa * rho_b, sd[r], su[r]);
+                const double ga = fma(al[r], al[r], -(be[r] * be[r]));
+                const double n11 = fma(ga, P.p11, be[r] * P.p21), n12 = fma(ga, P.p12, be[r] * P.p22);
+                P.p21 = fma(-be[r], P.p11, P.p21);
+                P.p22 = fma(-be[r], P.p12, P.p22);
+                P.p11 = n11;
+                P.p12 = n12;
+            }
+            {   // entries near one before the lanes are combined: a stack of thick, nearly conservative scatterers shrinks the
+                // product by 4e-5 per row, and only the ratios matter
+                const double sc = 1.0 / fmax(fmax(fabs(P.p11), fabs(P.p12)), fmax(fabs(P.p21), fabs(P.p22)));
+                P.p11 *= sc; P.p12 *= sc; P.p21 *= sc; P.p22 *= sc;
+            }
+            moebius_scan_up<K>(P, m.j, k);
+            double e11 = K ? below_fixed<K>(P.p11) : from_lane_below<1>(P.p11, k), e12 = K ? below_fixed<K>(P.p12) : from_lane_below<1>(P.p12, k);
+            double e21 = K ? below_fixed<K>(P.p21) : from_lane_below<1>(P.p21, k), e22 = K ? below_fixed<K>(P.p22) : from_lane_below<1>(P.p22, k);
+            const double alb = K ? group_first_lane<K>(albedo, m.lane) : __shfl(albedo, 0, k);
+            double rho = fma(e11, alb, e12) / fma(e21, alb, e22);   // at this lane's lowest node
+            if (m.j == 0) rho = alb;
+            // per row: a = alpha / (1 - beta rho_b) -- the factor of BOTH affine recurrences --, the constant of the sigma
+            // recurrence s_up + a rho_b s_down, what the D recurrence needs: beta / (1 - beta rho_b), s_down / (1 - beta rho_b),
+            // and rho at the row's top node (kept where the sweeps keep their up-flux)
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const double inv = 1.0 / (1.0 - be[r] * rho), aa = al[r] * inv;
+                su[r] = fma(aa * rho, sd[r], su[r]);
+                rho = fma(aa * al[r], rho, be[r]);
+                Uo[r] = rho;
                 be[r] *= inv;
                 sd[r] *= inv;
                 al[r] = aa;
-                rho_b = Uo[r];
             }
             // ---------------- sigma: surface -> TOA ----------------
             double sigma0 = 0.0;

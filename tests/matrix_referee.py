@@ -7,7 +7,7 @@ Why it exists.  The reference's elimination carries the reciprocal of the reflec
 2^10 ... 2^40 times larger than their difference, and the down-fluxes it returns carry that many bits of rounding noise (the
 reference's documentation calls the method unstable, docs/sections/parameters.rst:326).  Two builds of the SAME algorithm agree
 because they round alike.  The library solves the same equations with the reflectivity itself (csrc/rt_kernels.h,
-k_rt_matrix_prep) and does not share the noise, so the two differ by exactly the reference's error -- which this referee
+k_rt_flux<.., true>) and does not share the noise, so the two differ by exactly the reference's error -- which this referee
 measures: the library is held to the extended-precision solution at the tolerance the tests always used, and the reference's
 double-precision result is shown to sit further from it.
 

@@ -260,7 +260,7 @@ def test_fused_matrix_method_vs_oracle(ctx, port, name):
     # 100 layers: the elimination over 402 unknowns amplifies last-bit differences of the temperatures it is fed -- the
     # same kernels agree with the oracle to 1e-12 on identical inputs (test_matrix_flux_solve_vs_oracle) and to 1e-9 after
     # one iteration here, 2e-7 after twelve (the reference's documentation calls the method unstable, parameters.rst:326)
-    # Round 5: the device-resident loop solves the same equations as two scans (k_rt_matrix_prep, k_rt_flux<.., true>) that
+    # Round 5: the device-resident loop solves the same equations as three scans (k_rt_flux<.., true>) that
     # carry the reflectivity of the atmosphere below a node where the reference's elimination carries its reciprocal.  The
     # reference's down-fluxes have rounding noise of their own (tests/matrix_referee.py); after ONE iteration the spectral
     # fluxes are therefore held, at the same 1e-9, to the extended-precision solution of the reference's system, with the

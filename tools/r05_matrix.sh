@@ -1,5 +1,5 @@
 #!/bin/bash
-# the matrix method as two scans (k_rt_matrix_prep + k_rt_flux<.., true>): its tests, then the same-box A/B against the
+# the matrix method as three scans (k_rt_flux<.., true>): its tests, then the same-box A/B against the
 # per-stage kernels of round 4 (HELIOS_RT_MATRIX=stage) at config 2's size, and the kernel's own line
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -24,3 +24,5 @@ rocprofv3 --kernel-trace --stats -d $O/prof_c2matrix -o run -- python3 bench.py 
 python3 tools/rocpd_summary.py $(find $O/prof_c2matrix -name "*.db" | head -1) > $O/c2matrix_kernel_stats.txt 2>&1
 rm -rf $O/prof_c2matrix
 head -12 $O/c2matrix_kernel_stats.txt
+# where a whole run's wall clock goes (config 2 and config 3 through helios.py to equilibrium)
+python3 tools/whole_run_timeline.py --out $O/whole_run_timeline.json > $O/timeline.log 2>&1; tail -5 $O/timeline.log
