@@ -21,8 +21,12 @@ namespace {
 //     q' = fma(fma(-q, n^k, a), r, q) is the correctly rounded quotient (Markstein's theorem: r correctly rounded, q within
 //     one ulp) -- three instructions instead of the division's scale / reciprocal / Newton / fix-up sequence.  On the CPU the
 //     whole table of config 2's grid and the test grids: not one entry differs from the divisions;
-//   * exp(-n y) underflows to exactly 0 beyond n y = 745.2, for that n and every later one: a wavefront whose edges have all
-//     reached it leaves the loop (short wavelengths / low temperatures: most of the table's rows).
+//   * the series is left where no later term can change the sum.  The n-th term of a bin is D times the integral of
+//     x^3 exp(-n x) over the bin's [y_top, y_bot]: positive and falling with n, and so is the rounding noise of its two computed
+//     halves (a few ulp of Phi_n(y_top)).  Once D (|term_n| + 2^-47 Phi_n(y_top)) < 2^-55 |sum| -- a quarter of an ulp of the sum,
+//     with the noise bound counted in -- every later addition would round back to the sum it was added to, in every bin of the
+//     wavefront: same bits, a tenth to a half of the 199 terms outside the Rayleigh-Jeans corner.  (exp(-n y) = 0 exactly,
+//     beyond n y = 745.2, is the special case of it.)
 // A multiply-recurrence for exp(-n y) (re-anchored or in double-double) is NOT used: at 10 000 bins the Rayleigh-Jeans corner
 // of the table cancels eleven digits inside the formula and the entries move by 1e-4 relative -- the table's own noise, but
 // two hundred times the tolerance the table is held to against the reference.
@@ -66,12 +70,15 @@ __device__ __forceinline__ void planck_row_entry(double* __restrict__ grid, cons
         for (int n = 1; n < 200; n++) {
             const double dn = c_planck_series.d[n][0];
             const double e = exp(-dn * y);
-            if (__ballot(e != 0.0) == 0ull) break;   // every later term of every bin of this wavefront is 0 - 0
             const double phi = e * (quotient(y3, dn, c_planck_series.r[n][0]) + quotient(a2, c_planck_series.d[n][1], c_planck_series.r[n][1]) +
                                     quotient(a1, c_planck_series.d[n][2], c_planck_series.r[n][2]) +
                                     quotient(6.0, c_planck_series.d[n][3], c_planck_series.r[n][3]));
             const double other = next_lane(phi);
-            acc += D * (mine_is_bot ? other - phi : phi - other);
+            const double diff = mine_is_bot ? other - phi : phi - other;
+            acc += D * diff;
+            // may a later term still move this bin's sum?  (lanes without a bin do not hold the wavefront back)
+            const bool live = bin && !(D * (fabs(diff) + 0x1p-47 * fmax(phi, other)) < 0x1p-55 * fabs(acc));
+            if (__ballot(live) == 0ull) break;
         }
     }
     if (bin) grid[x + (size_t)r * nbin] = acc / dlambda[x];
