@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/ and are copied into profiles/ afterwards).  Usage: bash tools/profile_round.sh r02
 # rocprofv3: --kernel-trace [--stats] only, counters in their own passes, the program itself after `--`.
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O && cd $R
@@ -34,7 +34,14 @@ stats c2 --steps 50 --warmup 10
 python3 bench.py --workload c3 --live-counters all > $O/c3_bench.json 2>> $O/bench.err
 stats c3 --steps 20 --warmup 10
 stats c5 --steps 20 --warmup 10
-python3 bench.py --workload c4 --steps 10 --warmup 10 > $O/c4_bench_64columns.json 2>> $O/bench.err
+# (config 4 at 64 columns per GPU, the default grid as a 64-column batch: live in bench_n1.json's `secondary` since round 5)
+python3 bench.py --workload c2matrix --steps 100 --warmup 20 --no-cpu-baseline --secondary none > $O/c2matrix_bench.json 2>> $O/bench.err
+stats c2matrix --steps 50 --warmup 10
+{ for pass in 1 2; do
+  echo "# three scans inside k_rt_flux<.., true> (default)"; python3 tools/time_matrix_method.py 10000 100 2>/dev/null | grep MATRIX_METHOD
+  echo "# per-stage kernels (HELIOS_RT_MATRIX=stage)"; HELIOS_RT_MATRIX=stage python3 tools/time_matrix_method.py 10000 100 2>/dev/null | grep MATRIX_METHOD
+done; } > $O/matrix_method_timing.txt 2>&1
+python3 tools/whole_run_timeline.py --out $O/whole_run_timeline.json > $O/timeline.log 2>&1
 python3 bench.py --workload c1 --steps 500 --no-cpu-baseline > $O/c1_bench.json 2>> $O/bench.err
 python3 bench.py --columns-per-gpu 4 --steps 50 --no-cpu-baseline --secondary none > $O/c2_bench_4columns.json 2>> $O/bench.err
 python3 bench.py --phase convection --steps 100 --no-cpu-baseline > $O/c2_bench_convection_loop.json 2>> $O/bench.err
