@@ -31,20 +31,39 @@ namespace {
 // of the table cancels eleven digits inside the formula and the entries move by 1e-4 relative -- the table's own noise, but
 // two hundred times the tolerance the table is held to against the reference.
 // ---------------------------------------------------------------------------------------------
+struct PlanckSeriesRow {   // one term of the series: what depends on n alone (64 bytes: one scalar load)
+    double d1, d2, d3;     // n, n^2, n^3 (exact)
+    double r1, r2, r3;     // their reciprocals, correctly rounded (host division)
+    double c4;             // 6 / n^4, correctly rounded (host division): the constant term of Phi_n's polynomial
+    double pad;
+};
 struct PlanckSeriesTable {
-    double d[200][4];  // n, n^2, n^3, n^4 (exact)
-    double r[200][4];  // their reciprocals, correctly rounded (host division)
+    PlanckSeriesRow row[200];
 };
 __constant__ PlanckSeriesTable c_planck_series;
+
+// a row of the table in sixteen scalar registers, loaded without the compiler's help (see planck_row_entry)
+typedef int int16v __attribute__((ext_vector_type(16)));
+union RowBits {
+    int16v v;
+    PlanckSeriesRow r;
+    __device__ RowBits() {}
+};
+__device__ __forceinline__ RowBits load_row(const PlanckSeriesRow* p) {
+    RowBits b;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(b.v) : "s"(p));
+    return b;
+}
+__device__ __forceinline__ void wait_row(RowBits& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b.v)); }
 
 __device__ __forceinline__ double quotient(double a, double d, double r) {
     const double q = a * r;
     return fma(fma(-q, d, a), r, q);
 }
 
-__device__ __forceinline__ double next_lane(double v) {  // the value of lane + 1 (lane 63: its own, unused)
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x130, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x130, 0xF, 0xF, false);
+__device__ __forceinline__ double next_lane(double v) {  // the value of lane + 1 (lane 63: unspecified, unused)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x130, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -52,7 +71,7 @@ constexpr int PLANCK_BINS_PER_WAVE = 63, PLANCK_WAVES = 4;
 
 __device__ __forceinline__ void planck_row_entry(double* __restrict__ grid, const double* __restrict__ lambda_edge,
                                                  const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T,
-                                                 int step) {
+                                                 int step, const PlanckSeriesTable* __restrict__ tab) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (blockIdx.x * PLANCK_WAVES + wave) * PLANCK_BINS_PER_WAVE + lane;   // this lane's edge, and its bin
     const int r = blockIdx.y;
@@ -64,21 +83,31 @@ __device__ __forceinline__ void planck_row_entry(double* __restrict__ grid, cons
         const double kh = HX_KBOLTZMANN / HX_HCONST;
         const double D = 2.0 * (kh * kh * kh * HX_KBOLTZMANN * (T * T * T * T)) / (HX_CSPEED * HX_CSPEED);
         const double y = x <= nbin ? HX_HCONST * HX_CSPEED / (lambda_edge[x] * HX_KBOLTZMANN * T) : 1e6;  // (beyond the grid: e = 0)
-        // the reference orders the two edges of a bin so that y_top < y_bot (:399-403) and sums D * (Phi(y_top) - Phi(y_bot))
-        const bool mine_is_bot = !(y < next_lane(y));
+        // the reference orders the two edges of a bin so that y_top < y_bot (:399-403) and sums D * (Phi(y_top) - Phi(y_bot)):
+        // D (other - mine) where this lane's edge is the bin's y_bot, D (mine - other) = (-D) (other - mine) otherwise (exact)
+        const double Ds = !(y < next_lane(y)) ? D : -D;
         const double y2 = y * y, y3 = y2 * y, a2 = 3.0 * y2, a1 = 6.0 * y;
+        const PlanckSeriesRow* __restrict__ rows = tab->row;
+        RowBits c = load_row(rows + 1);
+        wait_row(c);
         for (int n = 1; n < 200; n++) {
-            const double dn = c_planck_series.d[n][0];
-            const double e = exp(-dn * y);
-            const double phi = e * (quotient(y3, dn, c_planck_series.r[n][0]) + quotient(a2, c_planck_series.d[n][1], c_planck_series.r[n][1]) +
-                                    quotient(a1, c_planck_series.d[n][2], c_planck_series.r[n][2]) +
-                                    quotient(6.0, c_planck_series.d[n][3], c_planck_series.r[n][3]));
+            // the next term's row: ONE 64-byte scalar load, requested here and waited for behind this term's arithmetic (written
+            // as a plain struct load, the compiler sinks it to its first use and every term begins with a scalar-memory round trip)
+            RowBits nx = load_row(rows + (n < 199 ? n + 1 : 199));
+            const PlanckSeriesRow& cr = c.r;
+            const double e = exp(-cr.d1 * y);
+            const double phi = e * (quotient(y3, cr.d1, cr.r1) + quotient(a2, cr.d2, cr.r2) + quotient(a1, cr.d3, cr.r3) + cr.c4);
             const double other = next_lane(phi);
-            const double diff = mine_is_bot ? other - phi : phi - other;
-            acc += D * diff;
-            // may a later term still move this bin's sum?  (lanes without a bin do not hold the wavefront back)
-            const bool live = bin && !(D * (fabs(diff) + 0x1p-47 * fmax(phi, other)) < 0x1p-55 * fabs(acc));
-            if (__ballot(live) == 0ull) break;
+            const double diff = other - phi;
+            acc += Ds * diff;
+            // may a later term still move this bin's sum?  (lanes without a bin do not hold the wavefront back; asked every
+            // fourth term: leaving a few terms late changes nothing)
+            if ((n & 3) == 0) {
+                const bool live = bin && !(D * (fabs(diff) + 0x1p-47 * fmax(phi, other)) < 0x1p-55 * fabs(acc));
+                if (__ballot(live) == 0ull) break;
+            }
+            wait_row(nx);
+            c = nx;
         }
     }
     if (bin) grid[x + (size_t)r * nbin] = acc / dlambda[x];
@@ -87,14 +116,14 @@ __device__ __forceinline__ void planck_row_entry(double* __restrict__ grid, cons
 __global__ void __launch_bounds__(64 * PLANCK_WAVES)
 k_plancktable(double* __restrict__ grid, const double* __restrict__ lambda_edge,
               const double* __restrict__ dlambda, int nbin, double Tstar, int nrow_T, int step) {
-    planck_row_entry(grid, lambda_edge, dlambda, nbin, Tstar, nrow_T, step);
+    planck_row_entry(grid, lambda_edge, dlambda, nbin, Tstar, nrow_T, step, &c_planck_series);
 }
 
 // one row at the stellar temperature (a name of its own, so that kernel statistics do not average it with the table)
 __global__ void __launch_bounds__(64 * PLANCK_WAVES)
 k_planck_star_row(double* __restrict__ row, const double* __restrict__ lambda_edge,
                   const double* __restrict__ dlambda, int nbin, double Tstar) {
-    planck_row_entry(row, lambda_edge, dlambda, nbin, Tstar, 0, 1);
+    planck_row_entry(row, lambda_edge, dlambda, nbin, Tstar, 0, 1, &c_planck_series);
 }
 
 int upload_planck_series(hx_context* ctx) {
@@ -102,8 +131,10 @@ int upload_planck_series(hx_context* ctx) {
         PlanckSeriesTable t{};
         for (int n = 1; n < 200; n++) {
             const double dn = n;
-            t.d[n][0] = dn; t.d[n][1] = dn * dn; t.d[n][2] = dn * dn * dn; t.d[n][3] = dn * dn * dn * dn;
-            for (int k = 0; k < 4; k++) t.r[n][k] = 1.0 / t.d[n][k];
+            PlanckSeriesRow& r = t.row[n];
+            r.d1 = dn; r.d2 = dn * dn; r.d3 = dn * dn * dn;
+            r.r1 = 1.0 / r.d1; r.r2 = 1.0 / r.d2; r.r3 = 1.0 / r.d3;
+            r.c4 = 6.0 / (dn * dn * dn * dn);
         }
         return t;
     }();
