@@ -126,6 +126,35 @@ k_planck_star_row(double* __restrict__ row, const double* __restrict__ lambda_ed
     planck_row_entry(row, lambda_edge, dlambda, nbin, Tstar, 0, 1, &c_planck_series);
 }
 
+// The series as the reference writes it (kernels.cu:95-105, :362-416): one thread per (bin, row), 199 terms, two `exp` and
+// eight divisions each -- the form this file had until round 5.  Kept for ONE purpose: tests/test_gpu_stages.py holds
+// k_plancktable to it bit for bit at full size (hx_internal_plancktable_plain; not part of the C-ABI, not used by the product).
+__global__ void __launch_bounds__(256)
+k_plancktable_plain(double* __restrict__ grid, const double* __restrict__ lambda_edge, const double* __restrict__ dlambda,
+                    int nbin, double Tstar, int nrow_T, int step) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (x >= nbin) return;
+    const double T = (r < nrow_T) ? (double)(r * step + 1) : Tstar;
+    double acc = 0.0;
+    if (T > 0.01) {
+        const double kh = HX_KBOLTZMANN / HX_HCONST;
+        const double D = 2.0 * (kh * kh * kh * HX_KBOLTZMANN * (T * T * T * T)) / (HX_CSPEED * HX_CSPEED);
+        double y2 = HX_HCONST * HX_CSPEED / (lambda_edge[x + 1] * HX_KBOLTZMANN * T);   // y_top
+        double y1 = HX_HCONST * HX_CSPEED / (lambda_edge[x] * HX_KBOLTZMANN * T);       // y_bot
+        if (y1 < y2) {
+            const double t = y2;
+            y2 = y1;
+            y1 = t;
+        }
+        for (int n = 1; n < 200; n++) {
+            const double dn = n;
+            acc += D * (exp(-dn * y2) * ((y2 * y2 * y2) / dn + 3.0 * (y2 * y2) / (dn * dn) + 6.0 * y2 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn)) -
+                        exp(-dn * y1) * ((y1 * y1 * y1) / dn + 3.0 * (y1 * y1) / (dn * dn) + 6.0 * y1 / (dn * dn * dn) + 6.0 / (dn * dn * dn * dn)));
+        }
+    }
+    grid[x + (size_t)r * nbin] = acc / dlambda[x];
+}
+
 int upload_planck_series(hx_context* ctx) {
     static const PlanckSeriesTable tab = [] {
         PlanckSeriesTable t{};
@@ -258,6 +287,17 @@ int hx_plancktable(hx_context* ctx, double* planck_grid, const double* lambda_ed
     dim3 grid(hx_cdiv(nwave, PLANCK_BINS_PER_WAVE * PLANCK_WAVES), nrow_T + 1);
     k_plancktable<<<grid, 64 * PLANCK_WAVES, 0, ctx->stream>>>(planck_grid, lambda_edge, deltalambda, nwave, Tstar,
                                                              nrow_T, step);
+    HX_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// internal (not part of the C-ABI): the table by the reference's plain formula, for the bit-for-bit test of hx_plancktable
+int hx_internal_plancktable_plain(hx_context* ctx, double* planck_grid, const double* lambda_edge, const double* deltalambda,
+                                  int nwave, double Tstar, int dim, int step) {
+    HX_REQUIRE(ctx, nwave > 0 && dim >= 10 && step > 0, HX_E_ARG, "bad dimensions");
+    const int nrow_T = 10 * (dim / 10);
+    k_plancktable_plain<<<dim3(hx_cdiv(nwave, 256), nrow_T + 1), 256, 0, ctx->stream>>>(planck_grid, lambda_edge, deltalambda, nwave,
+                                                                                     Tstar, nrow_T, step);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -370,3 +370,37 @@ def test_integration_stub_from_the_docs_runs():
     want[0] = T_lay[0] - 0.5 * (T_lay[1] - T_lay[0])
     want[L] = T_lay[L - 1] + 0.5 * (T_lay[L - 1] - T_lay[L - 2])
     np.testing.assert_allclose(T_int, want, rtol=1e-15)
+
+
+@pytest.mark.parametrize("nbin,dim,step", [(10000, 8000, 2), (386, 8000, 2), (63, 400, 10), (64, 400, 10), (1, 400, 10)])
+def test_planck_table_is_the_plain_series_bit_for_bit(nbin, dim, step):
+    """k_plancktable (round 5: Phi_n once per bin edge and shared between neighbouring lanes, divisions through correctly
+    rounded reciprocals with one fma correction, the series left where no later term can change the sum) against the
+    reference's formula evaluated as it is written -- one thread per entry, 199 terms, two exp and eight divisions each
+    (kernels.cu:95-105, :362-416) -- on this GPU: every entry of the table the SAME BITS, at BASELINE's full size (8001 rows x
+    10 000 bins), on the reference's default grid and on grids that end inside / at / after a wavefront's 63 bins"""
+    import ctypes
+    from helios_amd import _lib
+    from helios_amd import synthetic as syn
+    from helios_amd.device import Context
+    ctx = Context(0)
+    try:
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        plain = raw.hx_internal_plancktable_plain
+        plain.restype = ctypes.c_int
+        P = ctypes.POINTER(ctypes.c_double)
+        plain.argtypes = [ctypes.c_void_p, P, P, P, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int]
+        edge, _, dl = syn.wavelength_grid(nbin)
+        if nbin == 386:            # a grid whose wavelengths DEcrease: the reference swaps the two edges (kernels.cu:399-403)
+            edge, dl = edge[::-1].copy(), np.abs(dl[::-1]).copy()
+        d_edge, d_dl = ctx.to_gpu(edge), ctx.to_gpu(dl)
+        a, b = ctx.zeros((dim + 1) * nbin), ctx.zeros((dim + 1) * nbin)
+        ctx.check(_lib.lib().hx_plancktable(ctx.handle, a.d, d_edge.d, d_dl.d, nbin, 5777.0, dim, step), "hx_plancktable")
+        ctx.check(plain(ctx.handle, b.d, d_edge.d, d_dl.d, nbin, 5777.0, dim, step), "hx_internal_plancktable_plain")
+        got, want = a.get(), b.get()
+        assert np.array_equal(got.view(np.int64), want.view(np.int64)), \
+            "%d of %d entries differ, largest relative difference %.3e" % (
+                int((got != want).sum()), got.size, float(np.nanmax(np.abs(got - want) / np.maximum(np.abs(want), 1e-300))))
+        assert np.isfinite(got).all() and (got[nbin:] > 0).all()          # (row 0 is T = 1 K: zeros at short wavelengths)
+    finally:
+        ctx.close()
