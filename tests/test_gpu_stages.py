@@ -401,6 +401,6 @@ def test_planck_table_is_the_plain_series_bit_for_bit(nbin, dim, step):
         assert np.array_equal(got.view(np.int64), want.view(np.int64)), \
             "%d of %d entries differ, largest relative difference %.3e" % (
                 int((got != want).sum()), got.size, float(np.nanmax(np.abs(got - want) / np.maximum(np.abs(want), 1e-300))))
-        assert np.isfinite(got).all() and (got >= 0).all() and (got[-nbin:] > 0).all()   # (cold rows underflow at short wavelengths)
+        assert np.isfinite(got).all() and (got[-nbin:] > 0).all()     # (the stellar row; cold rows underflow at short wavelengths)
     finally:
         ctx.close()
