@@ -1439,7 +1439,9 @@ static bool graph_wanted(hx_rt* rt) {
     // kappa refresh (computation.py:921-923)
     bool time_stepped = false;   // any column of the batch
     for (const auto& c : rt->cols) time_stepped = time_stepped || c.physical_tstep != 0;
-    return rt->use_graph == 1 && !rt->profiling && !rt->matrix && !(rt->entr_kappa && time_stepped);
+    // (the matrix method's direct solve replays like the sweeps; its per-stage form -- HELIOS_RT_MATRIX=stage -- launches
+    // column by column and stays outside)
+    return rt->use_graph == 1 && !rt->profiling && !(rt->matrix && !rt->matrix_scan) && !(rt->entr_kappa && time_stepped);
 }
 
 static int build_iteration_graph(hx_rt* rt) {

@@ -386,14 +386,17 @@ def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kerne
     assert comp._fused_supported(Q())
 
 
-@pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2)])
+@pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2), ("L50+matrix", 1), ("clouds_g0+matrix", 2)])
 def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, name, ncol, monkeypatch):
     """hx_rt_run replays the nine iterations between two opacity refreshes as ONE hipGraph where launches bound the loop
     (small grids; HELIOS_RT_GRAPH forces it either way): the iteration index comes from the device, so the captured
     kernels carry the same arguments every time.  Same kernels, same order, same arguments: the same bits -- after 47
     iterations in one call (refreshes, four graph replays, a tail of single steps), after a second call that continues
     from there, and for a batch whose columns differ."""
-    c0 = cases.make_case(**FUSED_CONFIGS[name])
+    matrix = name.endswith("+matrix")           # the direct solve of `flux calculation method = matrix` replays like the sweeps
+    c0 = cases.make_case(**dict(FUSED_CONFIGS[name.split("+")[0]], **({"albedo": 0.1} if matrix else {})))
+    if matrix:
+        c0.flux_calc_method = "matrix"
     T = [c0.T_lay * (1.0 + 0.02 * k) for k in range(ncol)] if ncol > 1 else None
     from helios_amd.rt import batch_from_case
 
