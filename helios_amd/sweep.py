@@ -22,9 +22,11 @@ from . import read as read_mod
 from . import write as write_mod
 
 # options that may vary between the columns of one batch (everything else defines the batch itself)
+# (directory_with_fastchem_files: every column reads its own chemistry -- a sweep over metallicity or C/O -- and keeps its own
+# (T, P) mixing-ratio tables on the device, hx_rt_set_column_vmr_table)
 PER_COLUMN_OPTIONS = ("internal_temperature", "f_factor", "stellar_zenith_angle", "surface_albedo", "surface_gravity",
                       "orbital_distance", "radius_planet", "radius_star", "temperature_star",
-                      "radiative_equilibrium_criterion", "name")
+                      "radiative_equilibrium_criterion", "directory_with_fastchem_files", "name")
 
 
 def expand_sweep(spec):

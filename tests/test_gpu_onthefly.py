@@ -546,6 +546,44 @@ def test_sweep_batch_equals_individual_runs(tmp_path):
             k += 1
 
 
+def test_sweep_over_fastchem_directories_equals_individual_runs(tmp_path):
+    """a sweep over chemistry (`-sweep "directory_with_fastchem_files=dirA/,dirB/,dirC/"`: metallicity, C/O): three columns in
+    ONE device batch, each with its own FastChem tables on the device (hx_rt_set_column_vmr_table), end where their own
+    single runs end -- same iteration counts, profiles and spectra -- and differ from each other"""
+    import shutil
+    import sweep
+    wd = str(tmp_path)
+    mk = _host_golden_module()
+    mk.write_species_inputs(wd, nbin=14, ny=20, sorted_k=True)
+    dirs = [os.path.join(wd, "chem") + "/"]
+    for k, seed in enumerate((21, 22)):             # two more chemistries: the same files with other abundances
+        alt = os.path.join(wd, "alt%d" % k)
+        mk.write_species_inputs(alt, seed=seed, nbin=14, ny=20, sorted_k=True)
+        d = os.path.join(wd, "chem%d" % k)
+        shutil.copytree(os.path.join(alt, "chem"), d)
+        dirs.append(d + "/")
+    base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "on-the-fly",
+            "-path_to_species_file", os.path.join(wd, "species.dat"),
+            "-file_with_vertical_mixing_ratios", os.path.join(wd, "vmr.txt"),
+            "-directory_with_opacity_files", os.path.join(wd, "opac") + "/",
+            "-number_of_layers", "18", "-maximum_number_of_iterations", "20000", "-name", "chem",
+            "-radiative_equilibrium_criterion", "1e-4", "-convective_adjustment", "no", "-toa_pressure", "1e0",
+            "-boa_pressure", "1e8"]
+    cols, spectra = sweep.main(["-sweep", "directory_with_fastchem_files=" + ",".join(dirs)] + base +
+                               ["-output_directory", wd + "/batch/"])
+    assert len(cols) == 3
+    for k, d in enumerate(dirs):
+        single = _run_driver(base + ["-directory_with_fastchem_files", d, "-output_directory", wd + "/single/",
+                                     "-name", "s%d" % k], True)
+        assert int(cols[k].iter_value) == int(single.iter_value), k
+        np.testing.assert_allclose(cols[k].T_lay, single.T_lay, rtol=1e-12, err_msg="column %d" % k)
+        np.testing.assert_allclose(spectra[k], single.F_up_band[-14:], rtol=1e-12)
+        for sb, ss in zip(cols[k].species_list, single.species_list):
+            if getattr(sb, "source_for_vmr", "") == "FastChem":
+                np.testing.assert_allclose(sb.vmr_layer, ss.vmr_layer, rtol=1e-12, err_msg="%s column %d" % (sb.name, k))
+    assert np.abs(cols[0].T_lay / cols[1].T_lay - 1.0).max() > 1e-4 and np.abs(spectra[0] / spectra[2] - 1.0).max() > 1e-4
+
+
 def test_sweep_with_the_matrix_method_equals_individual_runs(tmp_path):
     """`flux calculation method = matrix` in a sweep: four columns through one device batch (the solver runs column by
     column inside the loop, the work arrays of the elimination are shared) end where their own single runs end"""
