@@ -152,6 +152,8 @@ struct hx_rt {
     int* iter_dev = nullptr;
     int iter_dev_expected = -1;    // what iter_dev[0] holds as far as the host knows (-1: unknown)
     hipGraphExec_t iter_graph = nullptr;
+    hipGraphExec_t decade_graph = nullptr;   // refresh + ten iterations (hx_rt_run entered at a refresh boundary)
+    bool decade_graph_stale = true;
     bool graph_stale = true;       // arguments may have changed since the capture
     int use_graph = -1;            // -1: decide from the grid size (HELIOS_RT_GRAPH=0|1 overrides), 0 / 1
     std::vector<char> have_albedo; // per column: a surface albedo has been handed over (the matrix method divides by it)

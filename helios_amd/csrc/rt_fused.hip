@@ -545,6 +545,7 @@ int hx_rt_destroy(hx_rt* rt) {
     if (rt->ctx) (void)hipStreamSynchronize(rt->ctx->stream);
     ProfScope::flush(rt);
     if (rt->iter_graph) (void)hipGraphExecDestroy(rt->iter_graph);
+    if (rt->decade_graph) (void)hipGraphExecDestroy(rt->decade_graph);
     for (void* p : rt->allocs) (void)hipFree(p);
     delete rt;
     return 0;
@@ -1444,15 +1445,24 @@ static bool graph_wanted(hx_rt* rt) {
     return rt->use_graph == 1 && !rt->profiling && !(rt->matrix && !rt->matrix_scan) && !(rt->entr_kappa && time_stepped);
 }
 
-static int build_iteration_graph(hx_rt* rt) {
+// `with_refresh`: the whole decade -- the opacity refresh with the iteration that carries it, then the nine refresh-free
+// ones -- as ONE graph (round 5).  The refresh is launches with fixed arguments too (its host decisions -- species tables
+// uploaded, dynamic-LDS limits raised -- are taken by the first, uncaptured refresh); at 300 x 50 its ~19 launches cost the
+// host more than the nine replayed iterations cost the device.
+static int build_iteration_graph(hx_rt* rt, bool with_refresh) {
     hx_context* ctx = rt->ctx;
-    if (rt->iter_graph) {
-        (void)hipGraphExecDestroy(rt->iter_graph);
-        rt->iter_graph = nullptr;
+    hipGraphExec_t& exec = with_refresh ? rt->decade_graph : rt->iter_graph;
+    if (exec) {
+        (void)hipGraphExecDestroy(exec);
+        exec = nullptr;
     }
     HX_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    for (int n = 0; n < GRAPH_ITERATIONS && !rc; n++) rc = rt_step_kernels(rt, 1, 1, false);   // (the index comes from the device)
+    if (with_refresh) {
+        rc = hx_rt_refresh(rt);                               // (k_rt_nodes inside moves the device's iteration counter on)
+        if (!rc) rc = rt_step_kernels(rt, 1, 1, true);        // (the index comes from the device)
+    }
+    for (int n = 0; n < GRAPH_ITERATIONS && !rc; n++) rc = rt_step_kernels(rt, 1, 1, false);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc || e != hipSuccess || !graph) {
@@ -1463,33 +1473,37 @@ static int build_iteration_graph(hx_rt* rt) {
         (void)hipGetLastError();
         return 0;
     }
-    const hipError_t ei = hipGraphInstantiate(&rt->iter_graph, graph, nullptr, nullptr, 0);
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) {
-        rt->iter_graph = nullptr;
+        exec = nullptr;
         rt->use_graph = 0;
         (void)hipGetLastError();
         return 0;
     }
-    rt->graph_stale = false;
+    (with_refresh ? rt->decade_graph_stale : rt->graph_stale) = false;
     return 0;
 }
 
 int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
+    if (rt->graph_stale) rt->decade_graph_stale = true;   // every setter marks graph_stale: both captures hold old arguments
     for (int n = 0; n < nsteps;) {
         const int it = itervalue + n;
-        if (it % 10 == 1 && nsteps - n >= GRAPH_ITERATIONS && rt->refreshed && graph_wanted(rt)) {
-            if (rt->graph_stale || !rt->iter_graph) {
-                int rc = build_iteration_graph(rt);
+        const bool decade = it % 10 == 0 && nsteps - n >= GRAPH_ITERATIONS + 1 && !rt->species_dev_stale;
+        if ((decade || (it % 10 == 1 && nsteps - n >= GRAPH_ITERATIONS)) && rt->refreshed && graph_wanted(rt)) {
+            hipGraphExec_t& exec = decade ? rt->decade_graph : rt->iter_graph;
+            if ((decade ? rt->decade_graph_stale : rt->graph_stale) || !exec) {
+                int rc = build_iteration_graph(rt, decade);
                 if (rc) return rc;
             }
-            if (rt->iter_graph) {
+            if (exec) {
                 int rc = sync_iteration_counter(rt, it);
                 if (rc) return rc;
-                HX_HIP(rt->ctx, hipGraphLaunch(rt->iter_graph, rt->ctx->stream));
-                rt->iter_dev_expected = it + GRAPH_ITERATIONS;
-                n += GRAPH_ITERATIONS;
+                HX_HIP(rt->ctx, hipGraphLaunch(exec, rt->ctx->stream));
+                const int done = GRAPH_ITERATIONS + (decade ? 1 : 0);
+                rt->iter_dev_expected = it + done;
+                n += done;
                 continue;
             }
         }

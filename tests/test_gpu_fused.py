@@ -386,24 +386,34 @@ def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kerne
     assert comp._fused_supported(Q())
 
 
-@pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2), ("L50+matrix", 1), ("clouds_g0+matrix", 2)])
+@pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2), ("L50+matrix", 1), ("clouds_g0+matrix", 2),
+                                       ("dirbeam+species", 2)])
 def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, name, ncol, monkeypatch):
     """hx_rt_run replays the nine iterations between two opacity refreshes as ONE hipGraph where launches bound the loop
-    (small grids; HELIOS_RT_GRAPH forces it either way): the iteration index comes from the device, so the captured
-    kernels carry the same arguments every time.  Same kernels, same order, same arguments: the same bits -- after 47
+    (small grids; HELIOS_RT_GRAPH forces it either way) -- and, entered at a refresh boundary, the whole decade, refresh
+    included (round 5): the iteration index comes from the device, so the captured kernels carry the same arguments every
+    time.  Same kernels, same order, same arguments: the same bits -- after 47
     iterations in one call (refreshes, four graph replays, a tail of single steps), after a second call that continues
     from there, and for a batch whose columns differ."""
     matrix = name.endswith("+matrix")           # the direct solve of `flux calculation method = matrix` replays like the sweeps
+    species = name.endswith("+species")         # ... and so does a refresh that mixes absorbers on the fly (the decade graph)
     c0 = cases.make_case(**dict(FUSED_CONFIGS[name.split("+")[0]], **({"albedo": 0.1} if matrix else {})))
     if matrix:
         c0.flux_calc_method = "matrix"
+    if species:
+        c0 = cases.add_species(c0, nspecies=4)
     T = [c0.T_lay * (1.0 + 0.02 * k) for k in range(ncol)] if ncol > 1 else None
     from helios_amd.rt import batch_from_case
 
     def run(graph):
         monkeypatch.setenv("HELIOS_RT_GRAPH", graph)
-        rt = batch_from_case(ctx, c0, ncol=ncol)
+        rt = batch_from_case(ctx, c0, ncol=ncol, nspecies=len(c0.species) if species else 0)
         try:
+            if species:
+                for k, sp in enumerate(c0.species):
+                    rt.set_species(k, sp["pretab"], sp["scat"], sp["weight"], is_h2o=2 if sp["is_h2o"] else 0,
+                                   is_cia=1 if sp["is_cia"] else 0, in_mu=0 if sp["is_cia"] else 1)
+                rt.set_column_vmr(-1, *cases.species_vmr_arrays(c0))
             if T is not None:
                 for k, Tk in enumerate(T):
                     rt.set_temperatures(k, Tk)
@@ -443,8 +453,13 @@ def test_back_and_forth_launch_order_with_cached_state_is_the_same_run(ctx, name
         monkeypatch.setenv("HELIOS_RT_SERPENTINE", serpentine)
         monkeypatch.setenv("HELIOS_RT_STATE_CACHE_MB", mb if serpentine == "1" else "0")
         monkeypatch.setenv("HELIOS_RT_GRAPH", graph)
-        rt = batch_from_case(ctx, c0, ncol=ncol)
+        rt = batch_from_case(ctx, c0, ncol=ncol, nspecies=len(c0.species) if species else 0)
         try:
+            if species:
+                for k, sp in enumerate(c0.species):
+                    rt.set_species(k, sp["pretab"], sp["scat"], sp["weight"], is_h2o=2 if sp["is_h2o"] else 0,
+                                   is_cia=1 if sp["is_cia"] else 0, in_mu=0 if sp["is_cia"] else 1)
+                rt.set_column_vmr(-1, *cases.species_vmr_arrays(c0))
             if T is not None:
                 for k, Tk in enumerate(T):
                     rt.set_temperatures(k, Tk)
