@@ -1490,7 +1490,7 @@ int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
     if (rt->graph_stale) rt->decade_graph_stale = true;   // every setter marks graph_stale: both captures hold old arguments
     for (int n = 0; n < nsteps;) {
         const int it = itervalue + n;
-        const bool decade = it % 10 == 0 && nsteps - n >= GRAPH_ITERATIONS + 1 && !rt->species_dev_stale;
+        const bool decade = it % 10 == 0 && nsteps - n >= GRAPH_ITERATIONS + 1 && (rt->d.nspecies == 0 || !rt->species_dev_stale);
         if ((decade || (it % 10 == 1 && nsteps - n >= GRAPH_ITERATIONS)) && rt->refreshed && graph_wanted(rt)) {
             hipGraphExec_t& exec = decade ? rt->decade_graph : rt->iter_graph;
             if ((decade ? rt->decade_graph_stale : rt->graph_stale) || !exec) {

@@ -453,13 +453,8 @@ def test_back_and_forth_launch_order_with_cached_state_is_the_same_run(ctx, name
         monkeypatch.setenv("HELIOS_RT_SERPENTINE", serpentine)
         monkeypatch.setenv("HELIOS_RT_STATE_CACHE_MB", mb if serpentine == "1" else "0")
         monkeypatch.setenv("HELIOS_RT_GRAPH", graph)
-        rt = batch_from_case(ctx, c0, ncol=ncol, nspecies=len(c0.species) if species else 0)
+        rt = batch_from_case(ctx, c0, ncol=ncol)
         try:
-            if species:
-                for k, sp in enumerate(c0.species):
-                    rt.set_species(k, sp["pretab"], sp["scat"], sp["weight"], is_h2o=2 if sp["is_h2o"] else 0,
-                                   is_cia=1 if sp["is_cia"] else 0, in_mu=0 if sp["is_cia"] else 1)
-                rt.set_column_vmr(-1, *cases.species_vmr_arrays(c0))
             if T is not None:
                 for k, Tk in enumerate(T):
                     rt.set_temperatures(k, Tk)
