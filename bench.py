@@ -620,6 +620,7 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
 
     total_cols = ncol * world
     flux_policy = rt.get("flux_launch_policy")
+    graphs = rt.get("graph_replays")
     out = {
         "value": steps / dt * c.nbin * c.nlayer * total_cols, "unit": "bin*layer*iterations/s",
         "steps": steps, "warmup": warmup, "device_warmup_iterations": device_warmup, "ms_per_step": dt / steps * 1e3,
@@ -630,7 +631,10 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
                    "loop": phase, "parallelism": "columns sharded, %d per GPU" % ncol,
                    # what the batch chose for k_rt_flux: launches walking the grid back and forth,
                    # MiB of up-flux state the tail of a launch leaves in the Infinity Cache
-                   "flux_launch_policy": {"back_and_forth": bool(flux_policy[0]), "state_cached_mib": float(flux_policy[1])}},
+                   "flux_launch_policy": {"back_and_forth": bool(flux_policy[0]), "state_cached_mib": float(flux_policy[1])},
+                   # small grids: iterations replayed as hipGraphs (runs of nine refresh-free iterations, whole decades with
+                   # their refresh), counted over the whole measurement
+                   "graph_replays": {"nine_iterations": int(graphs[0]), "decades": int(graphs[1]), "in_use": bool(graphs[2])}},
         "iterations_per_s_per_column": steps / dt,
         "setup_s": setup_s, "setup_s_per_rank": ranks.gather_scalars(setup_s),
         "stream_event_ms_per_step": ev_ms / steps,

@@ -154,6 +154,7 @@ struct hx_rt {
     hipGraphExec_t iter_graph = nullptr;
     hipGraphExec_t decade_graph = nullptr;   // refresh + ten iterations (hx_rt_run entered at a refresh boundary)
     bool decade_graph_stale = true;
+    long long iter_graph_replays = 0, decade_graph_replays = 0;
     bool graph_stale = true;       // arguments may have changed since the capture
     int use_graph = -1;            // -1: decide from the grid size (HELIOS_RT_GRAPH=0|1 overrides), 0 / 1
     std::vector<char> have_albedo; // per column: a surface albedo has been handed over (the matrix method divides by it)

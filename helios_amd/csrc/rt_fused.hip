@@ -1501,6 +1501,7 @@ int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
                 int rc = sync_iteration_counter(rt, it);
                 if (rc) return rc;
                 HX_HIP(rt->ctx, hipGraphLaunch(exec, rt->ctx->stream));
+                (decade ? rt->decade_graph_replays : rt->iter_graph_replays)++;
                 const int done = GRAPH_ITERATIONS + (decade ? 1 : 0);
                 rt->iter_dev_expected = it + done;
                 n += done;
@@ -1647,6 +1648,12 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
     if (n == "flux_launch_policy") {   // host-side: {launch order back and forth (0/1), MiB of up-flux state kept cached}
         HX_REQUIRE(rt->ctx, out_bytes == 2 * sizeof(double), HX_E_ARG, "flux_launch_policy is two doubles");
         const double v[2] = {rt->serpentine ? 1.0 : 0.0, rt->serpentine ? rt->state_cache_mb : 0.0};
+        memcpy(out, v, sizeof(v));
+        return 0;
+    }
+    if (n == "graph_replays") {   // host-side: {replays of the nine refresh-free iterations, replays of a whole decade, graphs in use (0/1)}
+        HX_REQUIRE(rt->ctx, out_bytes == 3 * sizeof(double), HX_E_ARG, "graph_replays is three doubles");
+        const double v[3] = {(double)rt->iter_graph_replays, (double)rt->decade_graph_replays, rt->use_graph == 1 ? 1.0 : 0.0};
         memcpy(out, v, sizeof(v));
         return 0;
     }

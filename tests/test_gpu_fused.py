@@ -425,6 +425,9 @@ def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, na
             rt.run(71, 30)
             second = [{k: rt.get(k, col) for k in ("T_lay", "F_net", "F_up_band", "delta_t_prefactor", "abort", "iters_done")}
                       for col in range(ncol)]
+            nine, decades, on = rt.get("graph_replays")
+            # the replays really happened: 101 iterations = the first refresh launched, then whole decades and runs of nine
+            assert (on == 1 and decades >= 5 and nine >= 2) if graph == "1" else (nine == 0 and decades == 0)
             return first, second
         finally:
             rt.close()
