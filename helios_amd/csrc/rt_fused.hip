@@ -1423,17 +1423,18 @@ int hx_rt_conv_run(hx_rt* rt, int itervalue, int nsteps) {
     return 0;
 }
 
-// Nine refresh-free iterations as one hipGraph.  Where an iteration is a few microseconds of GPU work (the reference's
-// default problem is 386 bins x 105 layers; BASELINE config 1 is 300 x 50) the loop is bound by the host's four launches
-// per iteration, not by the device; with the iteration index on the device the kernels' arguments never change, so the
-// 36 launches between two opacity refreshes are captured once and replayed with one call.
+// Iterations as hipGraphs.  With the iteration index on the device the kernels' arguments never change, so the launches
+// between two opacity refreshes are captured once and replayed with one call -- nine refresh-free iterations (entered
+// mid-decade), or the whole decade with its refresh (entered at a refresh boundary, round 5).  Where an iteration is a few
+// microseconds of GPU work (the reference's default problem is 386 bins x 105 layers; BASELINE config 1 is 300 x 50) the
+// host's four launches per iteration were what bounded the loop; on large grids the device time is the same either way
+// (config 2: 0.386 ms per iteration with and without, same-box A/B) and the host does one call per ten iterations instead of
+// forty-odd launches -- which is what eight ranks sharing a few host cores need.  On for every grid since round 5.
 constexpr int GRAPH_ITERATIONS = 9;
 
 static bool graph_wanted(hx_rt* rt) {
     if (rt->use_graph < 0) {
-        // small grids only: from ~10^7 spectral half-layers on, an iteration keeps the device busy for longer than the
-        // host needs to queue the next one
-        rt->use_graph = (double)rt->X * rt->Y * rt->H * rt->C <= 6.0e6 ? 1 : 0;
+        rt->use_graph = 1;
         if (const char* e = getenv("HELIOS_RT_GRAPH")) rt->use_graph = atoi(e) != 0 ? 1 : 0;   // tuning knob
     }
     // not while the event profiler brackets every launch, not with the per-iteration host decisions of the time-stepped

@@ -171,6 +171,10 @@ def run_reference(lib, c0, species_tabs_dev, vl, vi, grid, max_iterations, conve
             if isinstance(v, np.ndarray) and v.nbytes > (1 << 20) and k not in ("F_up_band", "F_down_band", "F_dir_band"):
                 d[k] = lib.buf(v)
                 held.append(d[k])
+    if c.get("flux_calc_method", "iteration") == "matrix":
+        # the work arrays of the reference's elimination (alpha ... d_prime, quantities.py:652-665) stay on the device too
+        s.matrix_work = {k: lib.buf(v) for k, v in cases.matrix_scratch(c).items()}
+        held += list(s.matrix_work.values())
     refresh = cases.refresh_premixed
     if species:
         spec_l, spec_i = lib.buf(np.zeros(Y * X * I)), lib.buf(np.zeros(Y * X * I))
