@@ -83,11 +83,13 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
             if (force_k && k != force_k) continue;
             if (pass == 0 && flux_variant_spills(rows, k)) continue;
             int cost = k * rows * (k >= 16 ? 100 : 125);
-            // With the direct beam a tile has two more planes.  All seven register images (alpha, beta, u', v', U, dd, du)
-            // are in flight at once only while rows <= 10; beyond that the beam planes are a second, dependent request
-            // per tile (256 VGPRs).  Same-box A/B, k_rt_flux per launch: 10 000 x 100 with beam 0.617 ms (k = 16, 13 rows)
-            // -> 0.493 ms (k = 32, 7 rows); 30 000 x 200 with beam and I2S 3.92 ms (k = 32, 13 rows) -> 3.23 ms (k = 64, 7).
-            if (dir_beam && rows > 10) cost += cost * 3 / 10;
+            // (Until round 4 a tiling of more than ten rows paid a 30 % penalty here when the direct beam adds its two planes: the
+            // beam planes were then a second, dependent request per tile.  Since their rows are requested in groups that are
+            // in flight together -- k_rt_flux, HX_BEAM_GROUP -- the tiling with the fewest padded slots wins with the beam as
+            // without: same-box A/B of round 5, k_rt_flux per launch: 10 000 x 100 with beam 0.465 ms (k = 32, 7 rows) ->
+            // 0.434 ms (k = 16, 13 rows); 30 000 x 200 with beam and I2S 3.12-3.40 ms (k = 64, 7 rows) against 3.08-3.13 ms
+            // (k = 32, 13 rows), its coefficient kernel 6.4 -> 5.85 ms.  profiles/r05_flux_tilings_beam.txt.)
+            (void)dir_beam;
             if (cost < best_cost) {
                 best_cost = cost;
                 best_k = k;
