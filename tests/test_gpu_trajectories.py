@@ -1,6 +1,7 @@
 """Whole runs at size against the reference's kernels on the same GPU, with the trajectory recorded on both sides
-(tests/loop_to_convergence_on_gpu.py): BASELINE config 1 as named (300 x 50, no scattering) and config 2's physics at
-1000 bins x 50 layers, each to radiative equilibrium.  Where a layer has no physical flux divergence (the deep layers of
+(tests/loop_to_convergence_on_gpu.py): BASELINE config 1 as named (300 x 50, no scattering), config 2's physics at
+1000 bins x 50 layers, and the same with `flux calculation method = matrix` (the library's three scans against the
+reference's fband_matrix_noniso; round 5), each to radiative equilibrium.  Where a layer has no physical flux divergence (the deep layers of
 the isothermal start profile, every layer near the fixed point) F_net[i] - F_net[i+1] is the rounding residue of the
 wavelength totals, which differs between two orders of the same additions (the reference's atomics, the library's fixed
 tree), and the pseudo-time step amplifies it (dT ~ |dF|^0.1, kernels.cu:2694-2698): discrete decisions of two correct
@@ -20,8 +21,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-@pytest.mark.parametrize("argv", [["--workload", "c1"], ["--workload", "c2", "--nbin", "1000", "--nlayer", "50"]],
-                         ids=["config1_300x50", "config2_physics_1000x50"])
+@pytest.mark.parametrize("argv", [["--workload", "c1"], ["--workload", "c2", "--nbin", "1000", "--nlayer", "50"],
+                                  ["--workload", "c2matrix", "--nbin", "1000", "--nlayer", "50"]],
+                         ids=["config1_300x50", "config2_physics_1000x50", "matrix_method_1000x50"])
 def test_whole_run_trajectory_vs_the_reference_on_the_gpu(argv):
     import oracle
     if oracle.refgpu is None:
