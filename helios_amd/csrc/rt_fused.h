@@ -141,9 +141,6 @@ struct hx_rt {
     // work arrays in HBM) inside the loop instead, as until round 4
     bool matrix_scan = false;
     bool matrix_keep_state = false;   // the direct solve stores its up-fluxes too (debug = 1: the negative-flux counts read them)
-    bool inline_nodes = false;        // measurement builds (make INLINE_NODES=1, HELIOS_RT_INLINE_NODES=1): see rt_kernels.h
-    void* inline_nodes_dev = nullptr;
-    bool inline_now = false;
     int* zero_flags = nullptr;        // [C] zeros: the `done` flags of a launch that must cover every column
     // The iteration index lives on the device (iter_dev[0]: index of the next iteration; k_rt_nodes, the first kernel of an
     // iteration, moves it to iter_dev[1] and increments): the kernels of an iteration then have the SAME arguments every

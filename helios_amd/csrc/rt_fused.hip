@@ -239,9 +239,6 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.Kconst = a.Kconst;
     f.trigger = a.trigger;
     f.keep_up = rt->matrix_keep_state ? 1 : 0;
-#ifdef HX_INLINE_NODES
-    f.inl = rt->inline_now ? (const InlineNodes*)rt->inline_nodes_dev : nullptr;
-#endif
     f.colpar = a.colpar;
     f.Bn = a.Bn; f.coef = a.coef; f.U0_in = a.U0; f.boaK = a.boaK; f.Fdir0 = a.Fdir0;
     f.surf_albedo = a.surf_albedo; f.gauss_w = a.gauss_w;
@@ -425,9 +422,6 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->matrix_scan = rt->matrix;
     if (const char* e = getenv("HELIOS_RT_MATRIX")) rt->matrix_scan = rt->matrix && std::string(e) != "stage";
     rt->matrix_keep_state = rt->matrix_scan && flags->debug == 1;   // count_negative_fluxes reads the up-flux tiles
-#ifdef HX_INLINE_NODES
-    if (const char* e = getenv("HELIOS_RT_INLINE_NODES")) rt->inline_nodes = atoi(e) != 0;
-#endif
     if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g, rt->matrix_scan ? 1 : 0))
         return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512 (1024 isothermal layers); use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
@@ -1134,18 +1128,6 @@ static int spectral_fluxes(hx_rt* rt, const KArgs& a) {
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
     hx_context* ctx = rt->ctx;
     KArgs a = make_args(rt);
-#ifdef HX_INLINE_NODES
-    if (rt->inline_nodes && !rt->inline_nodes_dev) {
-        InlineNodes h = {rt->T_lay, rt->planck_grid, rt->Bstar, rt->iter_dev, rt->d.plancktable_dim, rt->d.plancktable_step};
-        InlineNodes* d = nullptr;
-        RT_ALLOC(d, 1);
-        int rc = h2d(rt, d, &h, sizeof(h));
-        if (rc) return rc;
-        rt->inline_nodes_dev = d;
-    }
-    rt->inline_now = rt->inline_nodes && !nodes_done;   // (a refresh has run k_rt_nodes itself)
-    if (rt->inline_now) nodes_done = true;               // evaluated in k_rt_flux's prologue
-#endif
     if (!nodes_done) {
         ProfScope ps(rt, "rt_nodes");
         dim3 grid(hx_cdiv(rt->X, 32), hx_cdiv(rt->H + 3, 32), rt->C);
@@ -1356,18 +1338,6 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
     }
     KArgs a = make_args(rt);
     rt->iter_dev_expected = -1;   // (the convection loop passes its own iteration index; k_rt_nodes still counts)
-#ifdef HX_INLINE_NODES
-    if (rt->inline_nodes && !rt->inline_nodes_dev) {
-        InlineNodes h = {rt->T_lay, rt->planck_grid, rt->Bstar, rt->iter_dev, rt->d.plancktable_dim, rt->d.plancktable_step};
-        InlineNodes* d = nullptr;
-        RT_ALLOC(d, 1);
-        int rc = h2d(rt, d, &h, sizeof(h));
-        if (rc) return rc;
-        rt->inline_nodes_dev = d;
-    }
-    rt->inline_now = rt->inline_nodes && !nodes_done;   // (a refresh has run k_rt_nodes itself)
-    if (rt->inline_now) nodes_done = true;               // evaluated in k_rt_flux's prologue
-#endif
     if (!nodes_done) {
         ProfScope ps(rt, "rt_nodes");
         dim3 grid(hx_cdiv(rt->X, 32), hx_cdiv(rt->H + 3, 32), rt->C);

@@ -51,15 +51,6 @@ struct KArgs {
     int* iter_dev;             // [0] index of the next iteration, [1] index of the iteration under way (k_rt_nodes)
 };
 
-#ifdef HX_INLINE_NODES
-// what k_rt_flux needs to evaluate the node Planck values itself, behind ONE pointer (the argument block stays lean)
-struct InlineNodes {
-    const double *T_lay, *planck_grid, *Bstar;
-    int* iter_dev;
-    int dim, step;
-};
-#endif
-
 // the subset k_rt_flux needs (a leaner argument block keeps its SGPR pressure -- and with it the VGPR
 // count, which sits at the 256-register / 2-waves-per-SIMD edge -- down)
 struct FluxArgs {
@@ -70,9 +61,6 @@ struct FluxArgs {
     int reverse;           // walk the grid from its far end (see launch_flux)
     int cache_state_from;  // dispatch index from which the state stores stay cached
     const int* trigger;    // matrix method: scat_trigger per spectral point
-#ifdef HX_INLINE_NODES     // measurement build (make INLINE_NODES=1): k_rt_nodes' work in this kernel's prologue
-    const struct InlineNodes* inl;
-#endif
     double Kconst;
     const hx_rt_column* colpar;
     const double *Bn, *coef, *U0_in, *boaK, *Fdir0, *surf_albedo, *gauss_w;
@@ -819,36 +807,6 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
     const size_t nc = (size_t)a.Y * a.X;
     const int k = K ? K : a.k;
 
-#ifdef HX_INLINE_NODES
-    if (a.inl != nullptr) {
-        // measurement build: the work of k_rt_nodes for this workgroup's bins -- two table rows per node, straight from the
-        // Planck table (the rows of neighbouring bins share sectors: L2 hits) -- and the iteration counter's move
-        const InlineNodes ni = *a.inl;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-            const int cur = ni.iter_dev[0];
-            ni.iter_dev[1] = cur;
-            ni.iter_dev[0] = cur + 1;
-        }
-        const double* T = ni.T_lay + (size_t)col * (a.L + 1);
-        for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
-            const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
-            double v = 0.0;
-            if (x < a.X) {
-                if (n == a.H + 1) {
-                    v = ni.Bstar[(size_t)col * a.X + x];
-                } else {
-                    double Tn;
-                    if (n == a.H + 2) Tn = T[a.L];
-                    else if (a.iso) Tn = T[min(n, a.L - 1)];
-                    else if (n & 1) Tn = T[(n - 1) >> 1];
-                    else Tn = interface_T(T, n >> 1, a.L);
-                    v = planck_lookup(ni.planck_grid, Tn, x, a.X, ni.dim, ni.step);
-                }
-            }
-            sB[t] = v;
-        }
-    } else
-#endif
     for (int t = threadIdx.x; t < a.nxb * NN; t += blockDim.x) {
         const int xl = t / NN, n = t - xl * NN, x = bx * a.nxb + xl;
         sB[t] = x < a.X ? a.Bn[((size_t)col * a.X + x) * NN + n] : 0.0;
