@@ -728,6 +728,18 @@ __global__ void __launch_bounds__(256) k_rt_dtau_halves(KArgs a) {
 // k_rt_flux<ROWS, K, true>: local product of a lane's rows, prefix product over the k lanes of the spectral point (DPP), the
 // lane's rows again from its true start value -- on the three coefficient planes the sweeps read, with nothing kept between
 // iterations (no flux state, no work arrays): 1.0 GB per launch at config 2 where the reference-shaped solver moved 9.
+// 1 / x for the direct solve's thirteen dependent reciprocals per lane: the hardware's estimate and two Newton steps (the last
+// bit is not guaranteed -- the solve is held to 1e-9, tests/matrix_referee.py -- at half the instructions of the IEEE division)
+#ifndef HX_MATRIX_RCP
+#define HX_MATRIX_RCP(x) newton_rcp(x)
+#endif
+__device__ __forceinline__ double newton_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 struct Moebius {
     double p11, p12, p21, p22;   // rho -> (p11 rho + p12) / (p21 rho + p22); only the ratios matter
 };
@@ -926,7 +938,7 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             // and rho at the row's top node (kept where the sweeps keep their up-flux)
 #pragma unroll
             for (int r = 0; r < ROWS; r++) {
-                const double inv = 1.0 / (1.0 - be[r] * rho), aa = al[r] * inv;
+                const double inv = HX_MATRIX_RCP(1.0 - be[r] * rho), aa = al[r] * inv;
                 su[r] = fma(aa * rho, sd[r], su[r]);
                 rho = fma(aa * al[r], rho, be[r]);
                 Uo[r] = rho;
