@@ -127,3 +127,26 @@ def test_work_list_gloo_world2(ncol, chunk):
     want = np.array([[c * 100.0 + k for k in range(5)] for c in range(ncol)])
     for rank in res:
         np.testing.assert_array_equal(res[rank][1], want)
+
+
+def test_sweep_batches_are_keyed_on_the_chemistry():
+    """columns of one device batch share the species list and the SOURCE of every species' mixing ratio (the device keeps one
+    (T, P) table per FastChem species and column: which species those are must agree); the FastChem directory itself may vary
+    from column to column (`-sweep "directory_with_fastchem_files=..."`)"""
+    from helios_amd.sweep import _batch_signature, expand_sweep
+
+    class Sp(object):
+        def __init__(self, name, source):
+            self.name, self.source_for_vmr = name, source
+
+    class Q(object):
+        nbin, ny, nlayer, scat, dir_beam, clouds, scat_corr, smooth, convection = 30, 20, 10, 1, 0, 0, 0, 0, 0
+        opacity_mixing, g_0, epsi, planet_type, iso, singlewalk, flux_calc_method = "on-the-fly", 0.0, 0.5, "gas", 0, 0, "iteration"
+
+    a, b, c = Q(), Q(), Q()
+    a.species_list = [Sp("H2O", "FastChem"), Sp("CO2", "file")]
+    b.species_list = [Sp("H2O", "FastChem"), Sp("CO2", "file")]
+    c.species_list = [Sp("H2O", "1e-3"), Sp("CO2", "file")]
+    assert _batch_signature(a) == _batch_signature(b) != _batch_signature(c)
+    cols = expand_sweep("directory_with_fastchem_files=chem/m0/,chem/m1/;internal_temperature=100,300")
+    assert len(cols) == 4 and cols[1] == {"directory_with_fastchem_files": "chem/m0/", "internal_temperature": "300"}
