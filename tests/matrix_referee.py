@@ -145,13 +145,22 @@ def exact_fluxes(c, o):
     return out
 
 
-def compare_first_solve(fh, f, o, c0, rtol):
+def compare_first_solve(fh, f, o, c0, rtol, rtol_T=None):
     """the comparison of tests/fused_helpers.py after ONE iteration, with the four spectral-flux arrays held to the
     extended-precision solution of the reference's system instead of to the reference's double-precision one -- and the
     reference's own distance from it put on record: its up-fluxes sit on it (1e-9), its down-fluxes within 1e-5 / 1e-10 of the
     largest flux (they carry the noise described above; 2 ... 25 times today's tolerance was observed)"""
     ex = exact_fluxes(c0, o)
-    fh.compare(f, dict(o, **ex), c0, rtol=rtol)
+    if rtol_T is None:
+        fh.compare(f, dict(o, **ex), c0, rtol=rtol)
+    else:
+        # deep columns: the temperatures after the step are compared on their own.  The step turns the flux divergence of a
+        # layer into dT ~ |dF|^0.1 (kernels.cu:2694-2698); where the divergence is the rounding residue of the totals -- deep
+        # layers of the start profile -- the reference's residue carries the noise of its down-fluxes (1e-13 of the largest
+        # net flux against the library's 1e-15, profiles/r05_trajectory_c2matrix.json) and its temperatures move by 1e-9 ... 1e-8
+        tkeys = ("T_lay", "T_int", "planckband_lay", "planckband_int", "delta_t_prefactor", "abort")
+        fh.compare(f, dict(o, **ex), c0, rtol=rtol, keys=[k for k in fh.FUSED_KEYS if k not in tkeys])
+        fh.compare(f, dict(o, **ex), c0, rtol=rtol_T, keys=[k for k in tkeys if k in fh.FUSED_KEYS])
     scale = max(np.abs(o["F_down_wg"]).max(), np.abs(o["F_dir_wg"]).max(), np.abs(o["F_up_wg"]).max())
     nwg = c0.ny * c0.nbin * c0.nlayer
     for k in fh.keys_for(c0, ["F_up_wg", "Fc_up_wg", "F_down_wg", "Fc_down_wg"]):

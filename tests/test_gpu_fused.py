@@ -254,7 +254,7 @@ MATRIX_CONFIGS = {
     # runtime-k scans of short columns (k = 8), one Gauss point per bin, the reference's default layer count
     "L200_beam": dict(nbin=7, nlayer=200, dir_beam=1, albedo=0.2),
     "L400_clouds": dict(nbin=5, nlayer=400, clouds=1, g_0=0.1, albedo=0.1),
-    "L3": dict(nbin=10, nlayer=3, albedo=0.3),
+    "L4": dict(nbin=10, nlayer=4, albedo=0.3),
     "ny1": dict(ny=1, nbin=17, albedo=0.1),
     "L105_i2s": dict(nbin=12, nlayer=105, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),
 }
@@ -280,7 +280,7 @@ def test_fused_matrix_method_vs_oracle(ctx, port, name):
         nscat = int(o["scat_trigger"].sum())      # both branches of the solver: "default" mixes them
         assert nscat == 0 if name == "noscat" else nscat > 0 and (name != "default" or nscat < o["scat_trigger"].size)
         if n_iter == 1:
-            matrix_referee.compare_first_solve(fh, f, o, c0, rtol)
+            matrix_referee.compare_first_solve(fh, f, o, c0, rtol, rtol_T=1e-7 if name in ("L200_beam", "L400_clouds") else None)
         else:
             fh.compare(f, o, c0, rtol=rtol)
 
