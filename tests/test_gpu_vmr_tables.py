@@ -160,7 +160,8 @@ def test_a_sweep_of_columns_with_tabulated_chemistry_needs_no_host_step(ctx, loo
     assert np.abs(got[0]["vmr_lay"] - got[7]["vmr_lay"]).max() > 1e-6
 
 
-def test_columns_of_one_batch_keep_their_own_chemistry_tables(ctx):
+@pytest.mark.parametrize("loop", ["radiation", "convection"])
+def test_columns_of_one_batch_keep_their_own_chemistry_tables(ctx, loop):
     """a sweep over FastChem directories (metallicity, C/O): every column of a batch comes with its OWN (T, P) mixing-ratio
     tables (hx_rt_set_column_vmr_table).  Three columns with the same start profile and different tables in one batch give,
     column by column, what each gives alone with its table -- and not what column 0's table gives."""
@@ -183,8 +184,18 @@ def test_columns_of_one_batch_keep_their_own_chemistry_tables(ctx):
             rt.set_species(k, sp["pretab"], sp["scat"], sp["weight"], is_h2o=2 if sp["is_h2o"] else 0,
                            is_cia=1 if sp["is_cia"] else 0, in_mu=0 if sp["is_cia"] else 1)
         rt.set_column_vmr(-1, np.zeros((S, c.nlayer)), np.zeros((S, c.nlayer + 1)))
+        if loop == "convection":    # (k_rt_mmm_from_vmr reads the column's table ahead of the adjustment, computation.py:1030-1036)
+            from helios_amd import phys_const as pc
+            L, kap = c.nlayer, 2.0 / 7.0
+            for name, v in (("kappa_lay", np.full(L, kap)), ("kappa_int", np.full(L + 1, kap)),
+                            ("c_p_lay", np.full(L, pc.R_UNIV / kap)), ("conv_layer", np.zeros(L + 1, np.int32)),
+                            ("conv_unstable", np.zeros(L + 1, np.int32)), ("dampara", np.array([-1.0]))):
+                rt.set_state(-1, name, v)
         rt.build_planck_table(1)
         return rt
+
+    def run(rt):
+        (rt.run if loop == "radiation" else rt.conv_run)(0, n_iter)
 
     keys = ("T_lay", "F_net", "F_up_band", "meanmolmass_lay", "vmr_lay", "vmr_int")
     a = make(ncol)
@@ -192,7 +203,7 @@ def test_columns_of_one_batch_keep_their_own_chemistry_tables(ctx):
         for col in range(ncol):
             for k in range(S):
                 a.set_column_vmr_table(col, k, tabs[col][k].reshape(-1))
-        a.run(0, n_iter)
+        run(a)
         got = [{k: a.get(k, col) for k in keys} for col in range(ncol)]
     finally:
         a.close()
@@ -201,7 +212,7 @@ def test_columns_of_one_batch_keep_their_own_chemistry_tables(ctx):
         try:
             for k in range(S):
                 b.set_species_vmr_table(k, tabs[col][k].reshape(-1))
-            b.run(0, n_iter)
+            run(b)
             for k in keys:
                 np.testing.assert_array_equal(got[col][k], b.get(k, 0), err_msg="%s column %d" % (k, col))
         finally:
