@@ -18,10 +18,16 @@ the N ranks itself (a child `python -m torch.distributed.run ...`, before this p
 
 The same run also measures, live, into `secondary`: at N = 1 config 3 (20 species mixed on the fly), config 4 (one GPU's
 share of the 512-column sweep: 64 on-the-fly columns in one batch -- the same shape at every N) and config 5 (30 000 x 200,
-20 species on the fly, two cloud decks, beam, albedo, I2S) from the radiation loop and from the convection loop; at N > 1
-config 4 alone.  Synthetic k-tables are formed on the device from their two factors (hx_rt_set_*_separable): a rank's
-set-up (`setup_s`) no longer depends on the host's core count.  `steady_state_200` is the headline workload over 200
-iterations from iteration 0 (20 refreshes), SURVEY.md 8(d)'s definition of the metric.
+20 species on the fly, two cloud decks, beam, albedo, I2S); at N > 1 config 4 alone (`--secondary all` adds config 5 from
+the convection loop and the default-grid batches).  Synthetic k-tables are formed on the device from their two factors
+(hx_rt_set_*_separable): a rank's set-up (`setup_s`) does not depend on the host's core count.  `steady_state_200` is the
+headline workload over 200 iterations from iteration 0 (20 refreshes), SURVEY.md 8(d)'s definition of the metric.
+
+OUTPUT.  Rank 0 prints ONE compact JSON line (compact_line(): < 4 KB at every N -- the contract's fields, `config`,
+`roofline`, `cpu_baseline`, `steady_state_200`, `process_group`, and per secondary workload value / ms_per_step / roofline
+fraction / kernel) as the LAST thing on stdout.  Everything else the run measured (per-kernel times, per-column spectrum
+checksums, byte models, the thread probe of the CPU baseline, notes) goes to the side file `--detail` names (default
+bench_detail.json next to this script), never to stdout.
 """
 import argparse
 import json
@@ -257,17 +263,17 @@ def native_oracle():
         return oracle.port, "-O2 (prebuilt)"
 
 
-def cpu_baseline(w, seed):
+def cpu_baseline(w, seed, budget_s=20.0):
     """the CPU oracle (oracle/helios_oracle.c, OpenMP over bins) on a bounded sample of the same workload, from
-    iteration 0 (one opacity refresh per 10 iterations).  Premixed: ALL bins, 30 iterations.  On-the-fly mixing
-    (the reference's bubble sort of 400 sums per point and species): 4000 of the bins, 20 iterations, i.e. two
-    refreshes.  The thread count is probed (8 ... all usable cores) and the winner stated."""
+    iteration 0 (one opacity refresh per 10 iterations): whole decades of iterations, as many as fit about 20 s of CPU
+    work at the rate the thread probe measured (at least one decade, at most three).  Premixed: ALL bins.  On-the-fly
+    mixing (the reference's bubble sort of 400 sums per point and species): 4000 of the bins.  The thread count is
+    probed (8 ... all usable cores) and the winner stated."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     lib, flags = native_oracle()
     species = bool(w.get("nspecies"))
     nb = min(w["nbin"], 4000 if species else w["nbin"])
-    n_it = 20 if species else 30
     ws = dict(w)
     ws["nbin"] = nb
     c = build_case(ws, seed)
@@ -305,7 +311,9 @@ def cpu_baseline(w, seed):
     # thread-count probe (all cores or a shown optimum): the first refresh + iteration, then three
     # refresh-free iterations per candidate on the same state; the fastest count runs the sample
     lib.set_num_threads(min(ncpu, 64))
+    t0 = time.perf_counter()
     cases.radiation_iterations(lib, cc, s, 1, refresh=refresh)
+    t_first = time.perf_counter() - t0          # one refresh + one iteration
     probe = {}
     for th in sorted(set(t for t in (8, 16, 32, 64, 96, 128, 192, 256, ncpu) if t <= ncpu)):
         lib.set_num_threads(th)
@@ -314,6 +322,10 @@ def cpu_baseline(w, seed):
         probe[th] = 3.0 / (time.perf_counter() - t0)
     threads = max(probe, key=probe.get)
     lib.set_num_threads(threads)
+    # a decade = one refresh + ten iterations: (t_first - t_it) + 10 t_it with t_it from the probe; as many as fit the budget
+    t_it = 1.0 / probe[threads]
+    t_decade = max(t_first - t_it, 0.0) * (min(ncpu, 64) / float(threads) if threads < min(ncpu, 64) else 1.0) + 10.0 * t_it
+    n_it = 10 * int(max(1, min(3, budget_s // t_decade)))
     cc2 = cases.Case(cc)                      # the sample starts from iteration 0 on a fresh state
     cc2.T_lay = T0
     cc2.T_int = np.zeros(c.nlayer + 1)
@@ -324,7 +336,11 @@ def cpu_baseline(w, seed):
     cases.radiation_iterations(lib, cc2, s, n_it, refresh=refresh)
     dt = time.perf_counter() - t0
     return dict(value=n_it / dt * nb * c.nlayer, unit="bin*layer*iterations/s", cores=threads, kind="port",
-                host_cores=ncpu, thread_probe_iterations_per_s={str(k): round(v, 3) for k, v in probe.items()},
+                host_cores=ncpu, seconds=dt,
+                sample_short="%d of %d bins x %d layers x %d Gauss points%s, %d iterations from iteration 0 (refresh every 10), "
+                             "oracle/helios_oracle.c %s, OpenMP %d threads, %.1f s"
+                             % (nb, w["nbin"], c.nlayer, c.ny, ", %d species" % len(c.species) if species else "", n_it, flags,
+                                threads, dt), thread_probe_iterations_per_s={str(k): round(v, 3) for k, v in probe.items()},
                 sample="%d of %d bins x %d layers x %d Gauss points%s, %d iterations from iteration 0 (one opacity "
                        "refresh per 10), oracle/helios_oracle.c built %s with OpenMP over bins on %d threads (the fastest "
                        "of %s on %d usable cores, probed on refresh-free iterations; OMP_PROC_BIND=%s OMP_PLACES=%s), %.1f s; "
@@ -621,10 +637,11 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
     total_cols = ncol * world
     flux_policy = rt.get("flux_launch_policy")
     graphs = rt.get("graph_replays")
+    graph_builds = rt.get("graph_builds")
     out = {
         "value": steps / dt * c.nbin * c.nlayer * total_cols, "unit": "bin*layer*iterations/s",
         "steps": steps, "warmup": warmup, "device_warmup_iterations": device_warmup, "ms_per_step": dt / steps * 1e3,
-        "config": {"workload": w["desc"], "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
+        "config": {"workload": w["desc"], "name": wname, "nbin": c.nbin, "nlayer": c.nlayer, "ny": c.ny,
                    "species": len(c.species) if c.species else 0,
                    "opacity_table_TP_grid": [c.ntemp, c.npress], "columns_per_gpu": ncol,
                    "columns_total": total_cols, "refresh_every": 10, "sweeps_per_iteration": 3 * c.scat + 1,
@@ -634,7 +651,8 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
                    "flux_launch_policy": {"back_and_forth": bool(flux_policy[0]), "state_cached_mib": float(flux_policy[1])},
                    # small grids: iterations replayed as hipGraphs (runs of nine refresh-free iterations, whole decades with
                    # their refresh), counted over the whole measurement
-                   "graph_replays": {"nine_iterations": int(graphs[0]), "decades": int(graphs[1]), "in_use": bool(graphs[2])}},
+                   "graph_replays": {"nine_iterations": int(graphs[0]), "decades": int(graphs[1]), "in_use": bool(graphs[2]),
+                                     "builds": int(graph_builds[0]) + int(graph_builds[1])}},
         "iterations_per_s_per_column": steps / dt,
         "setup_s": setup_s, "setup_s_per_rank": ranks.gather_scalars(setup_s),
         "stream_event_ms_per_step": ev_ms / steps,
@@ -669,6 +687,94 @@ def measure(ctx, ranks, wname, ncol, steps, warmup, seed, phase="radiative", pro
     return out
 
 
+def _sig(v, digits=6):
+    """floats at `digits` significant digits (the side file keeps full precision), containers recursively"""
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v)) if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return v
+
+
+LINE_LIMIT = 4000        # bytes of the ONE line on stdout; tests/test_bench_cli.py holds compact_line() to it at N = 1 and N = 8
+
+
+def compact_line(full, detail_path=None):
+    """the line the driver parses, from the full record of the run: the contract's fields as they are (value, ms_per_step at
+    full precision), everything else reduced to what a reader of the line needs and rounded to six digits"""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full["config"]
+    line["config"] = {"workload": cfg["workload"][:160], "name": cfg.get("name"), "nbin": cfg["nbin"], "nlayer": cfg["nlayer"],
+                      "ny": cfg["ny"], "species": cfg["species"], "columns_per_gpu": cfg["columns_per_gpu"],
+                      "columns_total": cfg["columns_total"], "loop": cfg["loop"], "parallelism": cfg["parallelism"]}
+
+    def roof(r):
+        if not r:
+            return None
+        out = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms",
+                                     "launches_timed", "algorithmic_bytes_per_launch")}
+        if r.get("whole_step"):
+            out["whole_step_frac"] = r["whole_step"]["frac"]
+        if r.get("frac_of_achievable"):
+            out["frac_of_copy_rate"] = r["frac_of_achievable"]["frac"]
+        if r.get("valu_issue"):
+            out["valu_issue_frac"] = r["valu_issue"]["frac"]
+        out["traffic_live"] = bool(r.get("traffic_source") and r["traffic_source"].startswith("measured in this run"))
+        return _sig(out)
+    line["roofline"] = roof(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else _sig({"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                                     "host_cores": cb.get("host_cores"), "seconds": cb.get("seconds"),
+                                                     "sample": cb.get("sample_short") or cb["sample"][:200]})
+    ss = full.get("steady_state_200")
+    line["steady_state_200"] = None if not ss else _sig({"ms_per_iteration": ss["ms_per_iteration"], "value": ss["value"]})
+    line["process_group"] = _sig(full.get("process_group"))
+    for k in ("per_rank_ms_per_step", "rank_imbalance", "spectra_gather_ms", "spectrum_checksum", "setup_s",
+              "device_warmup_iterations", "columns_converged_during_run"):
+        line[k] = _sig(full.get(k), 5 if k == "per_rank_ms_per_step" else 9 if k == "spectrum_checksum" else 6)
+    gr = cfg.get("graph_replays") or {}
+    line["graphs"] = {"replays": int(gr.get("nine_iterations", 0)) + int(gr.get("decades", 0)), "builds": gr.get("builds")}
+    sec = {}
+    for name, r in (full.get("secondary") or {}).items():
+        if "error" in r:
+            sec[name] = {"error": str(r["error"])[:120]}
+            continue
+        rr = r.get("roofline") or {}
+        sec[name] = _sig({"value": r["value"], "ms_per_step": r["ms_per_step"], "frac": rr.get("frac"), "kernel": rr.get("kernel"),
+                          "kernel_ms": rr.get("avg_launch_ms"),
+                          "whole_step_frac": (rr.get("whole_step") or {}).get("frac")})
+    line["secondary"] = sec or None
+    if full.get("env_knobs"):
+        line["env_knobs"] = full["env_knobs"]
+    line["detail"] = detail_path
+    return line
+
+
+def emit(full, detail_path):
+    """side file first, then the one line -- the last thing this process writes to stdout"""
+    written = None
+    if detail_path:
+        try:
+            tmp = detail_path + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as f:
+                json.dump(full, f, indent=1)
+            os.replace(tmp, detail_path)
+            written = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT + os.sep) else detail_path
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (detail_path, e))
+    text = json.dumps(compact_line(full, written), separators=(",", ":"))
+    if len(text) > LINE_LIMIT:       # never happens with the fields above; if it does, the secondaries go first
+        slim = compact_line(dict(full, secondary=None), written)
+        slim["secondary_dropped_for_size"] = sorted(full.get("secondary") or {})
+        text = json.dumps(slim, separators=(",", ":"))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    print(text, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -678,8 +784,17 @@ def main():
                     help="headline workload (default c2, the configuration the metric is quoted on, at every N)")
     ap.add_argument("--columns-per-gpu", type=int, default=None)
     ap.add_argument("--secondary", default="default",
-                    help="'default' (N = 1: c3,c4,c5,c5conv,d64,d64s; N > 1: c4), 'none', or a comma-separated list of workloads measured in "
-                         "the same run into the line's `secondary` block")
+                    help="'default' (N = 1: c3,c4,c5; N > 1: c4), 'all' (N = 1: c3,c4,c5,c5conv,d64,d64s), 'none', or a "
+                         "comma-separated list of workloads measured in the same run into the line's `secondary` block")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="side file with the full record of the run (the line on stdout is its compact form); '' = none")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the full record instead of the compact line (the A/B scripts under tools/ read per-kernel "
+                         "times from it; never what the driver runs)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0,
+                    help="CPU work the oracle's timed sample is sized for (whole decades of iterations)")
+    ap.add_argument("--init-timeout", type=float, default=180.0,
+                    help="N > 1: seconds the process group's set-up, roll call and first collective may take each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--allow-debug-knobs", action="store_true")
@@ -709,10 +824,12 @@ def main():
     steps = args.steps if args.steps is not None else (20 if heavy else 200)
     warmup = args.warmup if args.warmup is not None else (10 if heavy else 20)
     ncol = args.columns_per_gpu or w.get("columns_per_gpu", 1)
-    if args.secondary == "default":
+    if args.secondary in ("default", "all"):
         # (config 4 with the SAME shape at every N: one GPU's share of the 512-column sweep, 64 columns in one batch)
-        # (and the regime HELIOS users run: the reference's default grid as a 64-column batch, premixed and with species.dat's list)
-        secondary = (["c3", "c4", "c5", "c5conv", "d64", "d64s"] if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
+        # ('all' adds the regime HELIOS users run: the reference's default grid as a 64-column batch, premixed and with
+        # species.dat's list, and config 5's steps taken from the convection loop)
+        n1 = ["c3", "c4", "c5"] + (["c5conv", "d64", "d64s"] if args.secondary == "all" else [])
+        secondary = (n1 if world == 1 else ["c4"]) if wname == "c2" and args.phase == "radiative" else []
     else:
         secondary = [x for x in args.secondary.split(",") if x and x != "none"]
     for x in secondary:
@@ -727,20 +844,23 @@ def main():
                                 ncol if x == wname else WORKLOADS[x].get("columns_per_gpu", 1))
             if got is not None:
                 LIVE_COUNTERS[x] = got
-    import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
-    dist = None
     # test hook for single-GPU machines: HELIOS_BENCH_BACKEND=gloo runs all ranks on GPU 0 with CPU-side collectives,
     # so that the multi-rank logic can be exercised where RCCL cannot (one GPU cannot host two RCCL ranks)
     backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")
     device_index = local_rank if backend == "nccl" else 0
     coll_device = "cuda" if backend == "nccl" else "cpu"
+    # before the first GPU call of this rank: onto the host cores of its GPU's NUMA node (plain sysfs reads and
+    # sched_setaffinity; at N = 1 the CPU baseline keeps all cores)
+    from helios_amd import parallel
+    affinity = parallel.bind_to_gpu_numa_node(device_index, apply=world > 1)
+    import torch  # first, so that its bundled HIP runtime is the one libhelios_hip.so binds to
+    dist = None
+    init_times = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
+        init_times = parallel.init_process_group_checked(dist, backend, rank, world, device=torch.device("cuda", device_index),
+                                                         timeout_s=args.init_timeout)
     ranks = Ranks(dist, world, rank, coll_device)
 
     from helios_amd.device import Context
@@ -762,11 +882,18 @@ def main():
             return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
         except Exception as e:      # (the line must not depend on this accessor)
             return "unavailable: %s" % type(e).__name__
+    # (per rank: the NUMA node its process was bound to before the first GPU call, -1 = not bound, and the cores it kept)
+    numa = ranks.gather_scalars(float(affinity["numa_node"]) if affinity["bound"] else -1.0)
+    cpus = ranks.gather_scalars(float(affinity["cpus"] or 0))
     line["process_group"] = None if dist is None else {
         "backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()),
         "rccl_world": int(dist.get_world_size()) if str(dist.get_backend()) == "nccl" else None,
         "rccl_version": rccl_version() if str(dist.get_backend()) == "nccl" else None,
-        "ranks_seen_by_all_gather": len(ranks.gather_scalars(float(rank)))}
+        "ranks_seen_by_all_gather": len(ranks.gather_scalars(float(rank))),
+        "numa_node_per_rank": [int(v) for v in numa], "cpus_per_rank": [int(v) for v in cpus],
+        "init_s": init_times["init_s"], "roll_call_s": init_times["roll_call_s"],
+        "first_collective_s": init_times["first_collective_s"]}
+    line["host_affinity"] = affinity
     # the other configurations, measured live in this run on every rank (weak scaling like the headline)
     sec = {}
     for x in secondary:
@@ -781,13 +908,16 @@ def main():
         sec[x] = r
     line["secondary"] = sec or None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(w, seed)
+        line["cpu_baseline"] = cpu_baseline(w, seed, args.cpu_baseline_seconds)
     elif rank == 0:
         line["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and args.full_line:
+        print(json.dumps(line), flush=True)
+    elif rank == 0:
+        emit(line, args.detail or None)
 
 
 if __name__ == "__main__":

@@ -150,9 +150,14 @@ struct hx_rt {
     int iter_dev_expected = -1;    // what iter_dev[0] holds as far as the host knows (-1: unknown)
     hipGraphExec_t iter_graph = nullptr;
     hipGraphExec_t decade_graph = nullptr;   // refresh + ten iterations (hx_rt_run entered at a refresh boundary)
-    bool decade_graph_stale = true;
     long long iter_graph_replays = 0, decade_graph_replays = 0;
-    bool graph_stale = true;       // arguments may have changed since the capture
+    long long iter_graph_builds = 0, decade_graph_builds = 0;
+    // every setter that changes what a launch is given moves the generation on; a capture is good while it holds the
+    // generation it was taken at (one number per capture: building one graph says nothing about the other)
+    long long graph_gen = 1, iter_graph_gen = 0, decade_graph_gen = 0;
+    // counts everything that can change the spectral fluxes (solves, refreshes, graph replays, setters); the direct solve's
+    // tiles re-created for hx_rt_get carry the count they were made at
+    long long solve_serial = 1, matrix_tiles_serial = 0;
     int use_graph = -1;            // -1: decide from the grid size (HELIOS_RT_GRAPH=0|1 overrides), 0 / 1
     std::vector<char> have_albedo; // per column: a surface albedo has been handed over (the matrix method divides by it)
     hx::MatrixArrays mx;

@@ -547,11 +547,18 @@ int hx_rt_destroy(hx_rt* rt) {
     return 0;
 }
 
+// A setter changed what the launches are given: captured graphs hold older arguments (each compares its own generation),
+// and spectral flux tiles re-created for hx_rt_get are no longer the last solve's.
+static inline void rt_touch(hx_rt* rt) {
+    rt->graph_gen++;
+    rt->solve_serial++;
+}
+
 int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_deltawave,
                    const double* opac_wave, const double* gauss_y, const double* gauss_weight,
                    const double* ktemp, const double* kpress) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int rc = 0;
     rc |= h2d(rt, rt->interwave, opac_interwave, (rt->X + 1) * 8);
     rc |= h2d(rt, rt->deltawave, opac_deltawave, rt->X * 8);
@@ -567,7 +574,7 @@ int hx_rt_set_grid(hx_rt* rt, const double* opac_interwave, const double* opac_d
 int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opac_scat_cross,
                               const double* opac_meanmass) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, rt->d.nspecies == 0, HX_E_STATE, "object was created for on-the-fly mixing");
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
     if (!rt->opac_k) {
@@ -586,7 +593,7 @@ int hx_rt_set_premixed_tables(hx_rt* rt, const double* opac_k, const double* opa
 int hx_rt_set_species(hx_rt* rt, int s, const double* opacity_pretab, const double* scat_cross,
                       double weight, int is_h2o, int is_cia, int in_mu) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
     Species& sp = rt->species[s];
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
@@ -653,7 +660,7 @@ int hx_rt_set_species_separable(hx_rt* rt, int s, const double* kxy, const doubl
 int hx_rt_set_premixed_separable(hx_rt* rt, const double* kxy, const double* ftp, const double* opac_scat_cross,
                                  const double* opac_meanmass) {
     if (!rt) return HX_E_ARG;
-    rt->graph_stale = true;
+    rt_touch(rt);         
     HX_REQUIRE(rt->ctx, rt->d.nspecies == 0, HX_E_STATE, "object was created for on-the-fly mixing");
     HX_REQUIRE(rt->ctx, kxy && ftp && opac_scat_cross && opac_meanmass, HX_E_ARG, "null table");
     const size_t ntp = (size_t)rt->d.ntemp * rt->d.npress;
@@ -678,7 +685,7 @@ static int for_cols(hx_rt* rt, int col, int* c0, int* c1);
 // col): the species goes back to the profiles of hx_rt_set_column_vmr in every column.
 int hx_rt_set_column_vmr_table(hx_rt* rt, int col, int s, const double* vmr_pretab) {
     if (!rt) return HX_E_ARG;
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, s >= 0 && s < (int)rt->species.size(), HX_E_ARG, "species index out of range");
     HX_REQUIRE(rt->ctx, rt->d.ntemp >= 2 && rt->d.npress >= 2, HX_E_ARG, "a mixing-ratio table needs at least 2 x 2 nodes");
     int c0, c1;
@@ -713,7 +720,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
                              const double* T_lay, const double* surf_albedo,
                              const double* starflux) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     const size_t L = rt->L, I = rt->I, X = rt->X;
@@ -748,7 +755,7 @@ int hx_rt_set_column_profile(hx_rt* rt, int col, const double* p_lay, const doub
 
 int hx_rt_set_column_vmr(hx_rt* rt, int col, const double* vmr_lay, const double* vmr_int) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     HX_REQUIRE(rt->ctx, rt->d.nspecies > 0, HX_E_STATE, "no species in a premixed object");
@@ -768,7 +775,7 @@ int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
                             const double* scat_cross_int, const double* g_0_lay,
                             const double* g_0_int) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     HX_REQUIRE(rt->ctx, rt->f.clouds == 1, HX_E_STATE, "object was created with clouds = 0");
@@ -787,7 +794,7 @@ int hx_rt_set_column_clouds(hx_rt* rt, int col, const double* abs_cross_lay,
 int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
                              const double* F_add_heat_sum) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) {
@@ -799,7 +806,7 @@ int hx_rt_set_column_heating(hx_rt* rt, int col, const double* F_add_heat_lay,
 
 int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) rc |= h2d(rt, rt->T_lay + (size_t)c * (rt->L + 1), T_lay, (rt->L + 1) * 8);
@@ -808,7 +815,7 @@ int hx_rt_set_temperatures(hx_rt* rt, int col, const double* T_lay) {
 
 int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     int c0, c1, rc = for_cols(rt, col, &c0, &c1);
     if (rc) return rc;
     for (int c = c0; c < c1; c++) {
@@ -821,7 +828,7 @@ int hx_rt_set_convergence_limit(hx_rt* rt, int col, double limit) {
 
 int hx_rt_build_planck_table(hx_rt* rt, int energy_correction) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, rt->have_grid, HX_E_STATE, "hx_rt_set_grid first");
     hx_context* ctx = rt->ctx;
     const int X = rt->X, dim = rt->d.plancktable_dim, step = rt->d.plancktable_step;
@@ -1007,6 +1014,7 @@ static int matrix_solve(hx_rt* rt) {
 int hx_rt_refresh(hx_rt* rt) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
     hx_context* ctx = rt->ctx;
+    rt->solve_serial++;
     HX_REQUIRE(ctx, rt->have_grid && rt->have_tables && rt->have_planck, HX_E_STATE,
                "set grid, tables and build the Planck table first");
     HX_REQUIRE(ctx, !rt->matrix || std::all_of(rt->have_albedo.begin(), rt->have_albedo.end(), [](char v) { return v != 0; }),
@@ -1127,6 +1135,7 @@ static int spectral_fluxes(hx_rt* rt, const KArgs& a) {
 
 static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool nodes_done) {
     hx_context* ctx = rt->ctx;
+    rt->solve_serial++;
     KArgs a = make_args(rt);
     if (!nodes_done) {
         ProfScope ps(rt, "rt_nodes");
@@ -1269,7 +1278,7 @@ int hx_rt_kappa_cp_refresh(hx_rt* rt) {
 int hx_rt_set_kappa_table(hx_rt* rt, const double* entr_temp, int entr_ntemp, const double* entr_press,
                           int entr_npress, const double* entr_kappa, const double* entr_c_p) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     HX_REQUIRE(rt->ctx, entr_ntemp > 1 && entr_npress > 1 && entr_temp && entr_press && entr_kappa && entr_c_p,
                HX_E_ARG, "hx_rt_set_kappa_table: need a (T, P) grid of at least 2 x 2");
     const size_t n = (size_t)entr_ntemp * entr_npress;
@@ -1337,6 +1346,7 @@ int hx_rt_conv_advance(hx_rt* rt, int itervalue) {
         nodes_done = true;
     }
     KArgs a = make_args(rt);
+    rt->solve_serial++;
     rt->iter_dev_expected = -1;   // (the convection loop passes its own iteration index; k_rt_nodes still counts)
     if (!nodes_done) {
         ProfScope ps(rt, "rt_nodes");
@@ -1454,19 +1464,20 @@ static int build_iteration_graph(hx_rt* rt, bool with_refresh) {
         (void)hipGetLastError();
         return 0;
     }
-    (with_refresh ? rt->decade_graph_stale : rt->graph_stale) = false;
+    // each capture remembers the generation of arguments it holds: building one does not vouch for the other
+    (with_refresh ? rt->decade_graph_gen : rt->iter_graph_gen) = rt->graph_gen;
+    (with_refresh ? rt->decade_graph_builds : rt->iter_graph_builds)++;
     return 0;
 }
 
 int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    if (rt->graph_stale) rt->decade_graph_stale = true;   // every setter marks graph_stale: both captures hold old arguments
     for (int n = 0; n < nsteps;) {
         const int it = itervalue + n;
         const bool decade = it % 10 == 0 && nsteps - n >= GRAPH_ITERATIONS + 1 && (rt->d.nspecies == 0 || !rt->species_dev_stale);
         if ((decade || (it % 10 == 1 && nsteps - n >= GRAPH_ITERATIONS)) && rt->refreshed && graph_wanted(rt)) {
             hipGraphExec_t& exec = decade ? rt->decade_graph : rt->iter_graph;
-            if ((decade ? rt->decade_graph_stale : rt->graph_stale) || !exec) {
+            if ((decade ? rt->decade_graph_gen : rt->iter_graph_gen) != rt->graph_gen || !exec) {   // a setter ran since its capture
                 int rc = build_iteration_graph(rt, decade);
                 if (rc) return rc;
             }
@@ -1474,6 +1485,7 @@ int hx_rt_run(hx_rt* rt, int itervalue, int nsteps) {
                 int rc = sync_iteration_counter(rt, it);
                 if (rc) return rc;
                 HX_HIP(rt->ctx, hipGraphLaunch(exec, rt->ctx->stream));
+                rt->solve_serial++;
                 (decade ? rt->decade_graph_replays : rt->iter_graph_replays)++;
                 const int done = GRAPH_ITERATIONS + (decade ? 1 : 0);
                 rt->iter_dev_expected = it + done;
@@ -1630,6 +1642,12 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
         memcpy(out, v, sizeof(v));
         return 0;
     }
+    if (n == "graph_builds") {   // host-side: {captures of the nine-iteration graph, captures of the decade graph}
+        HX_REQUIRE(rt->ctx, out_bytes == 2 * sizeof(double), HX_E_ARG, "graph_builds is two doubles");
+        const double v[2] = {(double)rt->iter_graph_builds, (double)rt->decade_graph_builds};
+        memcpy(out, v, sizeof(v));
+        return 0;
+    }
     if (n == "planck_grid")
         return get_plain(rt, rt->planck_grid, (size_t)(rt->d.plancktable_dim + 1) * X * 8, out, out_bytes);
     if (n == "done") return get_plain(rt, rt->done + c, 4, out, out_bytes);
@@ -1677,19 +1695,24 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
         // the kernel).  Asked for, they are the last solve's: the coefficient tiles and node Planck values it read are still in
         // place, so the same launch -- this time with its stores, and for every column, also those whose loop has ended --
         // reproduces them bit for bit (and rewrites the same band fluxes).
+        // ONE such launch serves every name and column asked for until the next solve or setter (`solve_serial`).
         HX_REQUIRE(rt->ctx, rt->refreshed, HX_E_STATE, "no iteration has been run yet");
+        const bool first = !rt->Dtile;
         if (!rt->Dtile) RT_ALLOC(rt->Dtile, (size_t)rt->C * rt->g.flux_elems_per_col);
         if (!rt->zero_flags) RT_ALLOC(rt->zero_flags, (size_t)rt->C);
-        const bool kd = rt->keep_down, ks = rt->matrix_keep_state;
-        rt->keep_down = true;
-        rt->matrix_keep_state = true;
-        KArgs a = make_args(rt);
-        a.done = rt->zero_flags;
-        DISPATCH_ROWS(launch_flux, rt, a);
-        rt->keep_down = kd;
-        rt->matrix_keep_state = ks;
-        HX_LAUNCH_CHECK(rt->ctx);
-        rt->graph_stale = true;
+        if (first || rt->matrix_tiles_serial != rt->solve_serial) {
+            const bool kd = rt->keep_down, ks = rt->matrix_keep_state;
+            rt->keep_down = true;
+            rt->matrix_keep_state = true;
+            KArgs a = make_args(rt);
+            a.done = rt->zero_flags;
+            DISPATCH_ROWS(launch_flux, rt, a);
+            rt->keep_down = kd;
+            rt->matrix_keep_state = ks;
+            HX_LAUNCH_CHECK(rt->ctx);
+            rt->matrix_tiles_serial = rt->solve_serial;
+        }
+        if (first) rt->graph_gen++;   // the captures were taken without the down-flux tiles' address
     }
     if (n == "F_up_wg") return get_flux_wg(rt, col, rt->Utile, rt->U0, true, true, out, out_bytes);
     if (n == "Fc_up_wg") return get_flux_wg(rt, col, rt->Utile, nullptr, true, false, out, out_bytes);
@@ -1724,7 +1747,7 @@ int hx_rt_get(hx_rt* rt, int col, const char* name, void* out, size_t out_bytes)
 
 int hx_rt_set_state(hx_rt* rt, int col, const char* name, const void* in, size_t in_bytes) {
     if (!rt) return HX_E_ARG;  // e.g. a call after hx_rt_destroy
-    rt->graph_stale = true;   // a captured iteration graph holds the arguments of before this call
+    rt_touch(rt);            // a captured iteration graph holds the arguments of before this call
     const std::string n(name);
     if (n == "keep_down") {
         if (in_bytes != 4) return hx_fail(rt->ctx, HX_E_ARG, "keep_down expects one int32");

@@ -5,6 +5,8 @@ from a shared work list as a rank retires the columns it holds (`WorkList`); the
 The only exchange is one gather of the output spectra at the end of a run, done with torch.distributed -- backend "nccl" is RCCL over xGMI on ROCm,
 "gloo" is used by the CPU tests.  The reference has no counterpart (single process, single device).
 """
+import os
+
 import numpy as np
 
 
@@ -113,3 +115,179 @@ def gather_spectra(local, dist=None, device=None, columns=None):
         return rows[:, :-1]
     order = np.argsort(rows[:, -1].astype(np.int64), kind="stable")
     return rows[order, :-1]
+
+
+def _cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11}"""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every GPU in the order the HIP runtime enumerates them: the KFD topology's nodes that have SIMDs
+    (`/sys/class/kfd/kfd/topology/nodes/<n>/properties`: simd_count > 0), in node order; their PCI address (domain,
+    location_id = bus << 8 | devfn) leads to `/sys/bus/pci/devices/<bdf>/numa_node`.  Where the KFD topology cannot be read
+    the DRM cards (`/sys/class/drm/card<k>/device/numa_node`, AMD vendor id, ascending PCI address) stand in.  [] when
+    neither is there (containers without sysfs); -1 = the platform does not say."""
+    nodes = []
+    top = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    try:
+        for n in sorted(os.listdir(top), key=int):
+            props = {}
+            with open(os.path.join(top, n, "properties")) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) == 0:
+                continue
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+            try:
+                with open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")) as f:
+                    nodes.append(int(f.read()))
+            except (OSError, ValueError):
+                nodes.append(-1)
+        if nodes:
+            return nodes
+    except (OSError, ValueError):
+        nodes = []
+    drm = os.path.join(sysfs, "class/drm")
+    try:
+        cards = []
+        for c in os.listdir(drm):
+            if not (c.startswith("card") and c[4:].isdigit()):
+                continue
+            dev = os.path.join(drm, c, "device")
+            try:
+                with open(os.path.join(dev, "vendor")) as f:
+                    if int(f.read(), 16) != 0x1002:
+                        continue
+                with open(os.path.join(dev, "numa_node")) as f:
+                    numa = int(f.read())
+            except (OSError, ValueError):
+                continue
+            cards.append((os.path.basename(os.path.realpath(dev)), numa))
+        return [numa for _, numa in sorted(cards)]
+    except OSError:
+        return []
+
+
+def visible_device_index(local_index, env=None):
+    """the physical GPU behind HIP device `local_index` when ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES hold plain index
+    lists (ROCR's is applied first, HIP's indexes into what is left); None when a list is given by UUID"""
+    env = os.environ if env is None else env
+    idx = int(local_index)
+    hip_var = "HIP_VISIBLE_DEVICES" if env.get("HIP_VISIBLE_DEVICES") else "CUDA_VISIBLE_DEVICES"   # (HIP reads either)
+    for var in (hip_var, "ROCR_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if not v:
+            continue
+        items = [x.strip() for x in v.split(",") if x.strip()]
+        if not all(x.isdigit() for x in items):
+            return None
+        if idx >= len(items):
+            return None
+        idx = int(items[idx])
+    return idx
+
+
+def bind_to_gpu_numa_node(local_index, sysfs="/sys", env=None, apply=True):
+    """Bind this process to the host cores of the NUMA node its GPU hangs on -- `os.sched_setaffinity`, before the first
+    GPU call, so that the runtime's helper threads and the pinned staging buffers start there; no numactl, no re-exec.
+    The mask is the node's cpulist intersected with the cores the process may use already (cgroups, an outer taskset); an
+    empty intersection, an unknown node or a sysfs that is not there leave the process as it is.  Returns what happened,
+    for the bench line: {"gpu", "numa_node", "cpus", "bound", "why"}."""
+    out = {"gpu": None, "numa_node": None, "cpus": None, "bound": False, "why": None}
+    if not hasattr(os, "sched_getaffinity"):
+        out["why"] = "no sched_getaffinity on this platform"
+        return out
+    allowed = set(os.sched_getaffinity(0))
+    out["cpus"] = len(allowed)
+    gpu = visible_device_index(local_index, env)
+    if gpu is None:
+        out["why"] = "visible-devices list is not a plain index list"
+        return out
+    out["gpu"] = gpu
+    nodes = gpu_numa_nodes(sysfs)
+    if gpu >= len(nodes):
+        out["why"] = "no sysfs entry for GPU %d (%d found)" % (gpu, len(nodes))
+        return out
+    numa = nodes[gpu]
+    out["numa_node"] = numa
+    if numa < 0:
+        out["why"] = "platform reports no NUMA node for the GPU"
+        return out
+    try:
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % numa)) as f:
+            cpus = _cpulist(f.read())
+    except (OSError, ValueError):
+        out["why"] = "node%d has no cpulist" % numa
+        return out
+    mask = cpus & allowed
+    if not mask:
+        out["why"] = "none of node%d's cores is usable by this process" % numa
+        return out
+    if apply and mask != allowed:
+        os.sched_setaffinity(0, mask)
+    out["cpus"], out["bound"] = len(mask), bool(apply)
+    if not apply:
+        out["why"] = "not applied (single rank: the CPU baseline keeps every core)"
+    return out
+
+
+def init_process_group_checked(dist, backend, rank, world, device=None, timeout_s=180.0, log=None):
+    """`init_process_group` with a deadline, and a roll call before the first real collective: a gloo side group's
+    `monitored_barrier` names the ranks that did not arrive (RCCL itself only hangs or aborts), then one all-reduce on
+    the real backend confirms that every rank's communicator works.  A failure is reported with this rank's number and
+    device on stderr before it is raised again.  Returns {"init_s", "roll_call_s", "first_collective_s"}."""
+    import datetime
+    import sys
+    import time
+    import torch
+    log = log or (lambda m: (sys.stderr.write(m + "\n"), sys.stderr.flush()))
+    who = "rank %d/%d (device %s, pid %d)" % (rank, world, device, os.getpid())
+    to = datetime.timedelta(seconds=float(timeout_s))
+    t0 = time.perf_counter()
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", timeout=to, device_id=device)
+        else:
+            dist.init_process_group(backend, timeout=to)
+    except Exception as e:
+        log("helios_amd.parallel: %s: init_process_group(%r) failed within %.0f s: %s: %s"
+            % (who, backend, timeout_s, type(e).__name__, e))
+        raise
+    t1 = time.perf_counter()
+    side, roll_call = None, True
+    if backend != "gloo":
+        try:     # (a host whose name does not resolve may refuse gloo a network device: the roll call is a diagnostic, not a need)
+            side = dist.new_group(backend="gloo", timeout=to)
+        except Exception as e:
+            log("helios_amd.parallel: %s: no gloo side group for the roll call (%s: %s); going on without"
+                % (who, type(e).__name__, e))
+            roll_call = False
+    if roll_call:
+        try:
+            dist.monitored_barrier(group=side, timeout=to, wait_all_ranks=True)
+        except Exception as e:
+            log("helios_amd.parallel: %s: roll call failed -- %s: %s" % (who, type(e).__name__, e))
+            raise
+    t2 = time.perf_counter()
+    try:
+        t = torch.ones(1, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        seen = int(t.item())
+        if seen != world:
+            raise RuntimeError("first all-reduce counted %d ranks, expected %d" % (seen, world))
+    except Exception as e:
+        log("helios_amd.parallel: %s: first %s collective failed -- %s: %s" % (who, backend, type(e).__name__, e))
+        raise
+    t3 = time.perf_counter()
+    return {"init_s": t1 - t0, "roll_call_s": t2 - t1, "first_collective_s": t3 - t2}

@@ -218,7 +218,7 @@ class RTBatch(object):
             "delta_z_lay": (L, np.float64), "z_lay": (L, np.float64),
             "F_up_wg": (wg, np.float64), "F_down_wg": (wg, np.float64), "Fc_up_wg": (wg, np.float64),
             "Fc_down_wg": (wg, np.float64), "F_dir_wg": (wg, np.float64), "Fc_dir_wg": (wg, np.float64),
-            "iters_done": (1, np.int32), "done": (1, np.int32), "flux_launch_policy": (2, np.float64), "graph_replays": (3, np.float64),
+            "iters_done": (1, np.int32), "done": (1, np.int32), "flux_launch_policy": (2, np.float64), "graph_replays": (3, np.float64), "graph_builds": (2, np.float64),
             "conv_layer": (L + 1, np.int32), "conv_unstable": (L + 1, np.int32), "marked_red": (L + 1, np.int32),
             "kappa_lay": (L, np.float64), "kappa_int": (L + 1, np.float64), "c_p_lay": (L, np.float64),
             "F_smooth_sum": (L, np.float64), "F_add_heat_lay": (L, np.float64), "F_add_heat_sum": (L, np.float64),

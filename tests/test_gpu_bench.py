@@ -14,10 +14,48 @@ FIELDS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
           "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
 
-def _last_json(out):
+def _last_json(out, detail=True):
+    """the ONE line on stdout -- compact (bench.LINE_LIMIT), the last thing printed -- and, for the assertions on what the run
+    measured in full, the side file it names"""
+    import bench
     lines = [ln for ln in out.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-2000:]
-    return json.loads(lines[0])
+    assert out.rstrip().endswith(lines[0]) and len(lines[0]) < bench.LINE_LIMIT, len(lines[0])
+    line = json.loads(lines[0])
+    for f in FIELDS:
+        assert f in line, f
+    if not detail:
+        return line
+    path = line["detail"] if os.path.isabs(line["detail"]) else os.path.join(ROOT, line["detail"])
+    with open(path) as f:
+        full = json.load(f)
+    assert full["value"] == line["value"] and full["ms_per_step"] == line["ms_per_step"]      # the same run
+    return full
+
+
+def test_the_drivers_command_prints_one_short_line_last(tmp_path):
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` as the driver runs it (default secondaries, live counters, CPU
+    baseline): what a reader of the last 2 000 characters of stdout sees ends in one line that parses and holds the
+    contract's fields with `roofline` and `cpu_baseline`"""
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--detail",
+                        str(tmp_path / "detail.json")], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout[-4000:].rstrip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) < 4000
+    for f in FIELDS:
+        assert f in line, f
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["config"]["nbin"] == 10000
+    r = line["roofline"]
+    assert r["kernel"] == "k_rt_flux" and r["bound"] == "hbm" and 0.2 < r["frac"] < 1 and r["traffic"] > r["algorithmic_bytes_per_launch"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["seconds"] < 60
+    assert sorted(line["secondary"]) == ["c3", "c4", "c5"]
+    for x in line["secondary"].values():
+        assert x["value"] > 0 and x["kernel"] == "k_rt_mix_species" and 0 < x["frac"] < 1
+    assert abs(line["value"] - 10000 * 100 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    with open(str(tmp_path / "detail.json")) as f:
+        full = json.load(f)
+    assert len(full["spectrum_checksum_per_column"]) == 1 and "kernels_ms" in full["roofline"]
 
 
 def test_bench_single_rank_contract():
@@ -25,8 +63,6 @@ def test_bench_single_rank_contract():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     line = _last_json(p.stdout)
-    for f in FIELDS:
-        assert f in line, f
     assert line["n_gpus"] == 1 and line["steps"] == 40 and line["warmup"] == 10 and line["value"] > 0
     assert line["dtype"] == "f64" and line["scaling"] == "weak" and line["vs_baseline"] is None
     r = line["roofline"]
@@ -162,6 +198,13 @@ def test_bench_eight_ranks_rehearsal_on_one_gpu():
                         "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "8", "--secondary",
                         "c4small"] + common, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
+    # the N = 8 line itself: within the size limit, with what the first real 8-GPU run will be read for
+    short = _last_json(p.stdout, detail=False)
+    assert short["n_gpus"] == 8 and len(short["per_rank_ms_per_step"]) == 8 and 0 <= short["rank_imbalance"] < 1
+    assert short["spectra_gather_ms"] > 0 and short["secondary"]["c4small"]["value"] > 0
+    spg = short["process_group"]
+    assert spg["world_size"] == 8 and len(spg["numa_node_per_rank"]) == 8 and len(spg["cpus_per_rank"]) == 8
+    assert spg["init_s"] > 0 and spg["roll_call_s"] >= 0 and spg["first_collective_s"] >= 0
     line = _last_json(p.stdout)
     assert line["n_gpus"] == 8 and line["config"]["columns_total"] == 8 and line["config"]["columns_per_gpu"] == 1
     assert len(line["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in line["per_rank_ms_per_step"])

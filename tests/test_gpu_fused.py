@@ -436,6 +436,15 @@ def test_graph_replay_of_refresh_free_iterations_equals_launch_by_launch(ctx, na
             nine, decades, on = rt.get("graph_replays")
             # the replays really happened: 101 iterations = the first refresh launched, then whole decades and runs of nine
             assert (on == 1 and decades >= 5 and nine >= 2) if graph == "1" else (nine == 0 and decades == 0)
+            # ... from few captures: each graph once, and once more after the setter -- a capture vouches for itself only
+            # (a run entered at decade boundaries alone must not re-capture the decade graph on every call)
+            builds_nine, builds_decade = rt.get("graph_builds")
+            assert (1 <= builds_decade <= 2 and 1 <= builds_nine <= 2) if graph == "1" else (builds_nine == builds_decade == 0)
+            if graph == "1":
+                for it in range(110, 160, 10):          # five more calls, each one whole decade, no setter in between
+                    rt.run(it, 10)
+                assert tuple(rt.get("graph_builds")) == (builds_nine, builds_decade)
+                assert rt.get("graph_replays")[1] == decades + 5
             return first, second
         finally:
             rt.close()
