@@ -1,0 +1,478 @@
+// Random-overlap mixing for FIVE wavefronts per SIMD (round 6): the algorithm of random_overlap.h -- run layout, one 32-bit key
+// per slot, bitonic network entered behind its tenth step, exact finish, DPP scan, interval search -- with the two things that
+// held the mixing kernel at four wavefronts per SIMD removed (profiles/r05_mix_occupancy.txt: t = 13 + 85 / w ms):
+//
+//  * LDS.  random_overlap.h keeps two 4 KB images: (pair sum, weight) by fill position for the fetch behind the network, then
+//    (sorted sum, abscissa) by rank for the search.  Here a key carries its CELL -- the low bits are i << 5 | j instead of the
+//    fill position 21 i + j; both ascend with the reference's fill order -- so whoever holds a key recomputes the sum and the
+//    weight from the two 20-entry curve tables (two reads, one add / one product: the bits the fill computed).  Nothing is
+//    written at fill time, the network's result is kept as 400 keys by rank (1.6 KB), and the only fp64 image left is the
+//    abscissae (3.6 KB): 6.9 KB per wavefront with the tables, 7.9 KB with the species list of k_rt_mix_species -- twenty
+//    wavefronts share a CU's 160 KB.
+//  * Registers.  The compiler hoists everything that depends on the lane alone out of the problem loop -- eight cell addresses,
+//    eight fill positions, scan and search offsets: 55 of the old kernel's 128 VGPRs (tools/vgpr_liveness.py).  Here a lane's
+//    place in the run layout is TWO packed dwords (LaneConst), unpacked behind an optimisation barrier in every problem
+//    (a dozen vector instructions), and what the phases derive from the lane id is derived from an opaque copy of it.
+//  * The sums are fetched in fp64 only where two neighbouring keys share a quantised sum (the exact finish of
+//    random_overlap.h can have work only there: q is monotone in K); otherwise the sorted keys are final as they are.
+//
+// Same permutation, same arithmetic, same bits as random_overlap.h (tests/test_gpu_stages.py::test_random_overlap_orderings_
+// vs_oracle holds the kernels to each other bit for bit).  Reference: kernels.cu:3263-3399, sort :3152-3171.
+#pragma once
+#include "random_overlap.h"
+
+namespace rol {
+
+using ro::Counters;
+using ro::Keys;
+using ro::N;
+using ro::NY;
+using ro::Pair;
+using ro::RANK0;
+using ro::SLOTS;
+
+constexpr int NTAB = 32;                 // entries per curve table: a 5-bit cell index never leaves it
+constexpr int LANE0 = RANK0 / SLOTS;     // the first lane that holds ranks (positions RANK0 ... RANK0 + 399: lanes 2 ... 51)
+constexpr int NLANES = N / SLOTS;
+constexpr int YBASE = (SLOTS + 1) * LANE0;   // padded index of position RANK0: the abscissa image starts there
+constexpr int NYIMG = (SLOTS + 1) * NLANES;
+// table entries beyond the 20 Gauss points: (inf, 0) everywhere, op[OP_LOW] = (-inf, 0)
+constexpr int OP_LOW = 21;
+constexpr unsigned HIGHKEY = 0xFFFFFFFFu;            // cell (31, 31): inf + inf, weight 0 x 0
+constexpr unsigned LOWKEY = (unsigned)OP_LOW << 5;   // q = 0 (sums have q >= 1), cell (21, 0): -inf + ip[0], weight 0
+
+struct Shared {
+    double Y[NYIMG];          // abscissae by padded position - YBASE: nine cells per lane, the ninth repeats the next lane's first
+    unsigned E[N];            // the sorted keys by rank
+    Pair op[NTAB], ip[NTAB];  // op: the curve that is stronger at y = 0 (outer fill loop), ip: the other one
+    double gy[NY];
+    // the re-binning of a PRESORTED tableau (random_overlap.h, prepare_presorted): per Gauss point the abscissae of the two
+    // ranks that bracket it and the LDS byte offsets of their cells' table entries (per rank: op entry | ip entry << 16)
+    double pre_y0[NY], pre_y1[NY];
+    unsigned long long pre_cells[NY];
+    unsigned pre_skipped, pad_;
+};
+static_assert(sizeof(Shared) <= 6880, "twenty wavefronts per CU: 8 KB each with the species list of k_rt_mix_species");
+static_assert(offsetof(Shared, op) % 16 == 0 && offsetof(Shared, op) >= 4 * sizeof(Pair), "aligned tables; op[-4] stays inside the struct");
+
+// A lane's place in the run layout (random_overlap.h, run_lane), packed: kept in two registers through the kernel and
+// unpacked per problem.
+//   a: byte offset of the fixed table entry | col << 13 | padlow << 14 | padhigh << 15 | byte offset of slot 0's varying entry << 16
+//   b: (i0 << 5 | j0) + 128 (the cell code of slot 0; i0 = -4 in front of a column piece) | (i0 + 4) << 11 | j0 << 16
+// col: the lane walks down a column (i steps, the code steps by 32) instead of along a row; padlow: its slots 0-3 are low
+// padding; padhigh: all its slots are high padding.
+struct LaneConst {
+    unsigned a, b;
+};
+
+__device__ __forceinline__ LaneConst lane_const(int lane) {
+    const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
+    const int blk = lane >> 1, idx0 = 8 * (lane & 1);
+    int i = NY, j = NY, col = 0, padlow = 0, padhigh = 1;   // default: high padding (reads the constant entries)
+    if (blk < 12) { i = blk; j = idx0; padhigh = 0; }                                              // row i, columns idx0 ...
+    else if (blk < 16) { j = 16 + (blk - 12); i = idx0 - 4; col = 1; padhigh = 0; padlow = idx0 == 0; }   // column j, rows 0 ... 11 behind
+                                                                                                   // four positions of low padding
+    else if (blk < 24) { i = 12 + (blk - 16); j = idx0; padhigh = 0; }                             // row i, columns idx0 ...
+    else if (blk < 28 && idx0 == 0) { j = 16 + (blk - 24); i = 12; col = 1; padhigh = 0; }         // column j, rows 12 ... 19
+    const unsigned fix = col ? IP + PS * j : OP + PS * i;
+    const unsigned var = col ? OP + PS * i : IP + PS * j;   // (i = -4: the four cells in front of op, inside E: any bits do)
+    LaneConst lc;
+    lc.a = fix | (unsigned)col << 13 | (unsigned)padlow << 14 | (unsigned)padhigh << 15 | var << 16;
+    lc.b = (unsigned)((i << 5) + j + 128) | (unsigned)(i + 4) << 11 | (unsigned)j << 16;
+    return lc;
+}
+
+__device__ __forceinline__ void prepare_presorted(Shared& sh, int lane);
+
+__device__ __forceinline__ LaneConst init(Shared& sh, int lane, const double* gauss_weight, const double* gauss_y) {
+    if (lane < NTAB) {
+        const bool real = lane < NY;
+        const double hw = real ? 0.5 * gauss_weight[lane] : 0.0;
+        sh.op[lane].hw = sh.ip[lane].hw = hw;
+        if (!real) {
+            sh.op[lane].v = lane == OP_LOW ? -__builtin_inf() : __builtin_inf();
+            sh.ip[lane].v = __builtin_inf();
+        }
+        if (real) sh.gy[lane] = gauss_y[lane];
+    }
+    prepare_presorted(sh, lane);
+    return lane_const(lane);
+}
+
+using ro::dpp_or_zero;
+using ro::padded;
+using ro::shfl;
+using ro::sync;
+using ro::wave_inclusive_sum;
+
+__device__ __forceinline__ double from_next_lane(double x) {   // wave_shl:1 (lane 63: 0)
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double from_prev_lane(double x) {   // wave_shr:1 (lane 0: 0)
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xF, 0xF, false));
+}
+
+template <int L>
+__device__ __forceinline__ double lane_value(double x) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), L), __builtin_amdgcn_readlane(__double2loint(x), L));
+}
+
+// the table entries of a key's cell: byte offsets from the start of op / ip.  CROSSING: bit 10 says that the two fields
+// have changed places (the second fill region of :3332-3365, where the inner curve runs on the outer loop)
+template <bool CROSSING>
+__device__ __forceinline__ void decode(unsigned key, unsigned& ao, unsigned& ai) {
+    const unsigned hi = (key >> 1) & 0x1F0u, lo = (key << 4) & 0x1F0u;
+    if (CROSSING) {
+        const bool swapped = (key & 1024u) != 0;
+        ao = swapped ? lo : hi;
+        ai = swapped ? hi : lo;
+    } else {
+        ao = hi;
+        ai = lo;
+    }
+}
+
+template <bool CROSSING>
+__device__ __forceinline__ double cell_sum(const Shared& sh, unsigned key) {
+    unsigned ao, ai;
+    decode<CROSSING>(key, ao, ai);
+    return *(const double*)((const char*)sh.op + ao) + *(const double*)((const char*)sh.ip + ai);
+}
+
+// The abscissae of the eight ranks a lane holds (exclusive prefix `run` of the weights before them) to LDS at pitch 9 per
+// lane; the ninth cell of a lane takes the NEXT lane's first abscissa, so that the image is a gap-free ascending array
+// (random_overlap.h, put_abscissae).  All 64 lanes call.
+__device__ __forceinline__ void put_abscissae(Shared& sh, int lane, const double (&g)[SLOTS], double run) {
+    const double y_first = fma(0.5, g[0], run);
+    const double y_next = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(y_first), 0x130, 0xF, 0xF, false),
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(y_first), 0x130, 0xF, 0xF, false));  // wave_shl:1
+    const bool mine = lane >= LANE0 && lane < LANE0 + NLANES;
+    double* y = sh.Y + (SLOTS + 1) * lane - YBASE;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        if (mine) y[r] = fma(0.5, g[r], run);  // = run + 0.5 g bit for bit (0.5 g is exact)
+        run += g[r];
+    }
+    if (mine) y[SLOTS] = y_next;  // (last lane: the high padding's abscissa, the total weight, above every Gauss point)
+}
+
+// re-binning (:3379-3396): the rank w >= 1 whose abscissa is the first above Gauss point `lane`'s (returned in yq), at most one
+// Gauss point per rank (random_overlap.h, locate: the same search on the same image, whose first cell is YBASE here)
+__device__ __forceinline__ int locate(const Shared& sh, int lane, double& yq, unsigned& skipped) {
+    int w = N + lane;
+    yq = 0.0;
+    if (lane < NY) {
+        yq = sh.gy[lane];
+        constexpr int P0 = padded(RANK0 + 1);                       // rank 1
+        constexpr int NP = padded(RANK0 + N - 1) + 1 - P0 + 1;      // ... rank 399 and the duplicate behind it
+        const char* Bb = (const char*)sh.Y;
+        unsigned pb = 8 * (P0 - YBASE);      // byte offset inside the image, which begins at padded index YBASE
+#pragma unroll
+        for (int len = NP; len > 1; len -= len / 2) {
+            const int half = len / 2;
+            pb = *(const double*)(Bb + pb + 8 * (half - 1)) > yq ? pb : pb + 8 * half;
+        }
+        pb += *(const double*)(Bb + pb) > yq ? 0u : 8u;
+        const unsigned pi = (pb >> 3) + YBASE;
+        w = (int)(pi - (__umul24(pi, 7282u) >> 16)) - RANK0;   // padded index -> position (minus pi / 9) -> rank
+    }
+    int wq = w;
+    const int wprev = __builtin_amdgcn_update_dpp(0, w, 0x138, 0xF, 0xF, false);   // wave_shr:1: the lane below's rank (no address register)
+    if (__ballot(lane >= 1 && lane < NY && w <= wprev) != 0) {  // never seen with Gauss-Legendre points and weights
+        int ll = lane, floor_ = -(1 << 20);
+        asm volatile("" : "+v"(ll), "+v"(floor_));   // this path's addresses and constants are made here, not kept in registers for it
+        int t = ll < NY ? w - ll : floor_;
+        for (int d = 1; d < 32; d <<= 1) {
+            const int up = __builtin_amdgcn_ds_bpermute((ll >= d ? ll - d : ll) << 2, t);
+            if (ll >= d) t = max(t, up);
+        }
+        wq = t + ll;
+        skipped += __popcll(__ballot(ll < NY && wq != w));
+    }
+    return wq;
+}
+
+__device__ __forceinline__ void prepare_presorted(Shared& sh, int lane) {
+    sync();  // the half weights and the Gauss points are in LDS
+    // exactly what mix() does with a tableau it finds presorted -- weights in rank order (rank w = cell (w / 20, w % 20)),
+    // their sum per lane, the wave scan, the abscissae, the interval search, the skip rule
+    const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
+    double g[SLOTS];
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const int w = SLOTS * lane + r - RANK0;
+        g[r] = (w >= 0 && w < N) ? sh.op[w / NY].hw * sh.ip[w % NY].hw : 0.0;
+    }
+    double csum = 0.0;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) csum += g[r];
+    const double run = wave_inclusive_sum(csum) - csum;
+    put_abscissae(sh, lane, g, run);
+    sync();
+    double yq;
+    unsigned skipped = 0;
+    const int wq = locate(sh, lane, yq, skipped);
+    double y0 = 0.0, y1 = 0.0;
+    unsigned long long cells = 0ull;
+    if (lane < NY && wq < N) {
+        y0 = sh.Y[padded(RANK0 + wq - 1) - YBASE];
+        y1 = sh.Y[padded(RANK0 + wq) - YBASE];
+        const unsigned c0 = (OP + PS * ((wq - 1) / NY)) | (IP + PS * ((wq - 1) % NY)) << 16;
+        const unsigned c1 = (OP + PS * (wq / NY)) | (IP + PS * (wq % NY)) << 16;
+        cells = (unsigned long long)c1 << 32 | c0;
+    }
+    if (lane < NY) {
+        sh.pre_y0[lane] = y0;
+        sh.pre_y1[lane] = y1;
+        sh.pre_cells[lane] = cells;
+    }
+    if (lane == 0) sh.pre_skipped = skipped;
+}
+
+// keys of the run layout for two ascending curves: key = q << TB | cell code, where the code orders equal quantised sums as
+// the reference's fill order does -- i << 5 | j without a crossing (fill position 20 i + j), and with one (:3332-3365 with the
+// stronger curve on the outer loop) i << 5 | j in the first region (j < yx: position j + yx i), 1 << 10 | j << 5 | i in the
+// second (position i + 20 j, behind all of the first).  HI: sh_bits >= 32.  Nothing is written: the cell IS the address.
+template <bool CROSSING, bool HI>
+__device__ __forceinline__ void fill_runs(const Shared& sh, LaneConst lc, Keys& v, int yx, int hmin, int sh_bits) {
+    constexpr int TB = CROSSING ? 11 : 10;
+    const char* base = (const char*)&sh;
+    const unsigned fix = lc.a & 0x1FFFu, var = (lc.a >> 16) & 0x1FFFu;
+    const bool col = (lc.a & (1u << 13)) != 0;
+    const unsigned nlow = (unsigned)__builtin_amdgcn_sbfe((int)lc.a, 14, 1), padhi = (unsigned)__builtin_amdgcn_sbfe((int)lc.a, 15, 1);  // 0 or ~0
+    const unsigned aklo = ~nlow, oklo = (nlow & LOWKEY) | padhi;
+    const double F = *(const double*)(base + fix);
+    const int t0 = (int)(lc.b & 0x7FFu) - 128, tstep = col ? 32 : 1;
+    const int i0 = (int)((lc.b >> 11) & 31u) - 4, j0 = (int)((lc.b >> 16) & 31u);
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const double K = F + *(const double*)(base + var + (unsigned)sizeof(Pair) * r);   // padding: inf, or any bits (masked below)
+        int t = t0 + tstep * r;
+        if (CROSSING) {
+            const int i = col ? i0 + r : i0, j = col ? j0 : j0 + r;
+            t = j < yx ? t : (1 << 10 | j << 5 | i);
+        }
+        const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
+        const unsigned q = HI ? dh >> (sh_bits - 32) : __builtin_amdgcn_alignbit(dh, (unsigned)__double2loint(K), sh_bits);
+        const unsigned key = (q << TB) + (unsigned)t;
+        v.k[r] = r < SLOTS / 2 ? (key & aklo) | oklo : key | padhi;
+    }
+}
+
+// rare path (a curve that is not ascending): positions in fill order, the whole network
+template <bool CROSSING>
+__device__ __forceinline__ void fill_any(const Shared& sh, int lane, Keys& v, int yx, int hmin, int sh_bits) {
+    constexpr int TB = CROSSING ? 11 : 10;
+    unsigned qmax = (1u << (32 - TB)) - 1u, lowkey = LOWKEY, inv20 = 52429;
+    asm volatile("" : "+v"(qmax), "+v"(lowkey), "+v"(inv20));   // a rare path: its constants are made here, not kept in registers for it
+    const int nfirst = NY * yx;
+    const int inv_yx = (1048576 + yx - 1) / yx;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        const int e = 64 * r + lane - RANK0;   // position 64 r + lane: RANK0 positions of low padding, the sums in fill order, high padding
+        unsigned key = e < 0 ? lowkey : HIGHKEY;
+        if (e >= 0 && e < N) {
+            int i = (int)(__umul24(e, inv20) >> 20), j = e - NY * i;   // e / 20 (exact below 512), e % 20
+            bool second = false;
+            if (CROSSING) {
+                const bool first = e < nfirst;
+                const int q = (int)(__umul24(e, first ? (unsigned)inv_yx : inv20) >> 20);   // e / yx, e / 20 (exact below 512)
+                const int rem = e - __umul24(q, first ? yx : NY);
+                i = first ? q : rem;
+                j = first ? rem : q;
+                second = !first;
+            }
+            const double K = sh.op[i].v + sh.ip[j].v;
+            const int dh = max(__double2hiint(K) - hmin, 0);
+            unsigned q = sh_bits >= 32 ? (unsigned)dh >> (sh_bits - 32)
+                                       : __builtin_amdgcn_alignbit((unsigned)dh, (unsigned)__double2loint(K), sh_bits);
+            q = min(max(q, 1u), qmax);
+            key = q << TB | (second ? (1u << 10 | (unsigned)j << 5 | (unsigned)i) : ((unsigned)i << 5 | (unsigned)j));
+        }
+        v.k[r] = key;
+    }
+}
+
+// Behind the network: the exact order, the keys by rank to LDS, the abscissae; returns this lane's Gauss point re-binned.
+template <bool CROSSING>
+__device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v, double my_mix, Counters& cnt) {
+    constexpr int TB = CROSSING ? 11 : 10;
+    const bool mine = lane >= LANE0 && lane < LANE0 + NLANES;
+    RO_MARK("finish");
+    {
+        // q is monotone in the sum: the quantised order can differ from the exact one only between neighbours that share a q
+        const unsigned nk = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.k[0], 0x130, 0xF, 0xF, false);   // wave_shl:1: the next lane's first key
+        bool eq = ((v.k[SLOTS - 1] ^ nk) >> TB) == 0;
+#pragma unroll
+        for (int r = 0; r + 1 < SLOTS; r++) eq = eq || ((v.k[r] ^ v.k[r + 1]) >> TB) == 0;
+        if (__ballot(eq && mine) != 0) {
+            double K[SLOTS];
+#pragma unroll
+            for (int r = 0; r < SLOTS; r++) K[r] = cell_sum<CROSSING>(sh, v.k[r]);   // padding: -inf, inf
+            int passes = 0;
+            for (;;) {   // odd-even transposition on the exact sums (strict '>': stable), as random_overlap.h; the keys go along
+                bool inv = false;
+#pragma unroll
+                for (int r = 0; r + 1 < SLOTS; r++) inv = inv || K[r] > K[r + 1];
+                const double kn = from_next_lane(K[0]);
+                inv = inv || (lane < 63 && K[SLOTS - 1] > kn);
+                if (__ballot(inv) == 0 || passes >= 2 * ro::LDS_N) break;
+                passes++;
+                auto ce = [&](int a, int b) {
+                    const bool sw = K[a] > K[b];
+                    const double ka = K[a], kb = K[b];
+                    const unsigned ea = v.k[a], eb = v.k[b];
+                    K[a] = sw ? kb : ka; K[b] = sw ? ka : kb;
+                    v.k[a] = sw ? eb : ea; v.k[b] = sw ? ea : eb;
+                };
+                ce(0, 1); ce(2, 3); ce(4, 5); ce(6, 7);
+                ce(1, 2); ce(3, 4); ce(5, 6);
+                // across the lanes: every lane looks at its neighbours' values of BEFORE the exchange (DPP: no address registers)
+                const double kn0 = from_next_lane(K[0]), kp7 = from_prev_lane(K[SLOTS - 1]);
+                const bool sw_hi = lane < 63 && K[SLOTS - 1] > kn0, sw_lo = lane > 0 && kp7 > K[0];
+                const unsigned en0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.k[0], 0x130, 0xF, 0xF, false);
+                const unsigned ep7 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.k[SLOTS - 1], 0x138, 0xF, 0xF, false);
+                if (sw_hi) { K[SLOTS - 1] = kn0; v.k[SLOTS - 1] = en0; }
+                if (sw_lo) { K[0] = kp7; v.k[0] = ep7; }
+            }
+            cnt.passes += passes;
+        }
+    }
+    RO_MARK("scan");
+    if (mine) {   // the keys by rank: what the interpolation below reads its two sums from
+        uint4* e = (uint4*)(sh.E + SLOTS * (lane - LANE0));
+        e[0] = make_uint4(v.k[0], v.k[1], v.k[2], v.k[3]);
+        e[1] = make_uint4(v.k[4], v.k[5], v.k[6], v.k[7]);
+    }
+    // the weights in rank order, from the cells; cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376)
+    double g[SLOTS];
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) {
+        unsigned ao, ai;
+        decode<CROSSING>(v.k[r], ao, ai);
+        g[r] = *(const double*)((const char*)sh.op + ao + 8) * *(const double*)((const char*)sh.ip + ai + 8);   // padding: 0
+    }
+    double csum = 0.0;
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) csum += g[r];
+    const double run = wave_inclusive_sum(csum) - csum;
+    put_abscissae(sh, lane, g, run);
+    sync();
+    RO_MARK("search");
+    double yq;
+    const int wq = locate(sh, lane, yq, cnt.skipped);
+    RO_MARK("interpolate");
+    double out = my_mix;  // w = 400: the walk ran out of sums, the reference leaves the entry as it was
+    if (lane < NY && wq < N) {
+        const double K0 = cell_sum<CROSSING>(sh, sh.E[wq - 1]), K1 = cell_sum<CROSSING>(sh, sh.E[wq]);
+        const double y0 = sh.Y[padded(RANK0 + wq - 1) - YBASE], y1 = sh.Y[padded(RANK0 + wq) - YBASE];
+        out = (K0 * (y1 - yq) + K1 * (yq - y0)) / (y1 - y0);
+    }
+    RO_MARK("end");
+    return out;
+}
+
+// One problem.  Lanes 0..19 pass the running mix and the new absorber's (already scaled) k-coefficients at their Gauss
+// point and receive the mixed value (kernels.cu:3293-3396, ro_method == 1, s > 0, ny == 20).  All 64 lanes must call.
+__device__ __forceinline__ double mix(Shared& sh, LaneConst lc, int lane, double my_mix, double my_add, Counters& cnt) {
+    RO_MARK("prologue");
+    // what depends on the lane alone is derived again in every problem, from these opaque copies: it does not occupy
+    // registers between the problems
+    asm volatile("" : "+v"(lane), "+v"(lc.a), "+v"(lc.b));
+    // corners of the tableau, wave-uniform (v_readlane: scalar results, no address registers)
+    const double m0 = lane_value<0>(my_mix), a0 = lane_value<0>(my_add), m19 = lane_value<NY - 1>(my_mix), a19 = lane_value<NY - 1>(my_add);
+    // less than 1 % of the other everywhere: correlated-k (:3297-3310)
+    if ((0.01 * m0 > a19) || (0.01 * a0 > m19)) return my_mix + my_add;
+    const bool mix_first = m0 > a0;
+    sync();  // the previous problem's readers are done with sh
+    if (lane < NY) {
+        sh.op[lane].v = mix_first ? my_mix : my_add;
+        sh.ip[lane].v = mix_first ? my_add : my_mix;
+    }
+    sync();
+    // last crossing of the two curves (:3321-3329); are both k-distributions (ascending)?  Do the rows of the tableau overlap?
+    bool cross = false, down = false, over = false, touch = false;
+    if (lane >= 1 && lane < NY) {
+        const double po = sh.op[lane - 1].v, pi = sh.ip[lane - 1].v;
+        const double pm = mix_first ? po : pi, pa = mix_first ? pi : po;
+        cross = (my_mix > my_add) != (pm > pa);
+        down = my_mix < pm || my_add < pa;
+        const double mo = mix_first ? my_mix : my_add;  // outer[lane]
+        const double row_end = po + (mix_first ? a19 : m19), next_start = mo + (mix_first ? a0 : m0);
+        over = row_end > next_start;
+        touch = row_end >= next_start;
+    }
+    const unsigned long long cmask = __ballot(cross);
+    const int yx = cmask ? 63 - __clzll((long long)cmask) : NY;
+    const bool monotone = __ballot(down) == 0;
+    const bool rows_apart = __ballot(over) == 0;
+    // row 11 ends below the start of row 12: the two halves of the run layout are sorted lists that follow each other
+    const bool halves_apart = ((__ballot(touch) >> 12) & 1ull) == 0;
+    RO_MARK("fill");
+    if (monotone && yx == NY && rows_apart) {
+        // nothing to sort, to scan or to search: rank w is cell (w / 20, w % 20) (random_overlap.h, prepare_presorted)
+        double out = my_mix;
+        if (lane < NY) {
+            const unsigned long long cells = sh.pre_cells[lane];
+            if (cells != 0ull) {
+                const char* base = (const char*)&sh;
+                const unsigned c0 = (unsigned)cells, c1 = (unsigned)(cells >> 32);
+                const double K0 = ((const Pair*)(base + (c0 & 0xFFFFu)))->v + ((const Pair*)(base + (c0 >> 16)))->v;
+                const double K1 = ((const Pair*)(base + (c1 & 0xFFFFu)))->v + ((const Pair*)(base + (c1 >> 16)))->v;
+                const double yq = sh.gy[lane], y0 = sh.pre_y0[lane], y1 = sh.pre_y1[lane];
+                out = (K0 * (y1 - yq) + K1 * (yq - y0)) / (y1 - y0);
+            }
+        }
+        cnt.skipped += sh.pre_skipped;
+        return out;
+    }
+    double kmin = m0 + a0, kmax = m19 + a19;
+    if (!monotone) {  // the extreme sums are not at the corners of the tableau
+        double mn1 = sh.op[0].v, mx1 = mn1, mn2 = sh.ip[0].v, mx2 = mn2;
+#pragma unroll 1
+        for (int j = 1; j < NY; j++) {
+            mn1 = fmin(mn1, sh.op[j].v); mx1 = fmax(mx1, sh.op[j].v);
+            mn2 = fmin(mn2, sh.ip[j].v); mx2 = fmax(mx2, sh.ip[j].v);
+        }
+        kmin = mn1 + mn2;
+        kmax = mx1 + mx2;
+    }
+    // key scale (wave-uniform): q = (bits(K) - (hmin << 32)) >> sh with 1 <= q < 2^QB for Kmin <= K <= Kmax (q = 0 is the
+    // low padding's), QB = 22 bits without a crossing, 21 with one (random_overlap.h has 23: its tie-break is nine bits)
+    const int QB = 32 - (yx == NY ? 10 : 11);
+    const int hk = __builtin_amdgcn_readfirstlane(__double2hiint(kmin));
+    const unsigned long long span =
+        ((unsigned long long)(unsigned)(__builtin_amdgcn_readfirstlane(__double2hiint(kmax)) - hk) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(kmax));
+    const int bl0 = span ? 64 - __clzll((long long)span) : 0;
+    const int bias = 1 << max(0, bl0 - QB - 31);                       // in units of 2^32: >= 2^sh once sh is settled below
+    const int hmin = hk - bias;
+    const unsigned long long dmax = span + ((unsigned long long)(unsigned)bias << 32);
+    const int bl = 64 - __clzll((long long)dmax);
+    const int sh_bits = bl > QB ? bl - QB : 0;
+    Keys v;
+    ro::Lane lnc;   // the network reads the three low lane bits as masks from here
+#pragma unroll
+    for (int t = 0; t < 3; t++) lnc.c[t] = (unsigned)__builtin_amdgcn_sbfe(lane, t, 1);
+    if (monotone) {
+        if (yx == NY) {
+            if (sh_bits >= 32) fill_runs<false, true>(sh, lc, v, yx, hmin, sh_bits);
+            else fill_runs<false, false>(sh, lc, v, yx, hmin, sh_bits);
+        } else {
+            if (sh_bits >= 32) fill_runs<true, true>(sh, lc, v, yx, hmin, sh_bits);
+            else fill_runs<true, false>(sh, lc, v, yx, hmin, sh_bits);
+        }
+        RO_MARK("network");
+        ro::sort512_from_runs16(v, lane, lnc, halves_apart);
+    } else {
+        if (yx == NY) fill_any<false>(sh, lane, v, yx, hmin, sh_bits);
+        else fill_any<true>(sh, lane, v, yx, hmin, sh_bits);
+        ro::sort512(v, lane, lnc);
+    }
+    if (yx == NY) return finish_and_rebin<false>(sh, lane, v, my_mix, cnt);
+    return finish_and_rebin<true>(sh, lane, v, my_mix, cnt);
+}
+
+}  // namespace rol

@@ -17,6 +17,7 @@
 // Columns whose loop has ended (done[c]) are skipped on the device: no host round trip inside a refresh.
 #pragma once
 #include "random_overlap.h"
+#include "random_overlap_lean.h"
 #include "two_stream.h"
 
 namespace hx {
@@ -126,11 +127,23 @@ __global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, doub
     mmm_lay[(size_t)col * I + i] = num / tot * HX_AMU;
 }
 
-constexpr int MIX_MAX_ABSORBERS = 48;  // LDS images of the species list: 1 KB next to ro::Shared; together <= 10 KB, so that
-                                       // 16 wavefronts share a CU's 160 KB
+constexpr int MIX_MAX_ABSORBERS = 48;  // LDS images of the species list: 1 KB next to the mixing images
 
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_rt_mix_species(MixArgs a) {
-    __shared__ ro::Shared sh;
+// HX_MIX_LEAN = 1 (default): rol::mix (random_overlap_lean.h) -- 7.9 KB of LDS and at most 96 VGPRs, five wavefronts per SIMD;
+// 0: ro::mix as until round 5 (10.2 KB, 128 VGPRs, four), kept for the same-box A/B (tools/ab_mix_lean.sh)
+#ifndef HX_MIX_LEAN
+#define HX_MIX_LEAN 1
+#endif
+#if HX_MIX_LEAN
+namespace mixro = rol;
+#define HX_MIX_WAVES_PER_EU 5
+#else
+namespace mixro = ro;
+#define HX_MIX_WAVES_PER_EU 4
+#endif
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HX_MIX_WAVES_PER_EU))) k_rt_mix_species(MixArgs a) {
+    __shared__ mixro::Shared sh;
     // what the species loop needs per absorber, staged once per wavefront: table base, correlated-k flag, and -- per
     // level -- the factor vmr * mass / mu.  (Read straight from the argument block these were chains of dependent
     // global loads inside the loop: the scalar registers are all taken, so the compiler fetched them through the
@@ -143,8 +156,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
     // 16 bytes per lane and point written and read back (2.1 GB of the 2.5 GB WRITE_SIZE of round 2's launch)
     __shared__ double s_blend[4];
     const int lane = threadIdx.x;
+#if HX_MIX_LEAN
+    const rol::LaneConst ln = rol::init(sh, lane, a.gauss_w, a.gauss_y);
+#else
     ro::Lane ln;
     ro::init(sh, ln, lane, a.gauss_w, a.gauss_y);
+#endif
     const int nabs = a.nabs;
     if (lane < nabs) {
         const int s = a.abs_list[lane];
@@ -184,14 +201,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
             lev_cur = cl;
             const bool lay = lev < a.L;
             const int i = lay ? lev : lev - a.L;
-            skip = a.done[col] != 0;
+            skip = __builtin_amdgcn_readfirstlane(a.done[col]) != 0;
             tp = (lay ? a.tp_lay : a.tp_int)[(size_t)col * a.I + i];
             const double* fac = (lay ? a.fac_lay : a.fac_int) + ((size_t)col * a.I + i) * a.S;
             out_level = (lay ? a.opac_wg_lay : a.opac_wg_int) + (size_t)col * nc * a.I + nc * i;
-            pl_dd = st_p * tp.pdown + st_t * tp.tdown;
-            pl_ud = st_p * tp.pup + st_t * tp.tdown;
-            pl_du = st_p * tp.pdown + st_t * tp.tup;
-            pl_uu = st_p * tp.pup + st_t * tp.tup;
+            // the level's table nodes are the same in every lane: as scalars (the loads above came through the vector path), so
+            // that the four plane offsets are scalar arithmetic and live in scalar registers
+            const int pdown = __builtin_amdgcn_readfirstlane(tp.pdown), pup = __builtin_amdgcn_readfirstlane(tp.pup);
+            const int tdown = __builtin_amdgcn_readfirstlane(tp.tdown), tup = __builtin_amdgcn_readfirstlane(tp.tup);
+            pl_dd = st_p * pdown + st_t * tdown;
+            pl_ud = st_p * pup + st_t * tdown;
+            pl_du = st_p * pdown + st_t * tup;
+            pl_uu = st_p * pup + st_t * tup;
             ro::sync();
             int ls = lane;
             asm volatile("" : "+v"(ls));  // addresses derived from the lane id are rebuilt here, once per level, instead of
@@ -201,7 +222,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
                 s_blend[0] = tp.pup - tp.p; s_blend[1] = tp.p - tp.pdown;
                 s_blend[2] = tp.tup - tp.t; s_blend[3] = tp.t - tp.tdown;
             }
-            tcase = (tp.pdown != tp.pup ? 1 : 0) | (tp.tdown != tp.tup ? 2 : 0);
+            tcase = (pdown != pup ? 1 : 0) | (tdown != tup ? 2 : 0);
             ro::sync();
         }
         if (skip) continue;
@@ -231,7 +252,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
                 const double raw = ro::shfl((ro::NY * j + y) << 2, raw_mine);  // lanes 0..19: from group j
                 const double add = s_fac[kb + j] * raw;
                 if ((s_info[kb + j] & 1) == 0) mixv += add;
-                else mixv = ro::mix(sh, ln, lane, mixv, add, cnt);
+                else mixv = mixro::mix(sh, ln, lane, mixv, add, cnt);
             }
         }
         if (lane < a.Y) out_level[off] = mixv;

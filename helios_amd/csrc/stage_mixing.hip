@@ -2,6 +2,7 @@
 // H2O Rayleigh scattering, scattering-cross-section accumulation, total asymmetry parameter.
 #include "two_stream.h"
 #include "random_overlap.h"
+#include "random_overlap_lean.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -390,6 +391,39 @@ k_add_to_mixed_opac_q32(const double* __restrict__ vmr, const double* __restrict
     ro::flush(cnt, lane, diag);
 }
 
+// ---- random overlap, default since round 6: the same network on keys that carry their cell (random_overlap_lean.h) --
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5)))
+k_add_to_mixed_opac_lean(const double* __restrict__ vmr, const double* __restrict__ opac_spec,
+                         double* __restrict__ opac_wg, const double* __restrict__ meanmolmass,
+                         const double* __restrict__ gauss_weight, const double* __restrict__ gauss_y,
+                         double mass_spec, int nbin, int nlev, unsigned long long* __restrict__ diag) {
+    __shared__ rol::Shared sh;
+    const int lane = threadIdx.x;
+    const rol::LaneConst lc = rol::init(sh, lane, gauss_weight, gauss_y);
+    const long long npair = (long long)nbin * nlev;
+    const long long chunk = (npair + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * chunk, p1 = min(npair, p0 + chunk);
+    int i_cur = -1;
+    double fac = 0.0;
+    ro::Counters cnt;
+    for (long long pair = p0; pair < p1; pair++) {
+        const int i = (int)(pair / nbin);
+        if (i != i_cur) {
+            i_cur = i;
+            fac = vmr[i] * mass_spec / meanmolmass[i];  // (vmr * mass) / mu, then times kappa (:3293)
+        }
+        const size_t base = (size_t)RO_NY * pair;  // = ny*x + ny*nbin*i
+        double my_mix = 0.0, my_add = 0.0;
+        if (lane < RO_NY) {
+            my_mix = opac_wg[base + lane];
+            my_add = fac * opac_spec[base + lane];
+        }
+        const double out = rol::mix(sh, lc, lane, my_mix, my_add, cnt);
+        if (lane < RO_NY) opac_wg[base + lane] = out;
+    }
+    ro::flush(cnt, lane, diag);
+}
+
 __global__ void __launch_bounds__(256)
 k_add_correlated_k(const double* __restrict__ vmr, const double* __restrict__ opac_spec, double* __restrict__ opac_wg,
                    const double* __restrict__ meanmolmass, double mass_spec, int ny, int nbin, int nlev) {
@@ -446,10 +480,11 @@ int hx_add_to_mixed_opac(hx_context* ctx, const double* vmr, const double* opac_
         return hx_fail(ctx, HX_E_RO_NY, "random-overlap mixing needs ny == 20 (got %d)", ny);
     const long long npair = (long long)nbin * nlay_or_nint;
     const int grid = (int)min(npair, (long long)256 * 12 * 16);
-    static const int sort_kind = [] {  // cross-check / A-B knob, read once: q32 (default), bitonic (fp64 network), rank
+    static const int sort_kind = [] {  // cross-check / A-B knob, read once: lean (default), q32 (rounds 2-5), bitonic (fp64 network), rank
         const char* e = getenv("HELIOS_RO_SORT");
         if (e != nullptr && strcmp(e, "rank") == 0) return 2;
         if (e != nullptr && strcmp(e, "bitonic") == 0) return 1;
+        if (e != nullptr && strcmp(e, "q32") == 0) return 3;
         return 0;
     }();
     if (sort_kind == 2)
@@ -463,9 +498,12 @@ int hx_add_to_mixed_opac(hx_context* ctx, const double* vmr, const double* opac_
     else if (!ro_possible)
         k_add_correlated_k<<<dim3(hx_cdiv((long long)ny * nbin, 1024), nlay_or_nint), 256, 0, ctx->stream>>>(
             vmr, opac_spec, opac_wg, meanmolmass, mass_spec, ny, nbin, nlay_or_nint);
-    else
+    else if (sort_kind == 3)
         k_add_to_mixed_opac_q32<<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
                                                              gauss_y, mass_spec, nbin, nlay_or_nint, ctx->diag);
+    else
+        k_add_to_mixed_opac_lean<<<grid, 64, 0, ctx->stream>>>(vmr, opac_spec, opac_wg, meanmolmass, gauss_weight,
+                                                              gauss_y, mass_spec, nbin, nlay_or_nint, ctx->diag);
     HX_LAUNCH_CHECK(ctx);
     return 0;
 }

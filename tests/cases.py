@@ -23,7 +23,7 @@ class Case(dict):
 def make_case(nbin=13, nlayer=9, ny=20, ntemp=7, npress=6, seed=20241, scat=1, dir_beam=0,
               clouds=0, scat_corr=0, g_0=0.0, iso=0, geom_zenith_corr=0, albedo=0.0,
               plancktable_dim=400, plancktable_step=10, thin_top=False, T_star=5000.0,
-              zenith_deg=60.0, f_factor=0.5, T_intern=100.0):
+              zenith_deg=60.0, f_factor=0.5, T_intern=100.0, p_boa=1e9):
     rng = np.random.default_rng(seed)
     c = Case()
     c.nbin, c.nlayer, c.ninterface, c.ny = nbin, nlayer, nlayer + 1, ny
@@ -60,7 +60,7 @@ def make_case(nbin=13, nlayer=9, ny=20, ntemp=7, npress=6, seed=20241, scat=1, d
         c.opac_scat_cross = c.opac_scat_cross * 1e3
     c.opac_meanmass = syn.meanmass_table(ntemp, npress) * (1.0 + 0.1 * rng.uniform(-1, 1, ntemp * npress))
     p_toa = 1e-1 if not thin_top else 1e-6
-    c.p_lay, c.p_int = syn.pressure_levels(1e9, p_toa, nlayer)
+    c.p_lay, c.p_int = syn.pressure_levels(p_boa, p_toa, nlayer)
     c.delta_colmass = (c.p_int[:-1] - c.p_int[1:]) / c.g
     c.delta_col_upper = (c.p_lay - c.p_int[1:]) / c.g
     c.delta_col_lower = (c.p_int[:-1] - c.p_lay) / c.g

@@ -35,6 +35,11 @@ FUSED_CONFIGS = {
     "L200_i2s": dict(nbin=6, nlayer=200, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),  # config-5 flags: 4 planes + clouds
     "L512": dict(nbin=3, nlayer=512, dir_beam=1),   # the fused path's largest column: k=64, 16 rows per lane
     "smallest": dict(nbin=2, nlayer=4),             # two bins, four layers (the height integration needs a layer below 10 bar)
+    # fewer half-layers than the eight lanes of the smallest tiling (H = 6, 4 < k = 8: lanes without a row); a deeper bottom
+    # boundary, because calculate_height_z (host_functions.py) starts from the lowest layer centre at >= 10 bar and the
+    # three layers of the standard grid have none -- that, not the kernels, is why round 5's "L3" case became "L4"
+    "L3": dict(nbin=5, nlayer=3, p_boa=1e11),
+    "L2_beam": dict(nbin=3, nlayer=2, p_boa=1e11, dir_beam=1, albedo=0.2),
     # isothermal layers (fband_iso / calc_trans_iso / fdir_iso): one segment per layer
     "iso": dict(iso=1, nbin=11, nlayer=20),
     "iso_clouds_beam": dict(iso=1, nbin=9, nlayer=37, clouds=1, scat_corr=1, g_0=0.2, dir_beam=1, albedo=0.15),
@@ -255,6 +260,10 @@ MATRIX_CONFIGS = {
     "L200_beam": dict(nbin=7, nlayer=200, dir_beam=1, albedo=0.2),
     "L400_clouds": dict(nbin=5, nlayer=400, clouds=1, g_0=0.1, albedo=0.1),
     "L4": dict(nbin=10, nlayer=4, albedo=0.3),
+    # H = 6 and 4 half-layers on k = 8 lanes (see FUSED_CONFIGS["L3"] for the bottom pressure), isothermal: H = 5 segments
+    "L3": dict(nbin=10, nlayer=3, albedo=0.3, p_boa=1e11),
+    "L2_beam": dict(nbin=6, nlayer=2, albedo=0.2, dir_beam=1, p_boa=1e11),
+    "iso_L5": dict(iso=1, nbin=7, nlayer=5, albedo=0.1),
     "ny1": dict(ny=1, nbin=17, albedo=0.1),
     "L105_i2s": dict(nbin=12, nlayer=105, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),
 }

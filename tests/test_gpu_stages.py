@@ -207,10 +207,11 @@ def _ro_run(impl):
 
 
 def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
-    """the quantised-key network with exact finish (default) against the oracle's adjacent-swap sort, incl. problems full
-    of equal sums, and against the two other device variants -- the fp64 bitonic network (HELIOS_RO_SORT=bitonic) and the
-    all-pairs ranking (HELIOS_RO_SORT=rank); the knob is read once per process -> child processes.  All three must
-    agree bit for bit."""
+    """the quantised-key network with exact finish (default: the lean kernel of round 6, whose keys carry their cell) against
+    the oracle's adjacent-swap sort, incl. problems full of equal sums, and against the three other device variants -- the
+    kernel of rounds 2-5 (HELIOS_RO_SORT=q32: fill positions as tie-break, sums and weights through LDS images), the fp64
+    bitonic network (HELIOS_RO_SORT=bitonic) and the all-pairs ranking (HELIOS_RO_SORT=rank); the knob is read once per
+    process -> child processes.  All four must agree bit for bit."""
     import os
     import subprocess
     import sys
@@ -224,7 +225,7 @@ def test_random_overlap_orderings_vs_oracle(hip, port, tmp_path):
         # decades apart multiply that by K[w] / K[w-1]
         np.testing.assert_allclose(got[k], want[k], rtol=2e-11 if k == "wide" else 5e-12, err_msg=k)
     here = os.path.dirname(os.path.abspath(__file__))
-    for kind in ("rank", "bitonic"):
+    for kind in ("q32", "rank", "bitonic"):
         out = tmp_path / (kind + ".npz")
         code = ("import sys, numpy as np; sys.path.insert(0, %r); import test_gpu_stages as t; from impls import hip_impl; "
                 "np.savez(%r, **t._ro_run(hip_impl()))" % (here, str(out)))
