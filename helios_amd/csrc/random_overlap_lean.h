@@ -169,11 +169,18 @@ __device__ __forceinline__ int locate(const Shared& sh, int lane, double& yq, un
         constexpr int NP = padded(RANK0 + N - 1) + 1 - P0 + 1;      // ... rank 399 and the duplicate behind it
         const char* Bb = (const char*)sh.Y;
         unsigned pb = 8 * (P0 - YBASE);      // byte offset inside the image, which begins at padded index YBASE
+        // Lower bound over the NP = 449 cells: halving gives the steps 224, 112, 56, 28, 14, 7, 4, 2, 1 cells -- the first five
+        // are 7 << k, written as `select 0 or 7, shift-add`: as byte counts they are 32-bit literals, which the select cannot
+        // take as an operand and the compiler therefore parks in five registers for the whole kernel.  Same probes as before.
+        static_assert(NP == 449, "the step sequence below is halving 449 cells");
 #pragma unroll
-        for (int len = NP; len > 1; len -= len / 2) {
-            const int half = len / 2;
-            pb = *(const double*)(Bb + pb + 8 * (half - 1)) > yq ? pb : pb + 8 * half;
+        for (int k = 8; k >= 4; k--) {      // 7 << (k - 3) cells = 7 << k bytes
+            const unsigned m = *(const double*)(Bb + pb + (7u << k) - 8) > yq ? 0u : 7u;
+            pb += m << k;
         }
+        pb += *(const double*)(Bb + pb + 56 - 8) > yq ? 0u : 56u;
+#pragma unroll
+        for (int st = 32; st >= 8; st >>= 1) pb += *(const double*)(Bb + pb + st - 8) > yq ? 0u : (unsigned)st;
         pb += *(const double*)(Bb + pb) > yq ? 0u : 8u;
         const unsigned pi = (pb >> 3) + YBASE;
         w = (int)(pi - (__umul24(pi, 7282u) >> 16)) - RANK0;   // padded index -> position (minus pi / 9) -> rank
@@ -184,8 +191,9 @@ __device__ __forceinline__ int locate(const Shared& sh, int lane, double& yq, un
         int ll = lane, floor_ = -(1 << 20);
         asm volatile("" : "+v"(ll), "+v"(floor_));   // this path's addresses and constants are made here, not kept in registers for it
         int t = ll < NY ? w - ll : floor_;
-        for (int d = 1; d < 32; d <<= 1) {
-            const int up = __builtin_amdgcn_ds_bpermute((ll >= d ? ll - d : ll) << 2, t);
+#pragma unroll 1
+        for (int d = 1; d < 32; d <<= 1) {   // (rolled: no per-step constants)
+            const int up = __builtin_amdgcn_ds_bpermute(max(ll - d, 0) << 2, t);
             if (ll >= d) t = max(t, up);
         }
         wq = t + ll;
@@ -242,7 +250,9 @@ __device__ __forceinline__ void fill_runs(const Shared& sh, LaneConst lc, Keys& 
     const unsigned fix = lc.a & 0x1FFFu, var = (lc.a >> 16) & 0x1FFFu;
     const bool col = (lc.a & (1u << 13)) != 0;
     const unsigned nlow = (unsigned)__builtin_amdgcn_sbfe((int)lc.a, 14, 1), padhi = (unsigned)__builtin_amdgcn_sbfe((int)lc.a, 15, 1);  // 0 or ~0
-    const unsigned aklo = ~nlow, oklo = (nlow & LOWKEY) | padhi;
+    unsigned lowkey = LOWKEY;
+    asm volatile("" : "+v"(lowkey));   // made here: as the literal operand of an and-or it would be parked in a register for the whole kernel
+    const unsigned aklo = ~nlow, oklo = (nlow & lowkey) | padhi;
     const double F = *(const double*)(base + fix);
     const int t0 = (int)(lc.b & 0x7FFu) - 128, tstep = col ? 32 : 1;
     const int i0 = (int)((lc.b >> 11) & 31u) - 4, j0 = (int)((lc.b >> 16) & 31u);
@@ -301,24 +311,34 @@ __device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v
     constexpr int TB = CROSSING ? 11 : 10;
     const bool mine = lane >= LANE0 && lane < LANE0 + NLANES;
     RO_MARK("finish");
+    // every slot's cell, decoded once: the byte offsets of its two table entries serve the sums (the exact test below) and
+    // the weights (the scan).  Sums and weights are read in two halves each, so that at most eight reads are in flight.
+    const char* ob = (const char*)sh.op;
+    const char* ib = (const char*)sh.ip;
+    unsigned ao[SLOTS], ai[SLOTS];
+#pragma unroll
+    for (int r = 0; r < SLOTS; r++) decode<CROSSING>(v.k[r], ao[r], ai[r]);
     {
-        // q is monotone in the sum: the quantised order can differ from the exact one only between neighbours that share a q
-        const unsigned nk = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.k[0], 0x130, 0xF, 0xF, false);   // wave_shl:1: the next lane's first key
-        bool eq = ((v.k[SLOTS - 1] ^ nk) >> TB) == 0;
+        double K[SLOTS];
 #pragma unroll
-        for (int r = 0; r + 1 < SLOTS; r++) eq = eq || ((v.k[r] ^ v.k[r + 1]) >> TB) == 0;
-        if (__ballot(eq && mine) != 0) {
-            double K[SLOTS];
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
-            for (int r = 0; r < SLOTS; r++) K[r] = cell_sum<CROSSING>(sh, v.k[r]);   // padding: -inf, inf
+            for (int r = 4 * h; r < 4 * h + 4; r++) K[r] = *(const double*)(ob + ao[r]) + *(const double*)(ib + ai[r]);   // padding: -inf, inf
+            asm volatile("" ::: "memory");
+        }
+        // exact finish: any inversion left by the quantisation?  (odd-even transposition on the exact sums, strict '>': stable,
+        // as random_overlap.h; the keys go along, sums and weights follow from them)
+        auto inverted = [&]() {
+            bool inv = false;
+#pragma unroll
+            for (int r = 0; r + 1 < SLOTS; r++) inv = inv || K[r] > K[r + 1];
+            const double kn = from_next_lane(K[0]);
+            inv = inv || (lane < 63 && K[SLOTS - 1] > kn);
+            return __ballot(inv) != 0;
+        };
+        if (inverted()) {   // wave-uniform, 1-5 % of the problems; the cells' offsets are decoded again behind it: the keys move
             int passes = 0;
-            for (;;) {   // odd-even transposition on the exact sums (strict '>': stable), as random_overlap.h; the keys go along
-                bool inv = false;
-#pragma unroll
-                for (int r = 0; r + 1 < SLOTS; r++) inv = inv || K[r] > K[r + 1];
-                const double kn = from_next_lane(K[0]);
-                inv = inv || (lane < 63 && K[SLOTS - 1] > kn);
-                if (__ballot(inv) == 0 || passes >= 2 * ro::LDS_N) break;
+            do {
                 passes++;
                 auto ce = [&](int a, int b) {
                     const bool sw = K[a] > K[b];
@@ -336,8 +356,10 @@ __device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v
                 const unsigned ep7 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v.k[SLOTS - 1], 0x138, 0xF, 0xF, false);
                 if (sw_hi) { K[SLOTS - 1] = kn0; v.k[SLOTS - 1] = en0; }
                 if (sw_lo) { K[0] = kp7; v.k[0] = ep7; }
-            }
+            } while (passes < 2 * ro::LDS_N && inverted());
             cnt.passes += passes;
+#pragma unroll
+            for (int r = 0; r < SLOTS; r++) decode<CROSSING>(v.k[r], ao[r], ai[r]);
         }
     }
     RO_MARK("scan");
@@ -349,10 +371,10 @@ __device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v
     // the weights in rank order, from the cells; cumulative mid-point abscissae Y_w = sum_{v<w} g_v + g_w/2 (:3371-3376)
     double g[SLOTS];
 #pragma unroll
-    for (int r = 0; r < SLOTS; r++) {
-        unsigned ao, ai;
-        decode<CROSSING>(v.k[r], ao, ai);
-        g[r] = *(const double*)((const char*)sh.op + ao + 8) * *(const double*)((const char*)sh.ip + ai + 8);   // padding: 0
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int r = 4 * h; r < 4 * h + 4; r++) g[r] = *(const double*)(ob + ao[r] + 8) * *(const double*)(ib + ai[r] + 8);   // padding: 0
+        asm volatile("" ::: "memory");
     }
     double csum = 0.0;
 #pragma unroll
