@@ -412,8 +412,20 @@ class Compute(object):
         # ... and the species loop of the fused refresh holds 48 absorbers (its LDS budget, csrc/rt_species.h)
         nabs = sum(1 for sp in (getattr(quant, "species_list", None) or []) if getattr(sp, "absorbing", "no") == "yes")
         # (`flux calculation method = matrix` runs in the same device-resident loop: hx_rt_flags.matrix)
-        return (self.use_fused and quant.flux_calc_method in ("iteration", "matrix")
-                and _i(quant.nlayer) <= (1024 if quant.iso == 1 else 512) and nabs <= 48)
+        why = None
+        if quant.flux_calc_method not in ("iteration", "matrix"):
+            why = "flux calculation method %r" % (quant.flux_calc_method,)
+        elif _i(quant.nlayer) > (1024 if quant.iso == 1 else 512):
+            why = "%d layers (the register-resident sweeps hold 512, 1024 isothermal ones)" % _i(quant.nlayer)
+        elif nabs > 48:
+            why = "%d absorbing species (the species loop on chip holds 48)" % nabs
+        if why is not None and self.use_fused and not getattr(self, "_told_stagewise", False):
+            # not silent: the same kernels' per-stage entry points, every array through HBM at every stage -- measured
+            # 5-10 times the device-resident loop's time per iteration
+            self._told_stagewise = True
+            print("\nhelios_amd: " + why + " -- outside the device-resident loop's limits; this run uses the per-stage "
+                  "kernels (still on the GPU, same results, about 5-10 times slower per iteration).")
+        return self.use_fused and why is None
 
     @staticmethod
     def _rt_flags(q):

@@ -308,7 +308,6 @@ __device__ __forceinline__ void fill_any(const Shared& sh, int lane, Keys& v, in
 // Behind the network: the exact order, the keys by rank to LDS, the abscissae; returns this lane's Gauss point re-binned.
 template <bool CROSSING>
 __device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v, double my_mix, Counters& cnt) {
-    constexpr int TB = CROSSING ? 11 : 10;
     const bool mine = lane >= LANE0 && lane < LANE0 + NLANES;
     RO_MARK("finish");
     // every slot's cell, decoded once: the byte offsets of its two table entries serve the sums (the exact test below) and

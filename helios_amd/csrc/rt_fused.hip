@@ -413,6 +413,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->C = dims->ncol;
     rt->have_albedo.assign(dims->ncol, 0);
     RT_ALLOC(rt->iter_dev, 2);
+    RT_ALLOC(rt->totals_ticket, rt->C);   // (device allocations are zeroed)
     // computation.py:531-537: 3*scat+1 sweeps per iteration, 1000*scat+1 in the post-processing run type
     rt->nsweep = (flags->singlewalk ? 1000 : 3) * (flags->scat ? 1 : 0) + 1;
 #ifdef HX_PROFILING
@@ -1147,17 +1148,19 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         int rc = spectral_fluxes(rt, a);
         if (rc) return rc;
     }
-    {
+    // HELIOS_RT_TOTALS=split: the two levels of the wavelength sum as two launches (rounds 1-5); default: one (k_rt_totals_ab)
+    static const bool split_totals = [] { const char* e = getenv("HELIOS_RT_TOTALS"); return e != nullptr && strcmp(e, "split") == 0; }();
+    if (split_totals) {
         ProfScope ps(rt, "rt_totals_a");
         k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
     }
     if (rt->entr_kappa && rt->cols[0].physical_tstep != 0 && itervalue % 10 == 0) {   // computation.py:921-923
-        int rc = kappa_cp_from_table(rt, false);
+        int rc = kappa_cp_from_table(rt, false);    // (reads temperatures and pressures, not the fluxes: before or behind the first level alike)
         if (rc) return rc;
     }
     {
-        ProfScope ps(rt, "rt_totals_b");
+        ProfScope ps(rt, split_totals ? "rt_totals_b" : "rt_totals");
         TotalsBArgs q;
         q.a = a;
         memset(&q.rt, 0, sizeof(q.rt));
@@ -1183,6 +1186,12 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         q.done_w = rt->done;
         q.iters_done = rt->iters_done;
         q.iter_dev = rt->iter_dev;
+        q.ticket = rt->totals_ticket;
+        if (!split_totals) {
+            k_rt_totals_ab<<<dim3(rt->nchunk, rt->C), 1024, 0, ctx->stream>>>(q);
+            HX_LAUNCH_CHECK(ctx);
+            return 0;
+        }
         k_rt_totals_b<<<rt->C, 1024, 0, ctx->stream>>>(q);
         HX_LAUNCH_CHECK(ctx);
     }

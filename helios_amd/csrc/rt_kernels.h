@@ -1225,15 +1225,13 @@ __global__ void __launch_bounds__(256) k_rt_matrix_bands(const double* __restric
 // ---- per iteration: wavelength totals, level 1 ---------------------------------------------------
 // grid (nchunk, C), 256 threads.  Thread t owns the (dir, i) slots t, t+256, ... (< 2I) and walks the
 // bins of its chunk; consecutive threads read consecutive addresses of the [x][i] band arrays.
-__global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
-    const int col = blockIdx.y, chunk = blockIdx.x;
-    if (a.done[col]) return;
+__device__ __forceinline__ void totals_a_body(const KArgs& a, int col, int chunk, int tid) {   // 256 threads' worth of slots
     const int I = a.I;
     const int per = (a.X + a.nchunk - 1) / a.nchunk;
     const int x0 = chunk * per, x1 = min(a.X, x0 + per);
     const double* __restrict__ fdir = a.F_dir_band_n + (size_t)col * a.X * I;
     const double* __restrict__ dl = a.deltawave;
-    for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
+    for (int t = tid; t < 2 * I; t += 256) {
         const int dir = t / I, i = t - dir * I;
         const double* __restrict__ band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
         // loads issued eight bins at a time (the loop is latency-bound otherwise); summed in bin order
@@ -1254,6 +1252,12 @@ __global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
+    const int col = blockIdx.y, chunk = blockIdx.x;
+    if (a.done[col]) return;
+    totals_a_body(a, col, chunk, threadIdx.x);
+}
+
 struct TotalsBArgs {
     KArgs a;
     RadTempArgs rt;  // pointers of column 0; strides applied below
@@ -1261,13 +1265,12 @@ struct TotalsBArgs {
     int* done_w;
     int* iters_done;
     const int* iter_dev;  // the iteration index on the device (see KArgs); nullptr: rt.itervalue
+    int* ticket;          // [C], zero between launches: chunk blocks of a column that have published their partial sums (k_rt_totals_ab)
     size_t sL, sL1, sI;
 };
 
-__global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
+__device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {   // one workgroup of 1024 threads per column
     const KArgs& a = q.a;
-    const int col = blockIdx.x;
-    if (a.done[col]) return;
     const int I = a.I, L = a.L;
     double* up = a.F_up_tot + (size_t)col * I;
     double* down = a.F_down_tot + (size_t)col * I;
@@ -1334,6 +1337,39 @@ __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
         q.done_w[col] = 1;  // the reference leaves radiation_loop once every flag is set
         q.iters_done[col] = r.itervalue + 1;
     }
+}
+
+__global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
+    const int col = blockIdx.x;
+    if (q.a.done[col]) return;
+    totals_b_body(q, col);
+}
+
+// Both levels in ONE launch (round 6): grid (nchunk, C) of 1024 threads.  Every workgroup sums its chunk of bins (the first
+// 256 threads: the same slots, the same order as k_rt_totals_a), publishes the partial sums and takes a ticket; the workgroup
+// that draws the column's last ticket has every partial in front of it and goes on with the second level and the temperature
+// step (k_rt_totals_b's body: the same four-segment tree over the chunks -- the same bits).  One kernel boundary less per
+// iteration; the ticket is left at zero for the next launch.  Memory order: every writer fences at device scope behind its
+// stores (write-back of its XCD's L2), the ticket is taken behind a barrier, the last workgroup fences again before it reads.
+__global__ void __launch_bounds__(1024) k_rt_totals_ab(TotalsBArgs q) {
+    const int col = blockIdx.y, chunk = blockIdx.x;
+    if (q.a.done[col]) return;   // (set by the last workgroup of an EARLIER launch: the same answer in all workgroups of a column)
+    __shared__ int s_last;
+    if (threadIdx.x < 256) {
+        totals_a_body(q.a, col, chunk, threadIdx.x);
+        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back has completed before the ticket can be seen (MI355X_MICROARCH.md)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int drawn = atomicAdd(q.ticket + col, 1);
+        s_last = drawn == (int)gridDim.x - 1;
+        if (s_last) q.ticket[col] = 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();   // acquire: nothing read below comes from a line cached before the other workgroups published
+    totals_b_body(q, col);
 }
 
 // ---- convection loop on the device (reference computation.py:992-1174) ---------------------------------------

@@ -175,9 +175,13 @@ def test_no_coef_kernel_serialises_its_beam_loads():
 def test_only_the_unselected_flux_tilings_use_scratch():
     """every other kernel of the library -- the species loop with random overlap, the coefficient kernel, all per-stage
     kernels -- runs without a private segment (k_rt_mix_species kept 7 VGPRs in scratch in round 2: 2.1 GB of stores per
-    launch); the mixing kernel also has to leave room for 16 wavefronts per CU (128 VGPRs, 10 KB of LDS)"""
+    launch); the mixing kernel has to leave room for FIVE wavefronts per SIMD, twenty per CU (round 6: at most 96 VGPRs --
+    the allocation granule is 8, 512 / 96 = 5 -- and 160 KB / 20 = 8 KB of LDS; rounds 2-5: 128 VGPRs, 10 KB, four per SIMD),
+    and so does the per-stage random-overlap kernel built on the same device function"""
     notes = _kernel_notes()
     with_scratch = sorted(n for n, k in notes.items() if k["private_segment_fixed_size"] > 0 or k["vgpr_spill_count"] > 0)
     assert with_scratch and all("k_rt_flux<" in n for n in with_scratch), with_scratch
     mix = [k for n, k in notes.items() if "k_rt_mix_species" in n]
-    assert len(mix) == 1 and mix[0]["vgpr_count"] <= 128 and mix[0]["group_segment_fixed_size"] <= 10240
+    assert len(mix) == 1 and mix[0]["vgpr_count"] <= 96 and mix[0]["group_segment_fixed_size"] <= 8192, mix
+    lean = [k for n, k in notes.items() if "k_add_to_mixed_opac_lean" in n]
+    assert len(lean) == 1 and lean[0]["vgpr_count"] <= 96 and lean[0]["group_segment_fixed_size"] <= 8192, lean

@@ -386,9 +386,10 @@ def test_fused_full_size_vs_stage_kernels(ctx):
     np.testing.assert_allclose(f["F_down_tot"][-1], toa, rtol=1e-10)
 
 
-def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kernels(ctx):
+def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kernels(ctx, capsys):
     """the register-resident sweeps hold at most 16 half-layers per lane x 64 lanes: beyond that hx_rt_create reports
-    HX_E_UNSUPPORTED and Compute runs the per-stage kernels instead (still on the GPU -- there is no CPU path)"""
+    HX_E_UNSUPPORTED and Compute runs the per-stage kernels instead (still on the GPU -- there is no CPU path) -- and says
+    so, once per run, with the reason (round 6: the 5-10x slower path is not taken silently)"""
     from helios_amd._lib import HeliosHipError
     from helios_amd.computation import Compute
     c = cases.make_case(nbin=2, nlayer=513)
@@ -399,8 +400,12 @@ def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kerne
         iso, singlewalk, flux_calc_method, nlayer = 0, 0, "iteration", 513
     comp = Compute(ctx)
     assert not comp._fused_supported(Q())
+    assert not comp._fused_supported(Q())
+    out = capsys.readouterr().out
+    assert out.count("helios_amd: 513 layers") == 1 and "per-stage kernels" in out and "slower" in out
     Q.nlayer = 512
     assert comp._fused_supported(Q())
+    assert capsys.readouterr().out == ""
 
 
 @pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2), ("L50+matrix", 1), ("clouds_g0+matrix", 2),

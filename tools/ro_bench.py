@@ -4,7 +4,7 @@
     python tools/ro_bench.py [--nbin 10000] [--nlev 101] [--kind generic|dominated|interleaved] [--reps 5]
 
 Prints the HIP-event time per launch, problems/s and the exact-finish pass count (hx_diag.ro_fixup_passes).
-HELIOS_RO_SORT=bitonic|rank selects the older kernels for A/B runs on the same box."""
+HELIOS_RO_SORT=q32|bitonic|rank selects the older kernels for A/B runs on the same box."""
 import argparse
 import ctypes
 import os
@@ -78,7 +78,7 @@ def main():
     best = min(times)
     print("%s kind=%s  %d problems: %.3f ms per launch (min of %d; mean %.3f)  = %.1f M problems/s;  fix-up passes per "
           "launch %.0f, re-binning skips %d;  checksum %.17g"
-          % (os.environ.get("HELIOS_RO_SORT", "q32"), a.kind, n, best, a.reps, np.mean(times), n / best / 1e3,
+          % (os.environ.get("HELIOS_RO_SORT", "lean"), a.kind, n, best, a.reps, np.mean(times), n / best / 1e3,
              dg["ro_fixup_passes"] / (a.reps + 1), dg["ro_rebin_skipped"], float(out.sum())))
 
 
