@@ -1148,8 +1148,9 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         int rc = spectral_fluxes(rt, a);
         if (rc) return rc;
     }
-    // HELIOS_RT_TOTALS=split: the two levels of the wavelength sum as two launches (rounds 1-5); default: one (k_rt_totals_ab)
-    static const bool split_totals = [] { const char* e = getenv("HELIOS_RT_TOTALS"); return e != nullptr && strcmp(e, "split") == 0; }();
+    // the two levels of the wavelength sum as two launches (default), or -- HELIOS_RT_TOTALS=merged -- as one (k_rt_totals_ab:
+    // measured slower; kept as the record of the A/B)
+    static const bool split_totals = [] { const char* e = getenv("HELIOS_RT_TOTALS"); return e == nullptr || strcmp(e, "merged") != 0; }();
     if (split_totals) {
         ProfScope ps(rt, "rt_totals_a");
         k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);

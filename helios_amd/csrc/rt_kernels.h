@@ -1225,6 +1225,7 @@ __global__ void __launch_bounds__(256) k_rt_matrix_bands(const double* __restric
 // ---- per iteration: wavelength totals, level 1 ---------------------------------------------------
 // grid (nchunk, C), 256 threads.  Thread t owns the (dir, i) slots t, t+256, ... (< 2I) and walks the
 // bins of its chunk; consecutive threads read consecutive addresses of the [x][i] band arrays.
+template <bool PUBLISH>   // PUBLISH: the partial sums are stored through to device-coherent memory (k_rt_totals_ab's hand-over)
 __device__ __forceinline__ void totals_a_body(const KArgs& a, int col, int chunk, int tid) {   // 256 threads' worth of slots
     const int I = a.I;
     const int per = (a.X + a.nchunk - 1) / a.nchunk;
@@ -1248,14 +1249,16 @@ __device__ __forceinline__ void totals_a_body(const KArgs& a, int col, int chunk
             for (int u = 0; u < 8; u++)
                 if (xb + u < x1) acc += v[u] * dl[xb + u];
         }
-        a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
+        double* dst = a.tot_part + (((size_t)col * a.nchunk + chunk) * 2) * I + t;
+        if (PUBLISH) __hip_atomic_store(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = acc;
     }
 }
 
 __global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
     const int col = blockIdx.y, chunk = blockIdx.x;
     if (a.done[col]) return;
-    totals_a_body(a, col, chunk, threadIdx.x);
+    totals_a_body<false>(a, col, chunk, threadIdx.x);
 }
 
 struct TotalsBArgs {
@@ -1269,6 +1272,7 @@ struct TotalsBArgs {
     size_t sL, sL1, sI;
 };
 
+template <bool PUBLISHED>
 __device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {   // one workgroup of 1024 threads per column
     const KArgs& a = q.a;
     const int I = a.I, L = a.L;
@@ -1286,7 +1290,10 @@ __device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {  
             for (int cb = c0; cb < c1; cb += 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = part[(size_t)min(cb + u, c1 - 1) * 2 * I];
+                for (int u = 0; u < 8; u++) {
+                    const double* src = part + (size_t)min(cb + u, c1 - 1) * 2 * I;
+                    v[u] = PUBLISHED ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                }
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (cb + u < c1) s += v[u];
@@ -1342,34 +1349,33 @@ __device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {  
 __global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
     const int col = blockIdx.x;
     if (q.a.done[col]) return;
-    totals_b_body(q, col);
+    totals_b_body<false>(q, col);
 }
 
-// Both levels in ONE launch (round 6): grid (nchunk, C) of 1024 threads.  Every workgroup sums its chunk of bins (the first
-// 256 threads: the same slots, the same order as k_rt_totals_a), publishes the partial sums and takes a ticket; the workgroup
-// that draws the column's last ticket has every partial in front of it and goes on with the second level and the temperature
-// step (k_rt_totals_b's body: the same four-segment tree over the chunks -- the same bits).  One kernel boundary less per
-// iteration; the ticket is left at zero for the next launch.  Memory order: every writer fences at device scope behind its
-// stores (write-back of its XCD's L2), the ticket is taken behind a barrier, the last workgroup fences again before it reads.
+// Both levels in ONE launch (round 6; HELIOS_RT_TOTALS=merged): grid (nchunk, C) of 1024 threads.  Every workgroup sums its
+// chunk of bins (the first 256 threads: the same slots, the same order as k_rt_totals_a), publishes the partial sums and takes
+// a ticket; the workgroup that draws the column's last ticket has every partial in front of it and goes on with the second
+// level and the temperature step (k_rt_totals_b's body: the same four-segment tree over the chunks -- the same bits).  The
+// ticket is left at zero for the next launch.  Hand-over without fences (MI355X_MICROARCH.md, R1): the partials are stored
+// through to device-coherent memory, every writer waits for its stores before the barrier behind which the ticket is taken,
+// and the last workgroup reads them with device-scope loads.
 __global__ void __launch_bounds__(1024) k_rt_totals_ab(TotalsBArgs q) {
     const int col = blockIdx.y, chunk = blockIdx.x;
     if (q.a.done[col]) return;   // (set by the last workgroup of an EARLIER launch: the same answer in all workgroups of a column)
     __shared__ int s_last;
     if (threadIdx.x < 256) {
-        totals_a_body(q.a, col, chunk, threadIdx.x);
-        __threadfence();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-back has completed before the ticket can be seen (MI355X_MICROARCH.md)
+        totals_a_body<true>(q.a, col, chunk, threadIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have completed before the ticket can be seen
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int drawn = atomicAdd(q.ticket + col, 1);
+        const int drawn = __hip_atomic_fetch_add(q.ticket + col, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = drawn == (int)gridDim.x - 1;
-        if (s_last) q.ticket[col] = 0;
+        if (s_last) __hip_atomic_store(q.ticket + col, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();   // acquire: nothing read below comes from a line cached before the other workgroups published
-    totals_b_body(q, col);
+    totals_b_body<true>(q, col);
 }
 
 // ---- convection loop on the device (reference computation.py:992-1174) ---------------------------------------

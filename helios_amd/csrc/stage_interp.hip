@@ -51,7 +51,9 @@ union RowBits {
 };
 __device__ __forceinline__ RowBits load_row(const PlanckSeriesRow* p) {
     RowBits b;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(b.v) : "s"(p));
+    // (early clobber: the sixteen registers are written asynchronously -- they must not double as the address operand; that no
+    // instruction touches them before wait_row() is held by tests/test_abi.py on the built code object)
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(b.v) : "s"(p));
     return b;
 }
 __device__ __forceinline__ void wait_row(RowBits& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b.v)); }

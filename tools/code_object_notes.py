@@ -100,6 +100,26 @@ def load_destinations(path=None, name_filter="k_rt_flux"):
     return out
 
 
+def disassembly(path=None, name_filter=""):
+    """{demangled kernel name: [instruction lines]} of the library's gfx950 code objects"""
+    path = path or os.path.join(ROOT, "helios_amd", "libhelios_hip.so")
+    out = {}
+    for _triple, elf in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as tf:
+            tf.write(elf)
+            tf.flush()
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", tf.name], capture_output=True, text=True,
+                                 check=True).stdout
+        for block in re.split(r"\n(?=[0-9a-f]+ <)", txt):
+            m = re.match(r"[0-9a-f]+ <([^>]+)>:", block)
+            if not m:
+                continue
+            name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+            if name_filter in name:
+                out[name] = [ln.split("//")[0].strip() for ln in block.split("\n")[1:] if ln.strip()]
+    return out
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     flt = sys.argv[sys.argv.index("--filter") + 1] if "--filter" in sys.argv else ""
