@@ -495,7 +495,7 @@ def kernel_roofline(rt, c, wname, ncol, run, start, profile_steps, step_s):
     rt.profile(False)
     flux_ms, nflux = rt.profile_read("matrix_solve" if c.get("flux_calc_method") == "matrix" else "rt_flux")
     prof = {k: rt.profile_read(k)[0] for k in ("rt_flux", "matrix_solve", "refresh_total", "add_to_mixed_opac", "mixed_scat", "rt_coef",
-                                               "opac_interpol", "direct_beam", "rt_nodes", "rt_totals", "rt_totals_a", "rt_totals_b")}
+                                               "opac_interpol", "direct_beam", "rt_nodes", "rt_totals_a", "rt_totals_b")}
     t_only_ms = prof["refresh_total"]
     B_E, B_T = tm["step_algorithmic"], tm["refresh_algorithmic"]      # bytes per launch, all columns
     B = B_E + B_T / 10.0

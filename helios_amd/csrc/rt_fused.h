@@ -147,7 +147,6 @@ struct hx_rt {
     // time, and the nine refresh-free iterations between two opacity refreshes are replayed as one hipGraph where the
     // launches, not the GPU, bound the loop (small grids: hx_rt_run)
     int* iter_dev = nullptr;
-    int* totals_ticket = nullptr;  // [C]: k_rt_totals_ab's count of chunk workgroups that have published (zero between launches)
     int iter_dev_expected = -1;    // what iter_dev[0] holds as far as the host knows (-1: unknown)
     hipGraphExec_t iter_graph = nullptr;
     hipGraphExec_t decade_graph = nullptr;   // refresh + ten iterations (hx_rt_run entered at a refresh boundary)

@@ -413,7 +413,6 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     rt->C = dims->ncol;
     rt->have_albedo.assign(dims->ncol, 0);
     RT_ALLOC(rt->iter_dev, 2);
-    RT_ALLOC(rt->totals_ticket, rt->C);   // (device allocations are zeroed)
     // computation.py:531-537: 3*scat+1 sweeps per iteration, 1000*scat+1 in the post-processing run type
     rt->nsweep = (flags->singlewalk ? 1000 : 3) * (flags->scat ? 1 : 0) + 1;
 #ifdef HX_PROFILING
@@ -1148,10 +1147,10 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         int rc = spectral_fluxes(rt, a);
         if (rc) return rc;
     }
-    // the two levels of the wavelength sum as two launches (default), or -- HELIOS_RT_TOTALS=merged -- as one (k_rt_totals_ab:
-    // measured slower; kept as the record of the A/B)
-    static const bool split_totals = [] { const char* e = getenv("HELIOS_RT_TOTALS"); return e == nullptr || strcmp(e, "merged") != 0; }();
-    if (split_totals) {
+    // (the two levels of the wavelength sum stay two launches: merged into one -- the workgroup that draws a column's last ticket
+    // going on with the second level and the temperature step -- measured slower with device-scope fences and not bit-identical
+    // without them, profiles/r06_ab_totals_merged.txt)
+    {
         ProfScope ps(rt, "rt_totals_a");
         k_rt_totals_a<<<dim3(rt->nchunk, rt->C), 256, 0, ctx->stream>>>(a);
         HX_LAUNCH_CHECK(ctx);
@@ -1161,7 +1160,7 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         if (rc) return rc;
     }
     {
-        ProfScope ps(rt, split_totals ? "rt_totals_b" : "rt_totals");
+        ProfScope ps(rt, "rt_totals_b");
         TotalsBArgs q;
         q.a = a;
         memset(&q.rt, 0, sizeof(q.rt));
@@ -1187,12 +1186,6 @@ static int rt_step_kernels(hx_rt* rt, int itervalue, int step_temperature, bool 
         q.done_w = rt->done;
         q.iters_done = rt->iters_done;
         q.iter_dev = rt->iter_dev;
-        q.ticket = rt->totals_ticket;
-        if (!split_totals) {
-            k_rt_totals_ab<<<dim3(rt->nchunk, rt->C), 1024, 0, ctx->stream>>>(q);
-            HX_LAUNCH_CHECK(ctx);
-            return 0;
-        }
         k_rt_totals_b<<<rt->C, 1024, 0, ctx->stream>>>(q);
         HX_LAUNCH_CHECK(ctx);
     }

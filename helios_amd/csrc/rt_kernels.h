@@ -1225,14 +1225,15 @@ __global__ void __launch_bounds__(256) k_rt_matrix_bands(const double* __restric
 // ---- per iteration: wavelength totals, level 1 ---------------------------------------------------
 // grid (nchunk, C), 256 threads.  Thread t owns the (dir, i) slots t, t+256, ... (< 2I) and walks the
 // bins of its chunk; consecutive threads read consecutive addresses of the [x][i] band arrays.
-template <bool PUBLISH>   // PUBLISH: the partial sums are stored through to device-coherent memory (k_rt_totals_ab's hand-over)
-__device__ __forceinline__ void totals_a_body(const KArgs& a, int col, int chunk, int tid) {   // 256 threads' worth of slots
+__global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
+    const int col = blockIdx.y, chunk = blockIdx.x;
+    if (a.done[col]) return;
     const int I = a.I;
     const int per = (a.X + a.nchunk - 1) / a.nchunk;
     const int x0 = chunk * per, x1 = min(a.X, x0 + per);
     const double* __restrict__ fdir = a.F_dir_band_n + (size_t)col * a.X * I;
     const double* __restrict__ dl = a.deltawave;
-    for (int t = tid; t < 2 * I; t += 256) {
+    for (int t = threadIdx.x; t < 2 * I; t += blockDim.x) {
         const int dir = t / I, i = t - dir * I;
         const double* __restrict__ band = (dir == 0 ? a.F_down_band_n : a.F_up_band_n) + (size_t)col * a.X * I;
         // loads issued eight bins at a time (the loop is latency-bound otherwise); summed in bin order
@@ -1249,16 +1250,8 @@ __device__ __forceinline__ void totals_a_body(const KArgs& a, int col, int chunk
             for (int u = 0; u < 8; u++)
                 if (xb + u < x1) acc += v[u] * dl[xb + u];
         }
-        double* dst = a.tot_part + (((size_t)col * a.nchunk + chunk) * 2) * I + t;
-        if (PUBLISH) __hip_atomic_store(dst, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *dst = acc;
+        a.tot_part[(((size_t)col * a.nchunk + chunk) * 2) * I + t] = acc;
     }
-}
-
-__global__ void __launch_bounds__(256) k_rt_totals_a(KArgs a) {
-    const int col = blockIdx.y, chunk = blockIdx.x;
-    if (a.done[col]) return;
-    totals_a_body<false>(a, col, chunk, threadIdx.x);
 }
 
 struct TotalsBArgs {
@@ -1268,13 +1261,13 @@ struct TotalsBArgs {
     int* done_w;
     int* iters_done;
     const int* iter_dev;  // the iteration index on the device (see KArgs); nullptr: rt.itervalue
-    int* ticket;          // [C], zero between launches: chunk blocks of a column that have published their partial sums (k_rt_totals_ab)
     size_t sL, sL1, sI;
 };
 
-template <bool PUBLISHED>
-__device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {   // one workgroup of 1024 threads per column
+__global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
     const KArgs& a = q.a;
+    const int col = blockIdx.x;
+    if (a.done[col]) return;
     const int I = a.I, L = a.L;
     double* up = a.F_up_tot + (size_t)col * I;
     double* down = a.F_down_tot + (size_t)col * I;
@@ -1290,10 +1283,7 @@ __device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {  
             for (int cb = c0; cb < c1; cb += 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const double* src = part + (size_t)min(cb + u, c1 - 1) * 2 * I;
-                    v[u] = PUBLISHED ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
-                }
+                for (int u = 0; u < 8; u++) v[u] = part[(size_t)min(cb + u, c1 - 1) * 2 * I];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                     if (cb + u < c1) s += v[u];
@@ -1344,38 +1334,6 @@ __device__ __forceinline__ void totals_b_body(const TotalsBArgs& q, int col) {  
         q.done_w[col] = 1;  // the reference leaves radiation_loop once every flag is set
         q.iters_done[col] = r.itervalue + 1;
     }
-}
-
-__global__ void __launch_bounds__(1024) k_rt_totals_b(TotalsBArgs q) {
-    const int col = blockIdx.x;
-    if (q.a.done[col]) return;
-    totals_b_body<false>(q, col);
-}
-
-// Both levels in ONE launch (round 6; HELIOS_RT_TOTALS=merged): grid (nchunk, C) of 1024 threads.  Every workgroup sums its
-// chunk of bins (the first 256 threads: the same slots, the same order as k_rt_totals_a), publishes the partial sums and takes
-// a ticket; the workgroup that draws the column's last ticket has every partial in front of it and goes on with the second
-// level and the temperature step (k_rt_totals_b's body: the same four-segment tree over the chunks -- the same bits).  The
-// ticket is left at zero for the next launch.  Hand-over without fences (MI355X_MICROARCH.md, R1): the partials are stored
-// through to device-coherent memory, every writer waits for its stores before the barrier behind which the ticket is taken,
-// and the last workgroup reads them with device-scope loads.
-__global__ void __launch_bounds__(1024) k_rt_totals_ab(TotalsBArgs q) {
-    const int col = blockIdx.y, chunk = blockIdx.x;
-    if (q.a.done[col]) return;   // (set by the last workgroup of an EARLIER launch: the same answer in all workgroups of a column)
-    __shared__ int s_last;
-    if (threadIdx.x < 256) {
-        totals_a_body<true>(q.a, col, chunk, threadIdx.x);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have completed before the ticket can be seen
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int drawn = __hip_atomic_fetch_add(q.ticket + col, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = drawn == (int)gridDim.x - 1;
-        if (s_last) __hip_atomic_store(q.ticket + col, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    totals_b_body<true>(q, col);
 }
 
 // ---- convection loop on the device (reference computation.py:992-1174) ---------------------------------------

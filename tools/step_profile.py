@@ -38,7 +38,7 @@ def main():
     rt.run(11, min(args.steps, 9))
     rt.profile(False)
     out = []
-    for k in ("rt_nodes", "rt_flux", "rt_totals", "rt_totals_a", "rt_totals_b"):
+    for k in ("rt_nodes", "rt_flux", "rt_totals_a", "rt_totals_b"):
         ms, n = rt.profile_read(k)
         out.append("%s %.1f us (n=%d)" % (k, ms * 1e3, n))
     ctx.timer_start()
