@@ -456,9 +456,33 @@ class Compute(object):
         q = quants[0]
         on_the_fly = q.opacity_mixing == "on-the-fly"
         nspecies = len(q.species_list) if on_the_fly else 0
+        if on_the_fly:
+            # before anything is allocated (the tables of a batch are gigabytes; a sweep goes on with its next batch after an
+            # error): the columns of one batch share the species list and the kind of their mixing ratios
+            for s, sp in enumerate(q.species_list):
+                if getattr(sp, "source_for_vmr", "") != "FastChem":
+                    continue
+                for c, qc in enumerate(quants):
+                    spc = qc.species_list[s] if s < len(qc.species_list) else None
+                    if spc is None or getattr(spc, "source_for_vmr", "") != "FastChem" or getattr(spc, "vmr_pretab", None) is None:
+                        raise ValueError("make_rt_batch: species %r is FastChem-tabulated in column 0 but not in column %d; "
+                                         "columns of one batch share the species list and the kind of their mixing ratios"
+                                         % (getattr(sp, "name", s), c))
         rt = RTBatch(self._ctx_of(q), _i(q.nbin), _i(q.ny), _i(q.nlayer), len(quants), _i(q.ntemp), _i(q.npress),
                      _i(q.plancktable_dim), _i(q.plancktable_step), self._rt_flags(q),
                      [self._rt_column(c) for c in quants], nspecies=nspecies)
+        try:
+            self._fill_rt_batch(rt, quants, on_the_fly)
+        except Exception:
+            rt.close()        # the device state of a batch that could not be set up is given back at once
+            for qc in quants:
+                if getattr(qc, "rt", None) is rt:
+                    qc.rt, qc.rt_col = None, None
+            raise
+        return rt
+
+    def _fill_rt_batch(self, rt, quants, on_the_fly):
+        q = quants[0]
         rt.set_grid(q.opac_interwave, q.opac_deltawave, q.opac_wave, q.gauss_y, q.gauss_weight, q.ktemp, q.kpress)
         if on_the_fly:
             for s, sp in enumerate(q.species_list):
@@ -471,14 +495,9 @@ class Compute(object):
                 # calculate_vmr_for_all_species on the device: a FastChem species hands over its (T, P) table once and its
                 # profile is interpolated from the device's temperatures at every refresh (host_functions.py:874-910).
                 # One table per COLUMN: the Stores of a sweep each read their own FastChem directory (read.py:577-606)
-                if getattr(sp, "source_for_vmr", "") == "FastChem":
+                if getattr(sp, "source_for_vmr", "") == "FastChem":      # (checked for every column in make_rt_batch)
                     for c, qc in enumerate(quants):
-                        spc = qc.species_list[s]
-                        if getattr(spc, "source_for_vmr", "") != "FastChem" or getattr(spc, "vmr_pretab", None) is None:
-                            raise ValueError("make_rt_batch: species %r is FastChem-tabulated in column 0 but not in column %d; "
-                                             "columns of one batch share the species list and the kind of their mixing ratios"
-                                             % (getattr(sp, "name", s), c))
-                        rt.set_column_vmr_table(c, s, np.asarray(spc.vmr_pretab, np.float64).reshape(-1))
+                        rt.set_column_vmr_table(c, s, np.asarray(qc.species_list[s].vmr_pretab, np.float64).reshape(-1))
         else:
             rt.set_premixed_tables(q.opac_k, q.opac_scat_cross, q.opac_meanmass)
         if self._kappa_from_table(q):
@@ -498,7 +517,6 @@ class Compute(object):
         rt.build_planck_table(1 if (q.energy_correction == 1 and q.T_star > 10) else 0)
         if _i(q.debug or 0) == 1:
             rt.keep_down_fluxes(True)     # so that the negative-flux count covers the downward fluxes too
-        return rt
 
     @staticmethod
     def _runtime_limit_iteration(quant):

@@ -264,6 +264,9 @@ MATRIX_CONFIGS = {
     "L3": dict(nbin=10, nlayer=3, albedo=0.3, p_boa=1e11),
     "L2_beam": dict(nbin=6, nlayer=2, albedo=0.2, dir_beam=1, p_boa=1e11),
     "iso_L5": dict(iso=1, nbin=7, nlayer=5, albedo=0.1),
+    # a grazing beam into strongly forward-scattering clouds: the direct-beam sources min(0, ...) are at their largest
+    # against the thermal ones (the regime in which a flux of the direct solve can come out negative, kernels.cu:2268)
+    "beam_forward": dict(nbin=16, nlayer=30, dir_beam=1, clouds=1, g_0=0.85, scat_corr=1, albedo=0.3, zenith_deg=85.0, T_star=9000.0),
     "ny1": dict(ny=1, nbin=17, albedo=0.1),
     "L105_i2s": dict(nbin=12, nlayer=105, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),
 }
