@@ -39,12 +39,20 @@ constexpr int NYIMG = (SLOTS + 1) * NLANES;
 // table entries beyond the 20 Gauss points: (inf, 0) everywhere, op[OP_LOW] = (-inf, 0)
 constexpr int OP_LOW = 21;
 constexpr unsigned HIGHKEY = 0xFFFFFFFFu;            // cell (31, 31): inf + inf, weight 0 x 0
-constexpr unsigned LOWKEY = (unsigned)OP_LOW << 5;   // q = 0 (sums have q >= 1), cell (21, 0): -inf + ip[0], weight 0
+constexpr unsigned LOWKEY = (unsigned)OP_LOW << 5;   // q = 0 (sums have q >= 1), cell (21, 0): -inf + ip[0], weight 0 x w
+
+// entry k of the curve table: both curves' Gauss point k side by side, 32 bytes -- a key's row field (bits 5-9) IS the byte
+// offset of its op entry, the column field shifted by five that of its ip entry (one and two instructions per decode)
+struct Cell {
+    double ov, ohw;   // op: the curve that is stronger at y = 0 (outer fill loop): coefficient, half weight
+    double iv, ihw;   // ip: the other one
+};
+constexpr unsigned IP_OFF = 16;   // byte offset of the ip half inside a Cell
 
 struct Shared {
     double Y[NYIMG];          // abscissae by padded position - YBASE: nine cells per lane, the ninth repeats the next lane's first
     unsigned E[N];            // the sorted keys by rank
-    Pair op[NTAB], ip[NTAB];  // op: the curve that is stronger at y = 0 (outer fill loop), ip: the other one
+    Cell tab[NTAB];
     double gy[NY];
     // the re-binning of a PRESORTED tableau (random_overlap.h, prepare_presorted): per Gauss point the abscissae of the two
     // ranks that bracket it and the LDS byte offsets of their cells' table entries (per rank: op entry | ip entry << 16)
@@ -53,20 +61,21 @@ struct Shared {
     unsigned pre_skipped, pad_;
 };
 static_assert(sizeof(Shared) <= 6880, "twenty wavefronts per CU: 8 KB each with the species list of k_rt_mix_species");
-static_assert(offsetof(Shared, op) % 16 == 0 && offsetof(Shared, op) >= 4 * sizeof(Pair), "aligned tables; op[-4] stays inside the struct");
+static_assert(offsetof(Shared, tab) % 16 == 0 && offsetof(Shared, tab) >= 4 * sizeof(Cell), "aligned table; entry -4 stays inside the struct");
 
 // A lane's place in the run layout (random_overlap.h, run_lane), packed: kept in two registers through the kernel and
 // unpacked per problem.
-//   a: byte offset of the fixed table entry | col << 13 | padlow << 14 | padhigh << 15 | byte offset of slot 0's varying entry << 16
-//   b: (i0 << 5 | j0) + 128 (the cell code of slot 0; i0 = -4 in front of a column piece) | (i0 + 4) << 11 | j0 << 16
-// col: the lane walks down a column (i steps, the code steps by 32) instead of along a row; padlow: its slots 0-3 are low
-// padding; padhigh: all its slots are high padding.
+//   a: byte offset (from the start of Shared) of the fixed table operand | byte offset of slot 0's varying operand << 16
+//   b: cell code of slot 0, i0 << 5 | j0 as a signed 16-bit number (i0 = -4 in front of a column piece) | code step per slot
+//      << 16 (1 along a row, 32 down a column) | padlow << 24 | padhigh << 25 | col << 26
+// col: the lane walks down a column (i steps) instead of along a row; padlow: its slots 0-3 are low padding; padhigh: all its
+// slots are high padding.
 struct LaneConst {
     unsigned a, b;
 };
 
 __device__ __forceinline__ LaneConst lane_const(int lane) {
-    const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
+    const unsigned TAB = (unsigned)offsetof(Shared, tab), CS = (unsigned)sizeof(Cell);
     const int blk = lane >> 1, idx0 = 8 * (lane & 1);
     int i = NY, j = NY, col = 0, padlow = 0, padhigh = 1;   // default: high padding (reads the constant entries)
     if (blk < 12) { i = blk; j = idx0; padhigh = 0; }                                              // row i, columns idx0 ...
@@ -74,11 +83,11 @@ __device__ __forceinline__ LaneConst lane_const(int lane) {
                                                                                                    // four positions of low padding
     else if (blk < 24) { i = 12 + (blk - 16); j = idx0; padhigh = 0; }                             // row i, columns idx0 ...
     else if (blk < 28 && idx0 == 0) { j = 16 + (blk - 24); i = 12; col = 1; padhigh = 0; }         // column j, rows 12 ... 19
-    const unsigned fix = col ? IP + PS * j : OP + PS * i;
-    const unsigned var = col ? OP + PS * i : IP + PS * j;   // (i = -4: the four cells in front of op, inside E: any bits do)
+    const unsigned o = TAB + CS * i, p = TAB + CS * j + IP_OFF;   // (i = -4: the four cells in front of the table, inside E: any bits do)
     LaneConst lc;
-    lc.a = fix | (unsigned)col << 13 | (unsigned)padlow << 14 | (unsigned)padhigh << 15 | var << 16;
-    lc.b = (unsigned)((i << 5) + j + 128) | (unsigned)(i + 4) << 11 | (unsigned)j << 16;
+    lc.a = (col ? p : o) | (col ? o : p) << 16;
+    lc.b = (unsigned)(((i << 5) + j) & 0xFFFF) | (unsigned)(col ? 32 : 1) << 16 | (unsigned)padlow << 24 | (unsigned)padhigh << 25 |
+           (unsigned)col << 26;
     return lc;
 }
 
@@ -88,10 +97,10 @@ __device__ __forceinline__ LaneConst init(Shared& sh, int lane, const double* ga
     if (lane < NTAB) {
         const bool real = lane < NY;
         const double hw = real ? 0.5 * gauss_weight[lane] : 0.0;
-        sh.op[lane].hw = sh.ip[lane].hw = hw;
+        sh.tab[lane].ohw = sh.tab[lane].ihw = hw;
         if (!real) {
-            sh.op[lane].v = lane == OP_LOW ? -__builtin_inf() : __builtin_inf();
-            sh.ip[lane].v = __builtin_inf();
+            sh.tab[lane].ov = lane == OP_LOW ? -__builtin_inf() : __builtin_inf();
+            sh.tab[lane].iv = __builtin_inf();
         }
         if (real) sh.gy[lane] = gauss_y[lane];
     }
@@ -119,11 +128,12 @@ __device__ __forceinline__ double lane_value(double x) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), L), __builtin_amdgcn_readlane(__double2loint(x), L));
 }
 
-// the table entries of a key's cell: byte offsets from the start of op / ip.  CROSSING: bit 10 says that the two fields
-// have changed places (the second fill region of :3332-3365, where the inner curve runs on the outer loop)
+// the table entries of a key's cell: byte offsets from the start of the table (the ip half is IP_OFF further: an immediate).
+// CROSSING: bit 10 says that the two fields have changed places (the second fill region of :3332-3365, where the inner curve
+// runs on the outer loop)
 template <bool CROSSING>
 __device__ __forceinline__ void decode(unsigned key, unsigned& ao, unsigned& ai) {
-    const unsigned hi = (key >> 1) & 0x1F0u, lo = (key << 4) & 0x1F0u;
+    const unsigned hi = key & 0x3E0u, lo = (key << 5) & 0x3E0u;
     if (CROSSING) {
         const bool swapped = (key & 1024u) != 0;
         ao = swapped ? lo : hi;
@@ -138,7 +148,8 @@ template <bool CROSSING>
 __device__ __forceinline__ double cell_sum(const Shared& sh, unsigned key) {
     unsigned ao, ai;
     decode<CROSSING>(key, ao, ai);
-    return *(const double*)((const char*)sh.op + ao) + *(const double*)((const char*)sh.ip + ai);
+    const char* tb = (const char*)sh.tab;
+    return *(const double*)(tb + ao) + *(const double*)(tb + ai + IP_OFF);
 }
 
 // The abscissae of the eight ranks a lane holds (exclusive prefix `run` of the weights before them) to LDS at pitch 9 per
@@ -206,12 +217,12 @@ __device__ __forceinline__ void prepare_presorted(Shared& sh, int lane) {
     sync();  // the half weights and the Gauss points are in LDS
     // exactly what mix() does with a tableau it finds presorted -- weights in rank order (rank w = cell (w / 20, w % 20)),
     // their sum per lane, the wave scan, the abscissae, the interval search, the skip rule
-    const unsigned OP = (unsigned)offsetof(Shared, op), IP = (unsigned)offsetof(Shared, ip), PS = (unsigned)sizeof(Pair);
+    const unsigned OP = (unsigned)offsetof(Shared, tab), IP = OP + IP_OFF, PS = (unsigned)sizeof(Cell);
     double g[SLOTS];
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
         const int w = SLOTS * lane + r - RANK0;
-        g[r] = (w >= 0 && w < N) ? sh.op[w / NY].hw * sh.ip[w % NY].hw : 0.0;
+        g[r] = (w >= 0 && w < N) ? sh.tab[w / NY].ohw * sh.tab[w % NY].ihw : 0.0;
     }
     double csum = 0.0;
 #pragma unroll
@@ -247,21 +258,20 @@ template <bool CROSSING, bool HI>
 __device__ __forceinline__ void fill_runs(const Shared& sh, LaneConst lc, Keys& v, int yx, int hmin, int sh_bits) {
     constexpr int TB = CROSSING ? 11 : 10;
     const char* base = (const char*)&sh;
-    const unsigned fix = lc.a & 0x1FFFu, var = (lc.a >> 16) & 0x1FFFu;
-    const bool col = (lc.a & (1u << 13)) != 0;
-    const unsigned nlow = (unsigned)__builtin_amdgcn_sbfe((int)lc.a, 14, 1), padhi = (unsigned)__builtin_amdgcn_sbfe((int)lc.a, 15, 1);  // 0 or ~0
+    const unsigned fix = lc.a & 0xFFFFu, var = lc.a >> 16;
+    const unsigned nlow = (unsigned)__builtin_amdgcn_sbfe((int)lc.b, 24, 1), padhi = (unsigned)__builtin_amdgcn_sbfe((int)lc.b, 25, 1);  // 0 or ~0
     unsigned lowkey = LOWKEY;
     asm volatile("" : "+v"(lowkey));   // made here: as the literal operand of an and-or it would be parked in a register for the whole kernel
     const unsigned aklo = ~nlow, oklo = (nlow & lowkey) | padhi;
     const double F = *(const double*)(base + fix);
-    const int t0 = (int)(lc.b & 0x7FFu) - 128, tstep = col ? 32 : 1;
-    const int i0 = (int)((lc.b >> 11) & 31u) - 4, j0 = (int)((lc.b >> 16) & 31u);
+    const int t0 = __builtin_amdgcn_sbfe((int)lc.b, 0, 16), tstep = (int)__builtin_amdgcn_ubfe(lc.b, 16, 6);
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
-        const double K = F + *(const double*)(base + var + (unsigned)sizeof(Pair) * r);   // padding: inf, or any bits (masked below)
+        const double K = F + *(const double*)(base + var + (unsigned)sizeof(Cell) * r);   // padding: inf, or any bits (masked below)
         int t = t0 + tstep * r;
         if (CROSSING) {
-            const int i = col ? i0 + r : i0, j = col ? j0 : j0 + r;
+            // (i, j) of this slot from its code: the low five bits never carry (j0 + r <= 15 along a row, j fixed down a column)
+            const int i = t >> 5, j = t & 31;
             t = j < yx ? t : (1 << 10 | j << 5 | i);
         }
         const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
@@ -294,7 +304,7 @@ __device__ __forceinline__ void fill_any(const Shared& sh, int lane, Keys& v, in
                 j = first ? rem : q;
                 second = !first;
             }
-            const double K = sh.op[i].v + sh.ip[j].v;
+            const double K = sh.tab[i].ov + sh.tab[j].iv;
             const int dh = max(__double2hiint(K) - hmin, 0);
             unsigned q = sh_bits >= 32 ? (unsigned)dh >> (sh_bits - 32)
                                        : __builtin_amdgcn_alignbit((unsigned)dh, (unsigned)__double2loint(K), sh_bits);
@@ -312,8 +322,8 @@ __device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v
     RO_MARK("finish");
     // every slot's cell, decoded once: the byte offsets of its two table entries serve the sums (the exact test below) and
     // the weights (the scan).  Sums and weights are read in two halves each, so that at most eight reads are in flight.
-    const char* ob = (const char*)sh.op;
-    const char* ib = (const char*)sh.ip;
+    const char* ob = (const char*)sh.tab;
+    const char* ib = (const char*)sh.tab + IP_OFF;
     unsigned ao[SLOTS], ai[SLOTS];
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) decode<CROSSING>(v.k[r], ao[r], ai[r]);
@@ -409,14 +419,14 @@ __device__ __forceinline__ double mix(Shared& sh, LaneConst lc, int lane, double
     const bool mix_first = m0 > a0;
     sync();  // the previous problem's readers are done with sh
     if (lane < NY) {
-        sh.op[lane].v = mix_first ? my_mix : my_add;
-        sh.ip[lane].v = mix_first ? my_add : my_mix;
+        sh.tab[lane].ov = mix_first ? my_mix : my_add;
+        sh.tab[lane].iv = mix_first ? my_add : my_mix;
     }
     sync();
     // last crossing of the two curves (:3321-3329); are both k-distributions (ascending)?  Do the rows of the tableau overlap?
     bool cross = false, down = false, over = false, touch = false;
     if (lane >= 1 && lane < NY) {
-        const double po = sh.op[lane - 1].v, pi = sh.ip[lane - 1].v;
+        const double po = sh.tab[lane - 1].ov, pi = sh.tab[lane - 1].iv;
         const double pm = mix_first ? po : pi, pa = mix_first ? pi : po;
         cross = (my_mix > my_add) != (pm > pa);
         down = my_mix < pm || my_add < pa;
@@ -440,8 +450,8 @@ __device__ __forceinline__ double mix(Shared& sh, LaneConst lc, int lane, double
             if (cells != 0ull) {
                 const char* base = (const char*)&sh;
                 const unsigned c0 = (unsigned)cells, c1 = (unsigned)(cells >> 32);
-                const double K0 = ((const Pair*)(base + (c0 & 0xFFFFu)))->v + ((const Pair*)(base + (c0 >> 16)))->v;
-                const double K1 = ((const Pair*)(base + (c1 & 0xFFFFu)))->v + ((const Pair*)(base + (c1 >> 16)))->v;
+                const double K0 = *(const double*)(base + (c0 & 0xFFFFu)) + *(const double*)(base + (c0 >> 16));
+                const double K1 = *(const double*)(base + (c1 & 0xFFFFu)) + *(const double*)(base + (c1 >> 16));
                 const double yq = sh.gy[lane], y0 = sh.pre_y0[lane], y1 = sh.pre_y1[lane];
                 out = (K0 * (y1 - yq) + K1 * (yq - y0)) / (y1 - y0);
             }
@@ -451,11 +461,11 @@ __device__ __forceinline__ double mix(Shared& sh, LaneConst lc, int lane, double
     }
     double kmin = m0 + a0, kmax = m19 + a19;
     if (!monotone) {  // the extreme sums are not at the corners of the tableau
-        double mn1 = sh.op[0].v, mx1 = mn1, mn2 = sh.ip[0].v, mx2 = mn2;
+        double mn1 = sh.tab[0].ov, mx1 = mn1, mn2 = sh.tab[0].iv, mx2 = mn2;
 #pragma unroll 1
         for (int j = 1; j < NY; j++) {
-            mn1 = fmin(mn1, sh.op[j].v); mx1 = fmax(mx1, sh.op[j].v);
-            mn2 = fmin(mn2, sh.ip[j].v); mx2 = fmax(mx2, sh.ip[j].v);
+            mn1 = fmin(mn1, sh.tab[j].ov); mx1 = fmax(mx1, sh.tab[j].ov);
+            mn2 = fmin(mn2, sh.tab[j].iv); mx2 = fmax(mx2, sh.tab[j].iv);
         }
         kmin = mn1 + mn2;
         kmax = mx1 + mx2;

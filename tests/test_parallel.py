@@ -150,3 +150,97 @@ def test_sweep_batches_are_keyed_on_the_chemistry():
     assert _batch_signature(a) == _batch_signature(b) != _batch_signature(c)
     cols = expand_sweep("directory_with_fastchem_files=chem/m0/,chem/m1/;internal_temperature=100,300")
     assert len(cols) == 4 and cols[1] == {"directory_with_fastchem_files": "chem/m0/", "internal_temperature": "300"}
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """a sysfs tree with the KFD topology of `gpus` = [(pci bus, numa node)] behind two CPU nodes, and `nodes` = {n: cpulist}"""
+    top = os.path.join(root, "class/kfd/kfd/topology/nodes")
+    k = 0
+    for n in sorted(nodes):           # the CPU agents come first in the KFD topology, without SIMDs
+        os.makedirs(os.path.join(top, str(k)))
+        with open(os.path.join(top, str(k), "properties"), "w") as f:
+            f.write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+        os.makedirs(os.path.join(root, "devices/system/node/node%d" % n))
+        with open(os.path.join(root, "devices/system/node/node%d/cpulist" % n), "w") as f:
+            f.write(nodes[n] + "\n")
+        k += 1
+    for bus, numa in gpus:
+        os.makedirs(os.path.join(top, str(k)))
+        with open(os.path.join(top, str(k), "properties"), "w") as f:
+            f.write("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        dev = os.path.join(root, "bus/pci/devices/0000:%02x:00.0" % bus)
+        os.makedirs(dev)
+        with open(os.path.join(dev, "numa_node"), "w") as f:
+            f.write("%d\n" % numa)
+        k += 1
+
+
+def test_rank_binds_to_the_cores_of_its_gpus_numa_node(tmp_path):
+    """bench.py binds every rank of a multi-GPU run to the host cores of its GPU's NUMA node before the first GPU call:
+    KFD topology order = HIP device order, PCI address -> numa_node -> cpulist, intersected with the cores the process may
+    use; a sysfs that is not there (this container), an unknown node or a UUID-style visible-devices list leave the process
+    alone and say why"""
+    from helios_amd import parallel as par
+    allowed = sorted(os.sched_getaffinity(0))
+    assert len(allowed) >= 2
+    lo, hi = allowed[: len(allowed) // 2], allowed[len(allowed) // 2:]
+    as_list = lambda cpus: ",".join(str(c) for c in cpus) + ",4090-4095"      # (cores this process may not use are ignored)
+    root = str(tmp_path)
+    _fake_sysfs(root, [(0x05, 0), (0x15, 0), (0x65, 1), (0x75, 1), (0x85, -1)], {0: as_list(lo), 1: as_list(hi)})
+    assert par.gpu_numa_nodes(root) == [0, 0, 1, 1, -1]
+    assert par._cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    try:
+        r = par.bind_to_gpu_numa_node(2, sysfs=root, env={})
+        assert r["bound"] and r["gpu"] == 2 and r["numa_node"] == 1 and r["cpus"] == len(hi)
+        assert sorted(os.sched_getaffinity(0)) == hi
+        os.sched_setaffinity(0, allowed)
+        # HIP's visible-devices list indexes into ROCR's: local device 0 -> HIP list [3, 0] -> 3 -> ROCR list [4, 2, 1, 3] -> GPU 3
+        r = par.bind_to_gpu_numa_node(0, sysfs=root, env={"HIP_VISIBLE_DEVICES": "3,0", "ROCR_VISIBLE_DEVICES": "4,2,1,3"}, apply=False)
+        assert r["gpu"] == 3 and r["numa_node"] == 1 and not r["bound"] and sorted(os.sched_getaffinity(0)) == allowed
+        r = par.bind_to_gpu_numa_node(4, sysfs=root, env={})
+        assert not r["bound"] and r["numa_node"] == -1 and "no NUMA node" in r["why"]
+        r = par.bind_to_gpu_numa_node(0, sysfs=root, env={"ROCR_VISIBLE_DEVICES": "GPU-deadbeef"})
+        assert not r["bound"] and "index list" in r["why"]
+        r = par.bind_to_gpu_numa_node(7, sysfs=root, env={})
+        assert not r["bound"] and "no sysfs entry" in r["why"]
+        r = par.bind_to_gpu_numa_node(0, sysfs=os.path.join(root, "nothing_here"), env={})
+        assert not r["bound"] and r["gpu"] == 0 and sorted(os.sched_getaffinity(0)) == allowed
+    finally:
+        os.sched_setaffinity(0, allowed)
+
+
+def _init_worker(rank, world, port, q, late):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    import torch.distributed as dist
+    from helios_amd.parallel import init_process_group_checked
+    if late and rank == 1:
+        time.sleep(1.0)
+    msgs = []
+    try:
+        t = init_process_group_checked(dist, "gloo", rank, world, device="cpu", timeout_s=60.0, log=msgs.append)
+        q.put((rank, "ok", t))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, "error", (type(e).__name__, msgs)))
+
+
+def test_checked_process_group_init_gloo_world2():
+    """the set-up bench.py uses for its ranks: init with a deadline, a roll call (monitored barrier), one all-reduce that must
+    count every rank -- here with gloo and one rank arriving a second late"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_init_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    for _rank, _ok, t in res:
+        assert set(t) == {"init_s", "roll_call_s", "first_collective_s"} and all(v >= 0 for v in t.values())
