@@ -409,16 +409,13 @@ class Compute(object):
 
     def _fused_supported(self, quant):
         # isothermal layers halve the segments per layer: 1024 of them fit the register-resident sweeps
-        # ... and the species loop of the fused refresh holds 48 absorbers (its LDS budget, csrc/rt_species.h)
-        nabs = sum(1 for sp in (getattr(quant, "species_list", None) or []) if getattr(sp, "absorbing", "no") == "yes")
-        # (`flux calculation method = matrix` runs in the same device-resident loop: hx_rt_flags.matrix)
+        # (`flux calculation method = matrix` runs in the same device-resident loop: hx_rt_flags.matrix; any number of
+        # absorbers: the species loop on chip takes them in blocks of 48, csrc/rt_fused.hip refresh_species)
         why = None
         if quant.flux_calc_method not in ("iteration", "matrix"):
             why = "flux calculation method %r" % (quant.flux_calc_method,)
         elif _i(quant.nlayer) > (1024 if quant.iso == 1 else 512):
             why = "%d layers (the register-resident sweeps hold 512, 1024 isothermal ones)" % _i(quant.nlayer)
-        elif nabs > 48:
-            why = "%d absorbing species (the species loop on chip holds 48)" % nabs
         if why is not None and self.use_fused and not getattr(self, "_told_stagewise", False):
             # not silent: the same kernels' per-stage entry points, every array through HBM at every stage -- measured
             # 5-10 times the device-resident loop's time per iteration

@@ -897,7 +897,7 @@ static int refresh_species(hx_rt* rt) {
     if (rc) return rc;
     MixArgs m;
     m.X = rt->X; m.Y = rt->Y; m.L = rt->L; m.I = rt->I; m.C = rt->C; m.S = rt->d.nspecies;
-    m.ntemp = rt->d.ntemp; m.npress = rt->d.npress; m.nabs = rt->nabs;
+    m.ntemp = rt->d.ntemp; m.npress = rt->d.npress; m.nabs = rt->nabs; m.carry_on = 0;
     m.sp = (const SpeciesDev*)rt->species_dev; m.abs_list = rt->abs_list;
     m.T_lay = rt->T_lay; m.T_int = rt->T_int; m.p_lay = rt->p_lay; m.p_int = rt->p_int;
     m.vmr_lay = rt->vmr_lay; m.vmr_int = rt->vmr_int;
@@ -920,8 +920,18 @@ static int refresh_species(hx_rt* rt) {
         // occupancy experiment (profiles/r05_mix_occupancy.txt): bytes of unused dynamic LDS per wavefront on top of the
         // kernel's 9.95 KB -- 16 wavefronts share a CU's 160 KB as built, +3.4 KB leaves 12, +10 KB 8.  Results unchanged.
         static const int extra_lds = [] { const char* e = getenv("HELIOS_RT_MIX_EXTRA_LDS"); return e ? atoi(e) : 0; }();
-        k_rt_mix_species<<<grid, 64, extra_lds, ctx->stream>>>(m);
-        HX_LAUNCH_CHECK(ctx);
+        // the species list on chip holds MIX_MAX_ABSORBERS entries: a longer list is folded in block by block, every launch but
+        // the first starting from the mix the one before it wrote (the absorbers' order, and so every sum, is the reference's)
+        const int nabs_all = rt->nabs;
+        for (int first = 0; first == 0 || first < nabs_all; first += MIX_MAX_ABSORBERS) {
+            m.abs_list = rt->abs_list + first;
+            m.nabs = std::min(MIX_MAX_ABSORBERS, nabs_all - first);
+            m.carry_on = first > 0 ? 1 : 0;
+            k_rt_mix_species<<<grid, 64, extra_lds, ctx->stream>>>(m);
+            HX_LAUNCH_CHECK(ctx);
+        }
+        m.abs_list = rt->abs_list;
+        m.nabs = nabs_all;
     }
     {
         ProfScope ps(rt, "mixed_scat");
@@ -1030,7 +1040,7 @@ int hx_rt_refresh(hx_rt* rt) {
         HX_REQUIRE(ctx, Y <= ro::NY, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 20 Gauss points");
         int nabs = 0;
         for (const Species& sp : rt->species) nabs += sp.absorbing ? 1 : 0;
-        HX_REQUIRE(ctx, nabs <= MIX_MAX_ABSORBERS, HX_E_UNSUPPORTED, "on-the-fly mixing in the fused path holds at most 48 absorbers");
+        (void)nabs;   // (any number: the species loop takes them in blocks of MIX_MAX_ABSORBERS, refresh_species)
     }
     KArgs a = make_args(rt);
     rt->iter_dev_expected = -1;   // k_rt_nodes below moves the device's iteration counter on (hx_rt_step sets it right again)

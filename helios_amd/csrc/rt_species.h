@@ -59,8 +59,10 @@ __device__ __forceinline__ double vmr_from_table(const double* tab, double T, do
 
 struct MixArgs {
     int X, Y, L, I, C, S, ntemp, npress, nabs;
+    int carry_on;          // 0: the mix starts from zero; 1: from what opac_wg_* holds -- the launch folds in the NEXT block of at most
+                           // MIX_MAX_ABSORBERS absorbers of a longer species list (round 6)
     const SpeciesDev* sp;  // [S]
-    const int* abs_list;   // [nabs] indices of the absorbing species, ascending
+    const int* abs_list;   // [nabs] indices of the absorbing species of this launch, ascending
     const double *T_lay, *T_int, *p_lay, *p_int;  // column strides L+1, I, L, I
     const double *vmr_lay, *vmr_int;              // [C][S][I]
     const double *ktemp, *kpress, *gauss_w, *gauss_y, *wave;
@@ -127,7 +129,8 @@ __global__ void k_rt_mmm_from_vmr(const SpeciesDev* __restrict__ sp, int S, doub
     mmm_lay[(size_t)col * I + i] = num / tot * HX_AMU;
 }
 
-constexpr int MIX_MAX_ABSORBERS = 48;  // LDS images of the species list: 1 KB next to the mixing images
+constexpr int MIX_MAX_ABSORBERS = 48;  // LDS images of the species list: 1 KB next to the mixing images; a longer list takes
+                                       // one launch per block of 48 (MixArgs::carry_on)
 
 // HX_MIX_LEAN = 1 (default): rol::mix (random_overlap_lean.h) -- 7.9 KB of LDS and at most 96 VGPRs, five wavefronts per SIMD;
 // 0: ro::mix as until round 5 (10.2 KB, 128 VGPRs, four), kept for the same-box A/B (tools/ab_mix_lean.sh)
@@ -235,6 +238,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HX_MIX_
             c_dd = (tab + pl_dd)[off]; c_ud = (tab + pl_ud)[off]; c_du = (tab + pl_du)[off]; c_uu = (tab + pl_uu)[off];
         }
         double mixv = 0.0;  // nullify_opac_scat_arrays (host_functions.py:1050-1056)
+        if (a.carry_on && lane < a.Y) mixv = out_level[off];   // (wave-uniform flag: a species list of more than 48 absorbers)
         for (int kb = 0; kb < nabs; kb += 3) {
             // blend_tp(..., species = true) with the level's weights re-read from LDS (same products in the same order)
             asm volatile("" ::: "memory");  // the weights are not to be carried in registers across the mixes

@@ -36,6 +36,31 @@ def test_fused_onthefly_vs_oracle(ctx, port, cfg):
     assert np.abs(o_ck["opac_wg_lay"] - f["opac_wg_lay"]).max() > 1e-3 * np.abs(f["opac_wg_lay"]).max()
 
 
+@pytest.mark.parametrize("nspecies", [48, 49, 101])
+def test_fused_onthefly_with_more_absorbers_than_the_species_list_on_chip_holds(ctx, port, nspecies):
+    """the species loop keeps 48 absorbers' table pointers and factors in LDS; a longer list is folded in block by block, every
+    launch but the first starting from the mix the one before it wrote (round 6: the limit of rounds 2-5 -- and the fall-back
+    to the per-stage kernels behind it -- is gone).  48 (one full block), 49 (a block of one), 101 (three launches) absorbers
+    mixed by random overlap, against the oracle's species loop: the same order of absorbers, so the same sums"""
+    c0 = cases.add_species(cases.make_case(nbin=6, nlayer=5), nspecies=nspecies)
+    rng = np.random.default_rng(5)
+    for sp in c0.species[1:nspecies]:          # comparable abundances: most problems take the network, not the 1 % short cut
+        sp["vmr"] = float(10.0 ** rng.uniform(-3.0, -2.0))
+    f, grid = fh.run_fused(ctx, c0, 1, with_planck_grid=True)
+    o = fh.run_oracle(port, c0, 1, planck_grid=grid, refresh=cases.refresh_onthefly)
+    fh.compare(f, o, c0, rtol=1e-9)
+    o_ck = fh.run_oracle(port, c0, 1, planck_grid=grid, refresh=lambda i, c, s: cases.refresh_onthefly(i, c, s, ro=0))
+    assert np.abs(o_ck["opac_wg_lay"] - f["opac_wg_lay"]).max() > 1e-3 * np.abs(f["opac_wg_lay"]).max()
+    from helios_amd.computation import Compute
+
+    class Sp(object):
+        absorbing = "yes"
+
+    class Q(object):
+        iso, singlewalk, flux_calc_method, nlayer, species_list = 0, 0, "iteration", 50, [Sp()] * nspecies
+    assert Compute(ctx)._fused_supported(Q())
+
+
 @pytest.mark.parametrize("cfg", [dict(nbin=9, nlayer=8, albedo=0.1), dict(nbin=14, nlayer=21, dir_beam=1, albedo=0.1, clouds=1,
                                                                            g_0=0.2, scat_corr=1)])
 def test_fused_onthefly_with_the_matrix_method_vs_oracle(ctx, port, cfg):
