@@ -408,14 +408,14 @@ class Compute(object):
             quant.dev_F_add_heat_sum.set(np.asarray(quant.F_add_heat_sum, np.float64))
 
     def _fused_supported(self, quant):
-        # isothermal layers halve the segments per layer: 1024 of them fit the register-resident sweeps
+        # isothermal layers halve the segments per layer: 2048 of them fit the sweeps' tiles (32 rows x 64 lanes)
         # (`flux calculation method = matrix` runs in the same device-resident loop: hx_rt_flags.matrix; any number of
         # absorbers: the species loop on chip takes them in blocks of 48, csrc/rt_fused.hip refresh_species)
         why = None
         if quant.flux_calc_method not in ("iteration", "matrix"):
             why = "flux calculation method %r" % (quant.flux_calc_method,)
-        elif _i(quant.nlayer) > (1024 if quant.iso == 1 else 512):
-            why = "%d layers (the register-resident sweeps hold 512, 1024 isothermal ones)" % _i(quant.nlayer)
+        elif _i(quant.nlayer) > (2048 if quant.iso == 1 else 1024):
+            why = "%d layers (the sweeps' tiles hold 1024, 2048 isothermal ones)" % _i(quant.nlayer)
         if why is not None and self.use_fused and not getattr(self, "_told_stagewise", False):
             # not silent: the same kernels' per-stage entry points, every array through HBM at every stage -- measured
             # 5-10 times the device-resident loop's time per iteration

@@ -78,8 +78,15 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
     if (const char* e = getenv("HELIOS_RT_K")) force_k = atoi(e);  // tuning knob
     for (int pass = 0; pass < 2 && !best_k; pass++)
         for (int k = 8; k <= 64; k <<= 1) {
-            const int rows = (H + k - 1) / k;
-            if (rows > 16) continue;
+            int rows = (H + k - 1) / k;
+            if (rows > 16) {
+                // columns beyond 16 rows x 64 lanes (512 layers, 1024 isothermal ones): 20, 24, 28 or 32 rows on 64 lanes -- up
+                // to 1024 layers (2048 isothermal).  These instantiations keep part of their register image in scratch
+                // (k_rt_flux<32, 64>: 1.2 KB per lane); still one launch per iteration on compact planes instead of the
+                // per-stage path's sixteen arrays per stage (round 6)
+                if (k != 64 || rows > 32) continue;
+                rows = (rows + 3) / 4 * 4;
+            }
             if (force_k && k != force_k) continue;
             if (pass == 0 && flux_variant_spills(rows, k)) continue;
             int cost = k * rows * (k >= 16 ? 100 : 125);
@@ -258,6 +265,18 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
         f.cache_state_from = (int)std::max(0LL, total - keep);
     }
     const bool generic = rt->generic_scans;
+    if constexpr (ROWS > 16) {   // (only on 64 lanes: choose_geometry)
+        if (rt->matrix_scan) {
+            f.reverse = 0;
+            f.cache_state_from = INT_MAX;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 64, true>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                               rt->ctx->stream, f);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS, 64>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
+                               rt->ctx->stream, f);
+        }
+        return;
+    } else {
     if (rt->matrix_scan) {   // the direct solve: no state to leave in the cache for a next launch, no launch order to alternate
         f.reverse = 0;
         f.cache_state_from = INT_MAX;
@@ -287,6 +306,7 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rt_flux<ROWS>), dim3(g.nblk_x, rt->C), dim3(g.threads), shmem,
                            rt->ctx->stream, f);
+    }
 }
 template <int ROWS, int TPB>
 void launch_coef_tpb(hx_rt* rt, KArgs a) {
@@ -312,9 +332,19 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
     switch (rt->coef_tpb) {
         case 1: launch_coef_tpb<ROWS, 1>(rt, a); break;
         case 2: launch_coef_tpb<ROWS, 2>(rt, a); break;
-        case 8: launch_coef_tpb<ROWS, 8>(rt, a); break;
+        case 8:
+            if constexpr (ROWS <= 16) { launch_coef_tpb<ROWS, 8>(rt, a); break; }   // (big columns: at most four tiles fit the LDS)
+            [[fallthrough]];
         default: launch_coef_tpb<ROWS, 4>(rt, a); break;
     }
+}
+
+// LDS demand of k_rt_coef with `tpb` tiles per workgroup (launch_coef_tpb's formula, without the optional cloud image)
+size_t coef_shmem_bytes(const hx_rt* rt, int tpb) {
+    const TileGeom& g = rt->g;
+    const int TS = tpb * g.S;
+    const int NBX = g.nxb * ((tpb - 1) / (g.NW * g.nparts) + 2);
+    return ((size_t)(rt->L + rt->I) * TS + (size_t)rt->H * (NBX + 2)) * sizeof(double) + 2 * TS * sizeof(int);
 }
 
 #define DISPATCH_ROWS(fn, rt, a)                  \
@@ -334,25 +364,34 @@ void launch_coef(hx_rt* rt, const KArgs& a) {
         case 13: fn<13>(rt, a); break;            \
         case 14: fn<14>(rt, a); break;            \
         case 15: fn<15>(rt, a); break;            \
+        case 20: fn<20>(rt, a); break;            \
+        case 24: fn<24>(rt, a); break;            \
+        case 28: fn<28>(rt, a); break;            \
+        case 32: fn<32>(rt, a); break;            \
         default: fn<16>(rt, a); break;            \
     }
 
 template <int ROWS>
 void raise_flux_shmem(hx_rt* rt, int shmem) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    hipError_t e = hipSuccess;
+    if constexpr (ROWS <= 16) {
+        e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     if (rt->matrix_scan) {
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        if constexpr (ROWS <= 16) {
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
+        }
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)k_rt_flux<ROWS, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, shmem);
     }
@@ -423,7 +462,7 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     if (const char* e = getenv("HELIOS_RT_MATRIX")) rt->matrix_scan = rt->matrix && std::string(e) != "stage";
     rt->matrix_keep_state = rt->matrix_scan && flags->debug == 1;   // count_negative_fluxes reads the up-flux tiles
     if (!choose_geometry(rt->H, rt->Y, rt->X, rt->C, flags->dir_beam, flags->scat_corr, rt->g, rt->matrix_scan ? 1 : 0))
-        return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 512 (1024 isothermal layers); use the per-stage API");
+        return hx_fail(ctx, HX_E_UNSUPPORTED, "fused path supports nlayer <= 1024 (2048 isothermal layers); use the per-stage API");
     // bin chunks of the totals reduction: k_rt_totals_a wants many, _b few.  nbin/48 measured best at 10 000 bins;
     // a small grid keeps at least 32 chunks (of >= 8 bins) so that the first level still spreads over the chip
     rt->nchunk = std::max(1, std::min(512, std::max((rt->X + 47) / 48, std::min(32, (rt->X + 7) / 8))));
@@ -433,6 +472,9 @@ static int rt_create_into(hx_rt* rt, hx_context* ctx, const hx_rt_dims* dims, co
     // at k = 16, 8 at k = 32 (config 5, same box: 2 tiles 6.4 ms, 4 tiles 4.5 ms, 8 tiles 3.4 ms per refresh)
     rt->coef_tpb = std::max(1, std::min(8, 16 / std::max(1, rt->g.S)));    // (16 tiles per workgroup at k = 64: measured, no faster)
     if (const char* e = getenv("HELIOS_RT_COEF_TPB")) rt->coef_tpb = atoi(e);   // tuning knobs
+    while (rt->coef_tpb > 1 && coef_shmem_bytes(rt, rt->coef_tpb) > 150 * 1024) rt->coef_tpb /= 2;   // (deep columns: the staged layers of fewer tiles)
+    if (coef_shmem_bytes(rt, rt->coef_tpb) > 160 * 1024)
+        return hx_fail(ctx, HX_E_UNSUPPORTED, "k_rt_coef's staging of one tile exceeds the 160 KiB of LDS");
     if (const char* e = getenv("HELIOS_RT_NCHUNK")) rt->nchunk = std::max(1, std::min(4096, atoi(e)));  // tuning knob
     {
         // The up-flux state is the one array a k_rt_flux launch writes and the next one reads.  Where it is larger than

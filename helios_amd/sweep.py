@@ -279,8 +279,8 @@ def _run_columns(base_argv, overrides_list, cols, computer, writer, shared, colu
     groups = {}
     for q, reader in fresh:
         if not computer._fused_supported(q):
-            raise IOError("sweeps run on the fused device path: flux calculation method 'iteration' or 'matrix' and at most 512 "
-                          "layers (1024 isothermal ones); run this configuration column by column with helios.py")
+            raise IOError("sweeps run on the fused device path: flux calculation method 'iteration' or 'matrix' and at most 1024 "
+                          "layers (2048 isothermal ones); run this configuration column by column with helios.py")
         groups.setdefault(_batch_signature(q), []).append((q, reader))
     for members in groups.values():
         quants = [q for q, _ in members]

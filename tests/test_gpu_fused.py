@@ -33,7 +33,11 @@ FUSED_CONFIGS = {
     "L33_ny16": dict(nbin=9, nlayer=33, ny=16),
     "L400": dict(nbin=5, nlayer=400, clouds=1, g_0=0.1),   # k=64: one spectral point per wavefront, >64 KiB LDS in k_rt_coef
     "L200_i2s": dict(nbin=6, nlayer=200, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),  # config-5 flags: 4 planes + clouds
-    "L512": dict(nbin=3, nlayer=512, dir_beam=1),   # the fused path's largest column: k=64, 16 rows per lane
+    "L512": dict(nbin=3, nlayer=512, dir_beam=1),   # the largest column whose rows are all in registers: k=64, 16 rows per lane
+    # beyond it (round 6): 20, 24, 28, 32 rows on 64 lanes, part of the register image in scratch -- up to 1024 layers
+    "L600": dict(nbin=3, nlayer=600, dir_beam=1, albedo=0.2),            # 1200 half-layers: 20 rows (1280 slots)
+    "L1024_clouds": dict(nbin=2, nlayer=1024, clouds=1, g_0=0.1),        # 2048 half-layers: 32 rows, every slot in use
+    "iso_L1500": dict(iso=1, nbin=2, nlayer=1500, albedo=0.1),           # isothermal: 1500 segments, 24 rows
     "smallest": dict(nbin=2, nlayer=4),             # two bins, four layers (the height integration needs a layer below 10 bar)
     # fewer half-layers than the eight lanes of the smallest tiling (H = 6, 4 < k = 8: lanes without a row); a deeper bottom
     # boundary, because calculate_height_z (host_functions.py) starts from the lowest layer centre at >= 10 bar and the
@@ -269,6 +273,7 @@ MATRIX_CONFIGS = {
     "beam_forward": dict(nbin=16, nlayer=30, dir_beam=1, clouds=1, g_0=0.85, scat_corr=1, albedo=0.3, zenith_deg=85.0, T_star=9000.0),
     "ny1": dict(ny=1, nbin=17, albedo=0.1),
     "L105_i2s": dict(nbin=12, nlayer=105, clouds=1, scat_corr=1, g_0=0.2, albedo=0.1),
+    "L700_beam": dict(nbin=3, nlayer=700, dir_beam=1, albedo=0.2),      # the direct solve beyond 16 rows per lane: 24 rows (round 6)
 }
 
 
@@ -285,14 +290,14 @@ def test_fused_matrix_method_vs_oracle(ctx, port, name):
     # fluxes are therefore held, at the same 1e-9, to the extended-precision solution of the reference's system, with the
     # reference's distance from it asserted next to it.  Everything else, and the twelve-iteration run, against the oracle.
     import matrix_referee
-    deep = name in ("L100", "L200_beam", "L400_clouds", "L105_i2s")     # (the elimination over >= 400 unknowns, see above)
+    deep = name in ("L100", "L200_beam", "L400_clouds", "L105_i2s", "L700_beam")     # (the elimination over >= 400 unknowns, see above)
     for n_iter, rtol in ((1, 1e-9), (12, 5e-6 if deep else 1e-7)):
         f, grid = fh.run_fused(ctx, c0, n_iter, with_planck_grid=True)
         o = fh.run_oracle(port, c0, n_iter, planck_grid=grid)
         nscat = int(o["scat_trigger"].sum())      # both branches of the solver: "default" mixes them
         assert nscat == 0 if name == "noscat" else nscat > 0 and (name != "default" or nscat < o["scat_trigger"].size)
         if n_iter == 1:
-            matrix_referee.compare_first_solve(fh, f, o, c0, rtol, rtol_T=1e-7 if name in ("L200_beam", "L400_clouds") else None)
+            matrix_referee.compare_first_solve(fh, f, o, c0, rtol, rtol_T=1e-7 if name in ("L200_beam", "L400_clouds", "L700_beam") else None)
         else:
             fh.compare(f, o, c0, rtol=rtol)
 
@@ -389,26 +394,34 @@ def test_fused_full_size_vs_stage_kernels(ctx):
     np.testing.assert_allclose(f["F_down_tot"][-1], toa, rtol=1e-10)
 
 
-def test_fused_refuses_more_than_512_layers_and_the_driver_takes_the_stage_kernels(ctx, capsys):
-    """the register-resident sweeps hold at most 16 half-layers per lane x 64 lanes: beyond that hx_rt_create reports
-    HX_E_UNSUPPORTED and Compute runs the per-stage kernels instead (still on the GPU -- there is no CPU path) -- and says
-    so, once per run, with the reason (round 6: the 5-10x slower path is not taken silently)"""
+def test_fused_refuses_more_than_1024_layers_and_the_driver_takes_the_stage_kernels(ctx, capsys):
+    """the sweeps' tiles hold at most 32 half-layers per lane x 64 lanes (16 of them in registers; round 6: 20-32 with part of
+    the image in scratch): beyond 1024 layers hx_rt_create reports HX_E_UNSUPPORTED and Compute runs the per-stage kernels
+    instead (still on the GPU -- there is no CPU path) -- and says so, once per run, with the reason (the 5-10x slower path
+    is not taken silently)"""
     from helios_amd._lib import HeliosHipError
     from helios_amd.computation import Compute
-    c = cases.make_case(nbin=2, nlayer=513)
-    with pytest.raises(HeliosHipError, match="512"):
+    c = cases.make_case(nbin=2, nlayer=1025)
+    with pytest.raises(HeliosHipError, match="1024"):
         fh.run_fused(ctx, c, 1)
 
     class Q(object):
-        iso, singlewalk, flux_calc_method, nlayer = 0, 0, "iteration", 513
+        iso, singlewalk, flux_calc_method, nlayer = 0, 0, "iteration", 1025
     comp = Compute(ctx)
     assert not comp._fused_supported(Q())
     assert not comp._fused_supported(Q())
     out = capsys.readouterr().out
-    assert out.count("helios_amd: 513 layers") == 1 and "per-stage kernels" in out and "slower" in out
-    Q.nlayer = 512
+    assert out.count("helios_amd: 1025 layers") == 1 and "per-stage kernels" in out and "slower" in out
+    Q.nlayer = 1024
     assert comp._fused_supported(Q())
     assert capsys.readouterr().out == ""
+    import ctypes
+    from helios_amd import _lib
+    k, r = ctypes.c_int(), ctypes.c_int()
+    for L, iso, want in ((513, 0, (64, 20)), (640, 0, (64, 20)), (641, 0, (64, 24)), (1024, 0, (64, 32)), (2048, 1, (64, 32)), (1100, 1, (64, 20))):
+        assert _lib.lib().hx_rt_flux_geometry(L, iso, 0, 20, 100, 1, ctypes.byref(k), ctypes.byref(r)) == 0
+        assert (k.value, r.value) == want, (L, iso, k.value, r.value)
+    assert _lib.lib().hx_rt_flux_geometry(1025, 0, 0, 20, 100, 1, ctypes.byref(k), ctypes.byref(r)) != 0
 
 
 @pytest.mark.parametrize("name,ncol", [("L50", 1), ("clouds_g0", 3), ("L100", 2), ("L50+matrix", 1), ("clouds_g0+matrix", 2),

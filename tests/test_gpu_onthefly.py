@@ -139,16 +139,26 @@ def test_run_helios_with_debugging_feedback(tmp_path, capfd, fused):
     assert "negative flux" not in out and "malfunctioning" not in out
 
 
-def test_run_helios_with_more_layers_than_the_fused_path_holds(tmp_path):
-    """520 layers: hx_rt_* would refuse (limit 512), the driver runs the per-stage kernels and converges"""
+def test_run_helios_with_more_layers_than_the_fused_path_holds(tmp_path, capfd):
+    """1030 layers: hx_rt_* would refuse (limit 1024 since round 6, 512 before), the driver says so, runs the per-stage kernels
+    and converges; 520 layers -- beyond the old limit -- stay in the device-resident loop (k = 64, 20 rows per lane)"""
     argv = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "20 6 5 7",
-            "-number_of_layers", "520", "-maximum_number_of_iterations", "2000", "-name", "big",
+            "-number_of_layers", "1030", "-maximum_number_of_iterations", "2000", "-name", "big",
             "-output_directory", str(tmp_path) + "/", "-radiative_equilibrium_criterion", "1e-2",
             "-convective_adjustment", "no"]
     q = _run_driver(argv, True)
     assert q.rt is None and 3 < int(q.iter_value) < 2000
+    assert "helios_amd: 1030 layers" in capfd.readouterr().out
     from helios_amd import host_functions as hs
     assert abs(hs.global_energy_imbalance(q)) < 2e-2
+    argv[argv.index("1030")] = "520"
+    q2 = _run_driver(argv, True)
+    assert q2.rt is not None and 3 < int(q2.iter_value) < 2000
+    assert "helios_amd:" not in capfd.readouterr().out
+    assert abs(hs.global_energy_imbalance(q2)) < 2e-2
+    q3 = _run_driver(argv, False)         # ... and gives what the per-stage loop gives
+    assert int(q3.iter_value) == int(q2.iter_value)
+    np.testing.assert_allclose(q2.T_lay, q3.T_lay, rtol=1e-7)
 
 
 def test_run_helios_with_convection(tmp_path):
