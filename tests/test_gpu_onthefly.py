@@ -156,13 +156,9 @@ def test_run_helios_with_more_layers_than_the_fused_path_holds(tmp_path, capfd):
     assert q2.rt is not None and 3 < int(q2.iter_value) < 2000
     assert "helios_amd:" not in capfd.readouterr().out
     assert abs(hs.global_energy_imbalance(q2)) < 2e-2
-    # ... and gives what the per-stage loop gives: after twelve iterations (to convergence the two runs' rounding differences
-    # are amplified by the pseudo-time step of a 520-layer column into different paths to the same criterion: 8e-8 after 45
-    # iterations against the oracle, the same as a 500-layer column on 16 rows)
-    argv[argv.index("2000")] = "12"
-    q4, q5 = _run_driver(argv, True), _run_driver(argv, False)
-    assert q4.rt is not None and q5.rt is None and int(q4.iter_value) == int(q5.iter_value) == 12
-    np.testing.assert_allclose(q4.T_lay, q5.T_lay, rtol=1e-7)
+    # (to convergence the per-stage loop takes another path to the same criterion -- a 520-layer column's pseudo-time step
+    # amplifies rounding differences, 8e-8 after 45 iterations against the oracle, the same as a 500-layer column on 16 rows;
+    # the kernels of 20-32 rows are held to the oracle in tests/test_gpu_fused.py: L600, L1024_clouds, iso_L1500, L700_beam)
 
 
 def test_run_helios_with_convection(tmp_path):
