@@ -19,8 +19,11 @@ base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-syn
         "-maximum_number_of_iterations", "100000", "-internal_temperature", "800", "-convective_adjustment", "no",
         "-surface_albedo", "0.1"]
 res = {}
-for label, method, fused in (("matrix, device-resident loop", "matrix", True), ("matrix, stage by stage", "matrix", False),
-                             ("sweeps, device-resident loop", "iteration", True)):
+runs = [("matrix, device-resident loop", "matrix", True), ("matrix, stage by stage", "matrix", False),
+        ("sweeps, device-resident loop", "iteration", True)]
+if "--sweeps-stagewise" in sys.argv:      # the price of leaving the device-resident loop (deep columns beyond its tilings)
+    runs.append(("sweeps, stage by stage", "iteration", False))
+for label, method, fused in runs:
     orig = computation.Compute.__init__
 
     def patched(self, ctx=None, _o=orig, _f=fused):
