@@ -263,20 +263,25 @@ def init_process_group_checked(dist, backend, rank, world, device=None, timeout_
             % (who, backend, timeout_s, type(e).__name__, e))
         raise
     t1 = time.perf_counter()
+    # The roll call is a diagnostic, never a reason to fail: its own (shorter) deadline, the loopback interface when the
+    # rendezvous is local (a host whose name does not resolve may refuse gloo any other device), and every failure in it is
+    # reported and passed over -- the first collective on the real backend below is the test that counts.
     side, roll_call = None, True
+    roll_to = datetime.timedelta(seconds=min(float(timeout_s), 60.0))
     if backend != "gloo":
-        try:     # (a host whose name does not resolve may refuse gloo a network device: the roll call is a diagnostic, not a need)
-            side = dist.new_group(backend="gloo", timeout=to)
+        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        try:
+            side = dist.new_group(backend="gloo", timeout=roll_to)
         except Exception as e:
             log("helios_amd.parallel: %s: no gloo side group for the roll call (%s: %s); going on without"
                 % (who, type(e).__name__, e))
             roll_call = False
     if roll_call:
         try:
-            dist.monitored_barrier(group=side, timeout=to, wait_all_ranks=True)
+            dist.monitored_barrier(group=side, timeout=roll_to, wait_all_ranks=True)
         except Exception as e:
-            log("helios_amd.parallel: %s: roll call failed -- %s: %s" % (who, type(e).__name__, e))
-            raise
+            log("helios_amd.parallel: %s: roll call incomplete -- %s: %s" % (who, type(e).__name__, e))
     t2 = time.perf_counter()
     try:
         t = torch.ones(1, dtype=torch.float64, device=device if backend == "nccl" else "cpu")

@@ -142,6 +142,23 @@ def test_rccl_gathers_the_spectra_with_one_rank():
     assert "backend nccl" in p.stdout
 
 
+def test_checked_process_group_init_over_rccl_with_one_rank():
+    """bench.py's set-up of its ranks on the real backend, as far as one GPU allows: init with a deadline, the roll call on a
+    gloo side group (loopback interface), the first all-reduce on RCCL that must count every rank"""
+    code = ("import os, torch, torch.distributed as dist\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29537', RANK='0', WORLD_SIZE='1')\n"
+            "from helios_amd.parallel import init_process_group_checked, bind_to_gpu_numa_node\n"
+            "print('affinity', bind_to_gpu_numa_node(0, apply=False))\n"
+            "torch.cuda.set_device(0)\n"
+            "t = init_process_group_checked(dist, 'nccl', 0, 1, device=torch.device('cuda', 0), timeout_s=120.0)\n"
+            "assert dist.get_backend() == 'nccl' and set(t) == {'init_s', 'roll_call_s', 'first_collective_s'}, t\n"
+            "print('times', t, os.environ.get('GLOO_SOCKET_IFNAME'))\n"
+            "dist.destroy_process_group()\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "times" in p.stdout and " lo" in p.stdout.splitlines()[-1] and "roll call incomplete" not in p.stderr
+
+
 def test_bench_two_ranks_share_the_columns():
     env = dict(os.environ, HELIOS_BENCH_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
