@@ -59,7 +59,7 @@ def _cpu_baseline_will_run(argv, env):
 # process that runs the baseline: with binding on, the runtime pins the initial thread to place 0, i.e. the N ranks of a
 # multi-GPU run (and every rocprofv3 child pass) would issue their launches from one and the same core
 _OMP_SET_HERE = []
-if _cpu_baseline_will_run(sys.argv[1:], os.environ):
+if __name__ == "__main__" and _cpu_baseline_will_run(sys.argv[1:], os.environ):     # (never on import: tests import this module)
     for _k, _v in (("OMP_PROC_BIND", "close"), ("OMP_PLACES", "cores")):
         if _k not in os.environ:
             os.environ[_k] = _v

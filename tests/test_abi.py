@@ -149,7 +149,9 @@ def test_no_flux_kernel_serialises_its_tile_loads():
     # (the tilings of 15 and 16 rows keep part of their register image in scratch and are never selected: not held to it)
     selectable = {n: w for n, w in worst.items() if int(n.split("<")[1].split(",")[0]) <= 14}
     assert max(selectable.values()) <= 6, sorted(selectable.items(), key=lambda kv: -kv[1])[:5]
-    assert max(worst.values()) <= 8
+    # (round 6: the tilings of 20-32 rows -- columns of 513-1024 layers, 64 lanes only -- live partly in scratch and reload
+    # through few registers by construction; they are what such a column gets instead of the per-stage path, not held to it)
+    assert max(w for n, w in worst.items() if int(n.split("<")[1].split(",")[0]) <= 16) <= 8
     # rows x 7 tile loads (three to six coefficient planes, the state) are all there
     rows = int([n for n in dest if "k_rt_flux<13, 16, false>" in n][0].split("<")[1].split(",")[0])
     assert sum(dest[[n for n in dest if "k_rt_flux<13, 16, false>" in n][0]].values()) >= 7 * rows

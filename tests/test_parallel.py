@@ -181,8 +181,15 @@ def test_rank_binds_to_the_cores_of_its_gpus_numa_node(tmp_path):
     use; a sysfs that is not there (this container), an unknown node or a UUID-style visible-devices list leave the process
     alone and say why"""
     from helios_amd import parallel as par
+    before = set(os.sched_getaffinity(0))
+    try:        # (an OpenMP runtime loaded by an earlier test may have pinned this thread to one core: ask for all again)
+        os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
+    except OSError:
+        pass
     allowed = sorted(os.sched_getaffinity(0))
-    assert len(allowed) >= 2
+    if len(allowed) < 2:
+        os.sched_setaffinity(0, before)
+        pytest.skip("one usable core: nothing to bind to")
     lo, hi = allowed[: len(allowed) // 2], allowed[len(allowed) // 2:]
     as_list = lambda cpus: ",".join(str(c) for c in cpus) + ",4090-4095"      # (cores this process may not use are ignored)
     root = str(tmp_path)
@@ -206,7 +213,7 @@ def test_rank_binds_to_the_cores_of_its_gpus_numa_node(tmp_path):
         r = par.bind_to_gpu_numa_node(0, sysfs=os.path.join(root, "nothing_here"), env={})
         assert not r["bound"] and r["gpu"] == 0 and sorted(os.sched_getaffinity(0)) == allowed
     finally:
-        os.sched_setaffinity(0, allowed)
+        os.sched_setaffinity(0, before)
 
 
 def _init_worker(rank, world, port, q, late):
