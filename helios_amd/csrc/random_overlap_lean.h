@@ -63,15 +63,16 @@ struct Shared {
 static_assert(sizeof(Shared) <= 6880, "twenty wavefronts per CU: 8 KB each with the species list of k_rt_mix_species");
 static_assert(offsetof(Shared, tab) % 16 == 0 && offsetof(Shared, tab) >= 4 * sizeof(Cell), "aligned table; entry -4 stays inside the struct");
 
-// A lane's place in the run layout (random_overlap.h, run_lane), packed: kept in two registers through the kernel and
-// unpacked per problem.
-//   a: byte offset (from the start of Shared) of the fixed table operand | byte offset of slot 0's varying operand << 16
-//   b: cell code of slot 0, i0 << 5 | j0 as a signed 16-bit number (i0 = -4 in front of a column piece) | code step per slot
-//      << 16 (1 along a row, 32 down a column) | padlow << 24 | padhigh << 25 | col << 26
-// col: the lane walks down a column (i steps) instead of along a row; padlow: its slots 0-3 are low padding; padhigh: all its
-// slots are high padding.
+// A lane's place in the run layout (random_overlap.h, run_lane): seven registers kept through the kernel (round 6 first
+// packed them into two and unpacked per problem, nine instructions; with the search's literals out of the register file there
+// is room for them as they are -- 94 VGPRs).
+//   fix, var: byte offsets (from the start of Shared) of the fixed table operand and of slot 0's varying operand
+//   t0, tstep: cell code of slot 0, i0 << 5 | j0 (i0 = -4 in front of a column piece), and its step per slot (1 along a row,
+//              32 down a column: the lane walks down a column instead of along a row)
+//   aklo, oklo, padhi: slots 0-3 take (key & aklo) | oklo, slots 4-7 key | padhi -- (~0, 0, 0) for sums, (0, LOWKEY, 0) where the
+//              lane's slots 0-3 are low padding, (~0, ~0, ~0) where all its slots are high padding
 struct LaneConst {
-    unsigned a, b;
+    unsigned fix, var, t0, tstep, aklo, oklo, padhi;
 };
 
 __device__ __forceinline__ LaneConst lane_const(int lane) {
@@ -85,9 +86,13 @@ __device__ __forceinline__ LaneConst lane_const(int lane) {
     else if (blk < 28 && idx0 == 0) { j = 16 + (blk - 24); i = 12; col = 1; padhigh = 0; }         // column j, rows 12 ... 19
     const unsigned o = TAB + CS * i, p = TAB + CS * j + IP_OFF;   // (i = -4: the four cells in front of the table, inside E: any bits do)
     LaneConst lc;
-    lc.a = (col ? p : o) | (col ? o : p) << 16;
-    lc.b = (unsigned)(((i << 5) + j) & 0xFFFF) | (unsigned)(col ? 32 : 1) << 16 | (unsigned)padlow << 24 | (unsigned)padhigh << 25 |
-           (unsigned)col << 26;
+    lc.fix = col ? p : o;
+    lc.var = col ? o : p;
+    lc.t0 = (unsigned)((i << 5) + j);
+    lc.tstep = col ? 32u : 1u;
+    lc.padhi = padhigh ? ~0u : 0u;
+    lc.aklo = padlow ? 0u : ~0u;
+    lc.oklo = padlow ? LOWKEY : lc.padhi;
     return lc;
 }
 
@@ -184,9 +189,11 @@ __device__ __forceinline__ int locate(const Shared& sh, int lane, double& yq, un
         // are 7 << k, written as `select 0 or 7, shift-add`: as byte counts they are 32-bit literals, which the select cannot
         // take as an operand and the compiler therefore parks in five registers for the whole kernel.  Same probes as before.
         static_assert(NP == 449, "the step sequence below is halving 449 cells");
+        unsigned seven = 7u;
+        asm volatile("" : "+v"(seven));     // (opaque: the compiler folds `select 0 or 7, shift` back into a select of parked literals)
 #pragma unroll
         for (int k = 8; k >= 4; k--) {      // 7 << (k - 3) cells = 7 << k bytes
-            const unsigned m = *(const double*)(Bb + pb + (7u << k) - 8) > yq ? 0u : 7u;
+            const unsigned m = *(const double*)(Bb + pb + (7u << k) - 8) > yq ? 0u : seven;
             pb += m << k;
         }
         pb += *(const double*)(Bb + pb + 56 - 8) > yq ? 0u : 56u;
@@ -258,25 +265,26 @@ template <bool CROSSING, bool HI>
 __device__ __forceinline__ void fill_runs(const Shared& sh, LaneConst lc, Keys& v, int yx, int hmin, int sh_bits) {
     constexpr int TB = CROSSING ? 11 : 10;
     const char* base = (const char*)&sh;
-    const unsigned fix = lc.a & 0xFFFFu, var = lc.a >> 16;
-    const unsigned nlow = (unsigned)__builtin_amdgcn_sbfe((int)lc.b, 24, 1), padhi = (unsigned)__builtin_amdgcn_sbfe((int)lc.b, 25, 1);  // 0 or ~0
-    unsigned lowkey = LOWKEY;
-    asm volatile("" : "+v"(lowkey));   // made here: as the literal operand of an and-or it would be parked in a register for the whole kernel
-    const unsigned aklo = ~nlow, oklo = (nlow & lowkey) | padhi;
+    const unsigned fix = lc.fix, var = lc.var, aklo = lc.aklo, oklo = lc.oklo, padhi = lc.padhi;
     const double F = *(const double*)(base + fix);
-    const int t0 = __builtin_amdgcn_sbfe((int)lc.b, 0, 16), tstep = (int)__builtin_amdgcn_ubfe(lc.b, 16, 6);
+    // q = (bits(K) >> sh) - (base >> sh) with the base a multiple of 2^sh (mix): the wave-uniform second term, shifted to the
+    // keys' q field, goes into the lane's cell code once instead of into every slot (all of it modulo 2^32: the key fits)
+    const unsigned qbase = HI ? (unsigned)hmin >> (sh_bits - 32) : (sh_bits ? (unsigned)hmin << (32 - sh_bits) : 0u);
+    const unsigned koff = qbase << TB;
+    const unsigned t0 = lc.t0 - koff, tstep = lc.tstep;
 #pragma unroll
     for (int r = 0; r < SLOTS; r++) {
         const double K = F + *(const double*)(base + var + (unsigned)sizeof(Cell) * r);   // padding: inf, or any bits (masked below)
-        int t = t0 + tstep * r;
+        unsigned t = t0 + tstep * (unsigned)r;
         if (CROSSING) {
             // (i, j) of this slot from its code: the low five bits never carry (j0 + r <= 15 along a row, j fixed down a column)
-            const int i = t >> 5, j = t & 31;
-            t = j < yx ? t : (1 << 10 | j << 5 | i);
+            const unsigned tc = t + koff;
+            const int i = (int)tc >> 5, j = (int)(tc & 31u);
+            t = j < yx ? t : (1u << 10 | (unsigned)j << 5 | (unsigned)i) - koff;
         }
-        const unsigned dh = (unsigned)(__double2hiint(K) - hmin);
-        const unsigned q = HI ? dh >> (sh_bits - 32) : __builtin_amdgcn_alignbit(dh, (unsigned)__double2loint(K), sh_bits);
-        const unsigned key = (q << TB) + (unsigned)t;
+        const unsigned qraw = HI ? (unsigned)__double2hiint(K) >> (sh_bits - 32)
+                                 : __builtin_amdgcn_alignbit((unsigned)__double2hiint(K), (unsigned)__double2loint(K), sh_bits);
+        const unsigned key = (qraw << TB) + (unsigned)t;
         v.k[r] = r < SLOTS / 2 ? (key & aklo) | oklo : key | padhi;
     }
 }
@@ -409,9 +417,9 @@ __device__ __forceinline__ double finish_and_rebin(Shared& sh, int lane, Keys& v
 // point and receive the mixed value (kernels.cu:3293-3396, ro_method == 1, s > 0, ny == 20).  All 64 lanes must call.
 __device__ __forceinline__ double mix(Shared& sh, LaneConst lc, int lane, double my_mix, double my_add, Counters& cnt) {
     RO_MARK("prologue");
-    // what depends on the lane alone is derived again in every problem, from these opaque copies: it does not occupy
-    // registers between the problems
-    asm volatile("" : "+v"(lane), "+v"(lc.a), "+v"(lc.b));
+    // what depends on the lane alone is derived again in every problem, from these opaque copies: only the seven numbers
+    // themselves occupy registers between the problems, not the eight addresses and eight codes that follow from them
+    asm volatile("" : "+v"(lane), "+v"(lc.fix), "+v"(lc.var), "+v"(lc.t0), "+v"(lc.tstep));
     // corners of the tableau, wave-uniform (v_readlane: scalar results, no address registers)
     const double m0 = lane_value<0>(my_mix), a0 = lane_value<0>(my_add), m19 = lane_value<NY - 1>(my_mix), a19 = lane_value<NY - 1>(my_add);
     // less than 1 % of the other everywhere: correlated-k (:3297-3310)
@@ -478,11 +486,20 @@ __device__ __forceinline__ double mix(Shared& sh, LaneConst lc, int lane, double
         ((unsigned long long)(unsigned)(__builtin_amdgcn_readfirstlane(__double2hiint(kmax)) - hk) << 32) |
         (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(kmax));
     const int bl0 = span ? 64 - __clzll((long long)span) : 0;
-    const int bias = 1 << max(0, bl0 - QB - 31);                       // in units of 2^32: >= 2^sh once sh is settled below
-    const int hmin = hk - bias;
+    const int bias = 1 << max(0, bl0 - QB - 30);                       // in units of 2^32: >= 2^(sh + 1) once sh is settled below
+    int hmin = hk - bias;
     const unsigned long long dmax = span + ((unsigned long long)(unsigned)bias << 32);
     const int bl = 64 - __clzll((long long)dmax);
-    const int sh_bits = bl > QB ? bl - QB : 0;
+    int sh_bits = bl > QB ? bl - QB : 0;
+    // The base hmin << 32 is made a multiple of 2^sh, so that a slot's q is (bits(K) >> sh) minus a wave-uniform number and the
+    // subtraction moves out of the slots into the lane's cell code (fill_runs).  With sh <= 32 it is one already; beyond, hmin
+    // is rounded down to a multiple of 2^(sh - 32) -- every q grows by at most one, which the scale allows for (one more shift
+    // where the largest q would touch 2^QB; the bias above keeps the smallest q at one or more either way).
+    if (sh_bits > 32) {
+        const unsigned long long slack = ((1ull << (sh_bits - 32)) - 1ull) << 32;
+        if (64 - __clzll((long long)(dmax + slack)) > bl) sh_bits++;
+        hmin &= ~((1 << (sh_bits - 32)) - 1);
+    }
     Keys v;
     ro::Lane lnc;   // the network reads the three low lane bits as masks from here
 #pragma unroll
