@@ -89,8 +89,6 @@ WORKLOADS = {
     "c2beam": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, dir_beam=1, albedo=0.1,
                    desc="config 2's grid with the direct stellar beam and a surface albedo (five coefficient planes, "
                         "13 rows per lane)"),
-    "c5small": dict(nbin=600, nlayer=200, ny=20, ntemp=6, npress=5, nspecies=6, clouds=2, albedo="smoothed", scat_corr=1,
-                    g_0=0.3, dir_beam=1, desc="config 5's physics at 600 bins x 200 layers x 6 species (quick check)"),
     "c4": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=64, sweep=True,
                desc="BASELINE config 4, one GPU's share of the 512-column sweep at 8 GPUs: 64 columns per GPU (g x a x "
                     "T_intern grid), on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
@@ -113,9 +111,6 @@ WORKLOADS = {
                       "sweep columns, on-the-fly mixing of the 15 species of the reference's input/species.dat: 13 absorbers -- the "
                       "first and the two CIA pairs correlated-k, ten by random overlap --, Rayleigh scattering by H2O (computed), "
                       "CO2, CO, H2, He"),
-    "c4x8": dict(nbin=10000, nlayer=100, ny=20, ntemp=30, npress=20, nspecies=20, columns_per_gpu=8, sweep=True,
-                 desc="BASELINE config 4 at reduced width: 8 columns of the 512-column sweep (g x a x T_intern grid) in one "
-                      "batch on one GPU, on-the-fly mixing of 20 species (random overlap), 10 000 bins x 100 layers"),
 }
 
 
@@ -361,7 +356,7 @@ def load_counters(workload):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None, None
-    alias = {"c4": "c3", "c4x8": "c3"}      # same kernels on the same column shape: per-column figures scale with the column count
+    alias = {"c4": "c3"}      # same kernels on the same column shape: per-column figures scale with the column count
     with open(tpath) as f:
         d = json.load(f).get(alias.get(workload, workload))
     src = "profiles/traffic.json" + (" (per column, measured on %s)" % alias[workload] if workload in alias else "")
