@@ -10,11 +10,12 @@
 //    abscissae (3.6 KB): 6.9 KB per wavefront with the tables, 7.9 KB with the species list of k_rt_mix_species -- twenty
 //    wavefronts share a CU's 160 KB.
 //  * Registers.  The compiler hoists everything that depends on the lane alone out of the problem loop -- eight cell addresses,
-//    eight fill positions, scan and search offsets: 55 of the old kernel's 128 VGPRs (tools/vgpr_liveness.py).  Here a lane's
-//    place in the run layout is TWO packed dwords (LaneConst), unpacked behind an optimisation barrier in every problem
-//    (a dozen vector instructions), and what the phases derive from the lane id is derived from an opaque copy of it.
-//  * The sums are fetched in fp64 only where two neighbouring keys share a quantised sum (the exact finish of
-//    random_overlap.h can have work only there: q is monotone in K); otherwise the sorted keys are final as they are.
+//    eight fill positions, scan and search offsets, 32-bit literals its VOP3 encodings cannot hold: 55 of the old kernel's 128
+//    VGPRs (tools/vgpr_liveness.py).  Here a lane's place in the run layout is seven numbers (LaneConst) passed through an
+//    optimisation barrier in every problem, and what the phases derive from the lane id is derived from an opaque copy of it.
+//  * One decode per slot -- a key's cell as two table offsets -- serves the exact test on the fp64 sums (always made: an
+//    "equal quantised sums?" pre-test in front of it fired in most problems and cost more than it saved) and the weights of
+//    the scan.
 //
 // Same permutation, same arithmetic, same bits as random_overlap.h (tests/test_gpu_stages.py::test_random_overlap_orderings_
 // vs_oracle holds the kernels to each other bit for bit).  Reference: kernels.cu:3263-3399, sort :3152-3171.
@@ -27,7 +28,6 @@ using ro::Counters;
 using ro::Keys;
 using ro::N;
 using ro::NY;
-using ro::Pair;
 using ro::RANK0;
 using ro::SLOTS;
 
@@ -64,8 +64,8 @@ static_assert(sizeof(Shared) <= 6880, "twenty wavefronts per CU: 8 KB each with 
 static_assert(offsetof(Shared, tab) % 16 == 0 && offsetof(Shared, tab) >= 4 * sizeof(Cell), "aligned table; entry -4 stays inside the struct");
 
 // A lane's place in the run layout (random_overlap.h, run_lane): seven registers kept through the kernel (round 6 first
-// packed them into two and unpacked per problem, nine instructions; with the search's literals out of the register file there
-// is room for them as they are -- 94 VGPRs).
+// packed them into two and unpacked per problem, twelve instructions; with the search's literals out of the register file
+// there is room for them as they are -- 93 VGPRs in k_rt_mix_species).
 //   fix, var: byte offsets (from the start of Shared) of the fixed table operand and of slot 0's varying operand
 //   t0, tstep: cell code of slot 0, i0 << 5 | j0 (i0 = -4 in front of a column piece), and its step per slot (1 along a row,
 //              32 down a column: the lane walks down a column instead of along a row)
