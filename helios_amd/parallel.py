@@ -240,6 +240,29 @@ def bind_to_gpu_numa_node(local_index, sysfs="/sys", env=None, apply=True):
     return out
 
 
+class _stdout_to_stderr(object):
+    """file descriptor 1 points at file descriptor 2 inside the block (what C++ libraries print goes along), if `active`"""
+
+    def __init__(self, active=True):
+        self.active, self.saved = active, None
+
+    def __enter__(self):
+        if self.active:
+            import sys
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None:
+            import sys
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 def init_process_group_checked(dist, backend, rank, world, device=None, timeout_s=180.0, log=None):
     """`init_process_group` with a deadline, and a roll call before the first real collective: a gloo side group's
     `monitored_barrier` names the ranks that did not arrive (RCCL itself only hangs or aborts), then one all-reduce on
@@ -268,20 +291,21 @@ def init_process_group_checked(dist, backend, rank, world, device=None, timeout_
     # reported and passed over -- the first collective on the real backend below is the test that counts.
     side, roll_call = None, True
     roll_to = datetime.timedelta(seconds=min(float(timeout_s), 60.0))
-    if backend != "gloo":
-        if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        try:
-            side = dist.new_group(backend="gloo", timeout=roll_to)
-        except Exception as e:
-            log("helios_amd.parallel: %s: no gloo side group for the roll call (%s: %s); going on without"
-                % (who, type(e).__name__, e))
-            roll_call = False
-    if roll_call:
-        try:
-            dist.monitored_barrier(group=side, timeout=roll_to, wait_all_ranks=True)
-        except Exception as e:
-            log("helios_amd.parallel: %s: roll call incomplete -- %s: %s" % (who, type(e).__name__, e))
+    with _stdout_to_stderr(backend != "gloo"):     # (gloo announces its connections on stdout: not in front of a bench line)
+        if backend != "gloo":
+            if os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            try:
+                side = dist.new_group(backend="gloo", timeout=roll_to)
+            except Exception as e:
+                log("helios_amd.parallel: %s: no gloo side group for the roll call (%s: %s); going on without"
+                    % (who, type(e).__name__, e))
+                roll_call = False
+        if roll_call:
+            try:
+                dist.monitored_barrier(group=side, timeout=roll_to, wait_all_ranks=True)
+            except Exception as e:
+                log("helios_amd.parallel: %s: roll call incomplete -- %s: %s" % (who, type(e).__name__, e))
     t2 = time.perf_counter()
     try:
         t = torch.ones(1, dtype=torch.float64, device=device if backend == "nccl" else "cpu")

@@ -157,6 +157,7 @@ def test_checked_process_group_init_over_rccl_with_one_rank():
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "times" in p.stdout and " lo" in p.stdout.splitlines()[-1] and "roll call incomplete" not in p.stderr
+    assert "[Gloo]" not in p.stdout        # (the side group's connection messages go to stderr: nothing in front of a bench line)
 
 
 def test_bench_two_ranks_share_the_columns():
