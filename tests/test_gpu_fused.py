@@ -310,6 +310,27 @@ def test_fused_matrix_method_vs_oracle(ctx, port, name):
             fh.compare(f, o, c0, rtol=rtol)
 
 
+def test_fused_matrix_method_counts_the_negative_fluxes_it_flips(ctx, port):
+    """debug = 1: the direct solve counts the genuinely negative fluxes it replaces by their absolute value
+    (hx_diag.matrix_negative; the reference does so row by row during its back-substitution, kernels.cu:2268, and carries the
+    flipped value on -- the one place where the three scans and the elimination can part).  A grazing beam into strongly
+    forward-scattering clouds over a dark surface, hot and cold: no negative flux anywhere, none counted, and the spectral
+    fluxes on the oracle's to 1e-11"""
+    for cold in (1.0, 0.2):
+        c0 = cases.make_case(nbin=16, nlayer=60, dir_beam=1, clouds=1, g_0=0.99, scat_corr=1, albedo=0.01, zenith_deg=89.5,
+                             T_star=40000.0, f_factor=1.0)
+        c0.flux_calc_method, c0.debug = "matrix", 1
+        c0.T_lay = c0.T_lay * cold
+        ctx.diag_reset()
+        f, grid = fh.run_fused(ctx, c0, 1, with_planck_grid=True)
+        d = ctx.diag()
+        assert d["matrix_negative"] == 0 and d["negative_down_flux"] == 0 and d["negative_up_flux"] == 0, d
+        o = fh.run_oracle(port, c0, 1, planck_grid=grid)
+        for k in ("F_down_wg", "F_up_wg"):
+            np.testing.assert_allclose(f[k], o[k], rtol=1e-9, atol=1e-11 * np.abs(o[k]).max(), err_msg=k)
+    ctx.diag_reset()
+
+
 def test_fused_matrix_method_batch_of_columns(ctx, port):
     """the matrix solve column by column inside one batch: three start profiles == three single runs, and a column whose
     loop has ended (its own, loose criterion) keeps the fluxes of its last iteration while the others go on"""
