@@ -78,9 +78,6 @@ class Compute(object):
         if d["negative_down_flux"] or d["negative_up_flux"]:
             print("WARNING WARNING WARNING WARNING -- negative flux found: %d downward, %d upward values !!!"
                   % (d["negative_down_flux"], d["negative_up_flux"]))
-        if d.get("matrix_negative"):
-            print("WARNING: the direct solve of the matrix method made %d negative fluxes positive (kernels.cu:2268 does so row by "
-                  "row and carries the flipped value on; HELIOS_RT_MATRIX=stage runs that elimination) !!!" % d["matrix_negative"])
         if d["g_limited"]:
             print("WARNING: G_functions are being artificially limited!!! (%d values)" % d["g_limited"])
         if d["ro_rebin_skipped"]:

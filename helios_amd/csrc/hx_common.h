@@ -17,7 +17,7 @@ struct hx_context {
 };
 
 // slots of hx_context::diag (the layout of hx_diag in include/helios_hip.h)
-enum { HX_DIAG_NEG_DOWN = 0, HX_DIAG_NEG_UP = 1, HX_DIAG_G_LIMITED = 2, HX_DIAG_RO_REBIN = 3, HX_DIAG_ENERGY = 4, HX_DIAG_RO_FIXUP = 5, HX_DIAG_MATRIX_NEGATIVE = 6,
+enum { HX_DIAG_NEG_DOWN = 0, HX_DIAG_NEG_UP = 1, HX_DIAG_G_LIMITED = 2, HX_DIAG_RO_REBIN = 3, HX_DIAG_ENERGY = 4, HX_DIAG_RO_FIXUP = 5,
        HX_DIAG_SLOTS = 8 };
 
 // post-pass counters used by the debug = 1 variants of the per-stage and fused solvers (context.hip)

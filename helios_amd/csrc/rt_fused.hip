@@ -253,7 +253,6 @@ void launch_flux(hx_rt* rt, const KArgs& a) {
     f.F_up_band_n = a.F_up_band_n;
     f.coef_col = a.coef_col; f.flux_col = a.flux_col;
     f.done = a.done;
-    f.diag = a.diag;
     // Serpentine order over the iterations: the workgroups of an odd launch take the tiles from the far end, so the
     // tiles the previous launch touched last -- still in the 256 MiB Infinity Cache -- are the ones this launch asks
     // for first.  Same bits (workgroups are independent).

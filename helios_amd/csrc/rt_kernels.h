@@ -67,7 +67,6 @@ struct FluxArgs {
     double *Utile, *Dtile, *U0, *F_down_band_n, *F_up_band_n;
     size_t coef_col, flux_col;
     const int* done;
-    unsigned long long* diag;   // hx_context::diag when the batch runs with debug = 1, else nullptr (matrix method: negative fluxes)
 };
 
 __device__ __forceinline__ double interface_T(const double* T, int i, int L) {
@@ -910,7 +909,6 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
             const bool flip_negative = scatters && !a.iso;
             const double tiny_d = scatters ? 0.0 : 1e-100;
             const double tiny_u_even = scatters ? 0.0 : ((a.iso || odd0) ? 1e-100 : 0.0), tiny_u_odd = scatters ? 0.0 : ((a.iso || !odd0) ? 1e-100 : 0.0);
-            unsigned nflip = 0;   // genuinely negative values made positive (debug = 1: hx_diag.matrix_negative)
             auto patch = [&](double v, double tiny) { return flip_negative ? (v < 1e-100 ? fabs(v) : v) : tiny_abs_below(v, tiny); };
             // ---------------- rho: surface -> TOA ----------------
             // (the tiles' padding rows and lanes hold alpha = 1, beta = 0: the identity)
@@ -1004,16 +1002,12 @@ __global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
                 if (m.j == k - 1) D = D_toa;
 #pragma unroll
                 for (int r = ROWS - 1; r >= 0; r--) {
-                    const double u_raw = fma(Uo[r], D, su[r]);
-                    Uo[r] = patch(u_raw, (r & 1) ? tiny_u_odd : tiny_u_even);   // U at the top node, D there still in hand
-                    const double d_raw = fma(al[r], D, sd[r]);
-                    D = patch(d_raw, tiny_d);
+                    Uo[r] = patch(fma(Uo[r], D, su[r]), (r & 1) ? tiny_u_odd : tiny_u_even);   // U at the top node, D there still in hand
+                    D = patch(fma(al[r], D, sd[r]), tiny_d);
                     Do[r] = D;
-                    if (a.diag != nullptr && flip_negative && m.j * ROWS + r < a.H) nflip += (u_raw < 0.0 ? 1u : 0u) + (d_raw < 0.0 ? 1u : 0u);
                 }
             }
             if (m.j == 0) U0 = patch(fma(albedo, Do[0], sigma0), 0.0);
-            if (a.diag != nullptr && nflip) atomicAdd(a.diag + HX_DIAG_MATRIX_NEGATIVE, (unsigned long long)nflip);
         } else
         for (int sweep = 0; sweep < a.nsweep; sweep++) {
             // ---------------- down: TOA -> BOA ----------------

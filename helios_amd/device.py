@@ -14,7 +14,7 @@ class HxDiag(ctypes.Structure):
     _fields_ = [("negative_down_flux", ctypes.c_uint64), ("negative_up_flux", ctypes.c_uint64),
                 ("g_limited", ctypes.c_uint64), ("ro_rebin_skipped", ctypes.c_uint64),
                 ("energy_correction", ctypes.c_double), ("ro_fixup_passes", ctypes.c_uint64),
-                ("matrix_negative", ctypes.c_uint64), ("reserved", ctypes.c_uint64 * 1)]
+                ("reserved", ctypes.c_uint64 * 2)]
 
 
 class Context(object):

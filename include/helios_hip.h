@@ -58,12 +58,7 @@ typedef struct hx_diag {
     double energy_correction;    /* factor applied by the last hx_corr_inc_energy (0 = none yet) */
     uint64_t ro_fixup_passes;    /* exact odd-even passes add_to_mixed_opac ran after its quantised-key sort (a cost
                                     figure: how often two pair sums of different rows agree to 2^-18) */
-    uint64_t matrix_negative;    /* matrix method inside the device-resident loop, debug = 1: genuinely negative fluxes the direct
-                                    solve replaced by their absolute value (kernels.cu:2268 does so during its back-substitution
-                                    and carries the flipped value into the rows below; the three scans flip each value once it is
-                                    produced: where this counter is not zero the two can differ, HELIOS_RT_MATRIX=stage runs
-                                    the reference-shaped elimination) */
-    uint64_t reserved[1];
+    uint64_t reserved[2];
 } hx_diag;
 int hx_diag_read(hx_context* ctx, hx_diag* out);
 int hx_diag_reset(hx_context* ctx);

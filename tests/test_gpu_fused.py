@@ -310,12 +310,13 @@ def test_fused_matrix_method_vs_oracle(ctx, port, name):
             fh.compare(f, o, c0, rtol=rtol)
 
 
-def test_fused_matrix_method_counts_the_negative_fluxes_it_flips(ctx, port):
-    """debug = 1: the direct solve counts the genuinely negative fluxes it replaces by their absolute value
-    (hx_diag.matrix_negative; the reference does so row by row during its back-substitution, kernels.cu:2268, and carries the
-    flipped value on -- the one place where the three scans and the elimination can part).  A grazing beam into strongly
-    forward-scattering clouds over a dark surface, hot and cold: no negative flux anywhere, none counted, and the spectral
-    fluxes on the oracle's to 1e-11"""
+def test_fused_matrix_method_where_negative_fluxes_would_show(ctx, port):
+    """the one place where the three scans and the reference's elimination can part is a genuinely negative flux: the reference
+    replaces it by its absolute value row by row during the back-substitution (kernels.cu:2268) and carries the flipped value
+    on, the scans flip each value once it is produced.  The regime that could produce one -- a grazing beam into strongly
+    forward-scattering clouds over a dark surface, under a hot star, the column hot and five times colder -- yields none
+    (debug = 1: no negative flux counted after the solve) and spectral fluxes on the oracle's to 1e-11.  (A counter inside
+    the solve was built and measured: +1.5 % on the memory-bound kernel for an event never seen; not kept.)"""
     for cold in (1.0, 0.2):
         c0 = cases.make_case(nbin=16, nlayer=60, dir_beam=1, clouds=1, g_0=0.99, scat_corr=1, albedo=0.01, zenith_deg=89.5,
                              T_star=40000.0, f_factor=1.0)
@@ -324,9 +325,10 @@ def test_fused_matrix_method_counts_the_negative_fluxes_it_flips(ctx, port):
         ctx.diag_reset()
         f, grid = fh.run_fused(ctx, c0, 1, with_planck_grid=True)
         d = ctx.diag()
-        assert d["matrix_negative"] == 0 and d["negative_down_flux"] == 0 and d["negative_up_flux"] == 0, d
+        assert d["negative_down_flux"] == 0 and d["negative_up_flux"] == 0, d
         o = fh.run_oracle(port, c0, 1, planck_grid=grid)
         for k in ("F_down_wg", "F_up_wg"):
+            assert o[k].min() >= 0.0
             np.testing.assert_allclose(f[k], o[k], rtol=1e-9, atol=1e-11 * np.abs(o[k]).max(), err_msg=k)
     ctx.diag_reset()
 

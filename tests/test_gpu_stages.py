@@ -290,7 +290,7 @@ def test_diagnostics_record(hip, port):
     rng = np.random.default_rng(4)
     ctx.diag_reset()
     assert ctx.diag() == dict(negative_down_flux=0, negative_up_flux=0, g_limited=0, ro_rebin_skipped=0,
-                              energy_correction=0.0, ro_fixup_passes=0, matrix_negative=0)
+                              energy_correction=0.0, ro_fixup_passes=0)
     # energy correction
     nbin = 64
     star, dl = rng.uniform(1e5, 1e6, nbin), rng.uniform(1e-6, 1e-5, nbin)
