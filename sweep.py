@@ -25,16 +25,21 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist, coll_device = None, "cpu"
     if world > 1:
+        backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")     # "gloo": all ranks on GPU 0 (single-GPU machines)
+        device_index = local_rank if backend == "nccl" else 0
+        # every rank like bench.py's: onto the host cores of its GPU's NUMA node before its first GPU call, the process group
+        # with a deadline, a roll call and a first collective that must count every rank (helios_amd/parallel.py)
+        from helios_amd import parallel
+        parallel.bind_to_gpu_numa_node(device_index)
         import torch
         import torch.distributed as dist
-        backend = os.environ.get("HELIOS_BENCH_BACKEND", "nccl")     # "gloo": all ranks on GPU 0 (single-GPU machines)
+        torch.cuda.set_device(device_index)
+        parallel.init_process_group_checked(dist, backend, int(os.environ.get("RANK", "0")), world,
+                                            device=torch.device("cuda", device_index),
+                                            timeout_s=float(os.environ.get("HELIOS_INIT_TIMEOUT", "180")))
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             coll_device = "cuda"
             os.environ["HELIOS_DEVICE"] = str(local_rank)
-        else:
-            dist.init_process_group(backend)
     from helios_amd import sweep as sw
     overrides = sw.expand_sweep(spec)
     columns, spectra = sw.run_sweep(base, overrides, dist, coll_device)
