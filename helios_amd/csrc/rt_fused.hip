@@ -114,7 +114,9 @@ bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, Ti
     // Gauss points of their bins at once (18 us).  Measured cross-over: about one single-wavefront workgroup per SIMD.
     // HELIOS_RT_MAXTHREADS (64..320) overrides the choice.
     int max_threads = 64;
-    if (const char* e = getenv("HELIOS_RT_MAXTHREADS")) {
+    if (flux_one_wave(g.ROWS)) {
+        choose_workgroup(Y, X, 64, g);   // (these kernels are built for single-wavefront workgroups: rt_kernels.h)
+    } else if (const char* e = getenv("HELIOS_RT_MAXTHREADS")) {
         max_threads = std::max(64, std::min(320, atoi(e)));
         choose_workgroup(Y, X, max_threads, g);
     } else {

@@ -803,8 +803,16 @@ __device__ __forceinline__ void moebius_scan_up(Moebius& P, int j, int k) {
 #endif
 // MATRIX: `flux calculation method = matrix` -- instead of the sweeps, the direct solve of the same equations by the two
 // scans described above (`the direct solve as three scans`) (no up-flux state is read: a direct solve has none)
+#ifndef HX_BIG_ROWS_ONE_WAVE
+#define HX_BIG_ROWS_ONE_WAVE 1   // tilings of 15 and more rows (columns of more than 448 layers) run as single-wavefront workgroups: with
+                                 // one wavefront per SIMD the part of the register image that does not fit 256 VGPRs lives in AGPRs
+                                 // instead of scratch -- 2 000 bins x 1 000 layers 6.73 -> 2.27 ms per iteration, 600 layers 1.29 -> 0.71,
+                                 // 512 layers 0.699 -> 0.649; 14 rows (2-3 spilled registers) lose 2 % that way and stay as they were
+                                 // (0: 320-thread workgroups, two wavefronts per SIMD, scratch; profiles/r06_deep_columns.txt)
+#endif
+constexpr bool flux_one_wave(int rows) { return rows >= 15 && HX_BIG_ROWS_ONE_WAVE; }
 template <int ROWS, int K = 0, bool MATRIX = false>
-__global__ void __launch_bounds__(320) k_rt_flux(FluxArgs a) {
+__global__ void __launch_bounds__(flux_one_wave(ROWS) ? 64 : 320) k_rt_flux(FluxArgs a) {
     extern __shared__ __align__(16) double smem[];
     const int col = a.reverse ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
     if (a.done[col]) return;
