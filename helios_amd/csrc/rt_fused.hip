@@ -61,7 +61,9 @@ void choose_workgroup(int Y, int X, int max_threads, TileGeom& g) {
     }
 }
 
-// k_rt_flux<ROWS, K> instantiations whose code objects report vgpr_spill_count > 0 (K = 0 stands for k = 8)
+// k_rt_flux<ROWS, K> instantiations that do not hold their register image in 256 VGPRs at two wavefronts per SIMD (K = 0 stands
+// for k = 8): 14 rows spill 2-3 registers (k != 16), 15 rows and more run as single-wavefront workgroups with the overflow in AGPRs
+// (round 6, rt_kernels.h flux_one_wave) -- chosen only where no other lane count avoids them
 bool flux_variant_spills(int rows, int k) { return rows >= 15 || (rows == 14 && k != 16); }
 
 bool choose_geometry(int H, int Y, int X, int C, int dir_beam, int scat_corr, TileGeom& g, int matrix = 0) {
