@@ -1,7 +1,7 @@
 """`flux calculation method = matrix` at a given size: iterations of the device-resident loop (hx_rt_flags.matrix) against
 the same iterations driven stage by stage from Python (Compute._radiation_loop_stagewise), and against the sweeps.
 Each run goes to radiative equilibrium at the given criterion.
-    python tools/time_matrix_method.py NBIN NLAYER [CRITERION]"""
+    python tools/time_matrix_method.py NBIN NLAYER [CRITERION] [--sweeps-stagewise]"""
 import os
 import sys
 import time
@@ -12,8 +12,9 @@ import numpy as np  # noqa: E402
 import helios  # noqa: E402
 from helios_amd import computation  # noqa: E402
 
-nbin, nlayer = sys.argv[1], sys.argv[2]
-crit = sys.argv[3] if len(sys.argv) > 3 else "1e-4"
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+nbin, nlayer = _args[0], _args[1]
+crit = _args[2] if len(_args) > 2 else "1e-4"
 base = ["-parameter_file", "/nonexistent", "-opacity_mixing", "synthetic", "-synthetic", "%s 30 20 20242" % nbin,
         "-number_of_layers", nlayer, "-output_directory", "/tmp/mm_out/", "-radiative_equilibrium_criterion", crit,
         "-maximum_number_of_iterations", "100000", "-internal_temperature", "800", "-convective_adjustment", "no",
