@@ -390,6 +390,8 @@ def live_counters(workload, counters=("FETCH_SIZE", "WRITE_SIZE"), ncol=1):
             env = dict(os.environ, TMPDIR=tmp)
             for k in _OMP_SET_HERE:       # the binding is the CPU baseline's, not the profiled children's
                 env.pop(k, None)
+            for k in [k for k in env if k.startswith(("ROCPROF_", "ROCP_")) or k == "ROCPROFILER_LIBRARY_CTOR"]:
+                env.pop(k, None)          # (the child profiler sets its own)
             try:
                 p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True,
                                    timeout=900 if WORKLOADS[workload].get("nspecies") else 240)
@@ -422,6 +424,12 @@ def live_counters(workload, counters=("FETCH_SIZE", "WRITE_SIZE"), ncol=1):
            "per counter, hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts half)"
            % (" | ".join(counters), workload))
     return d, src
+
+
+def under_a_profiler(env):
+    """rocprofv3 (or rocprof) has launched this process: its tool library is preloaded and ROCPROF_* variables configure it"""
+    return ("rocprofiler" in env.get("LD_PRELOAD", "") or "ROCPROFILER_LIBRARY_CTOR" in env
+            or any(k.startswith(("ROCPROF_", "ROCP_")) for k in env))
 
 
 def env_knobs(allow_debug):
@@ -842,6 +850,11 @@ def main():
         if x not in WORKLOADS:
             raise SystemExit("unknown secondary workload %r" % x)
 
+    if world == 1 and args.live_counters != "off" and under_a_profiler(os.environ):
+        # `rocprofv3 ... -- python3 bench.py`: no profiler children inside a profiled run (they would inherit its preloaded tool
+        # library and counter configuration); the committed per-launch figures are quoted instead (`traffic_live`: false)
+        sys.stderr.write("bench.py: running under a profiler -- HBM traffic is quoted from profiles/traffic.json, not counted in this run\n")
+        args.live_counters = "off"
     if world == 1 and args.live_counters != "off":
         # before this process touches the GPU: the profiler's children have the device to themselves
         for x in [wname] + (secondary if args.live_counters == "all" else []):

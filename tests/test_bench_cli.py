@@ -85,3 +85,12 @@ def test_emit_prints_the_line_last_and_writes_the_side_file(tmp_path, capsys):
 def test_default_secondaries_are_the_three_baseline_configs():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'n1 = ["c3", "c4", "c5"] + (["c5conv", "d64", "d64s"] if args.secondary == "all" else [])' in src
+
+
+def test_bench_knows_when_it_runs_under_a_profiler():
+    """`rocprofv3 ... -- python3 bench.py` must not start profiler children of its own (the live HBM counters): the preloaded
+    tool library and the ROCPROF_* variables of the outer run give it away"""
+    import bench
+    assert not bench.under_a_profiler({"PATH": "/usr/bin", "LD_PRELOAD": "/usr/lib/libjemalloc.so"})
+    assert bench.under_a_profiler({"LD_PRELOAD": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so:/opt/rocm/lib/librocprofiler-sdk.so"})
+    assert bench.under_a_profiler({"ROCPROF_OUTPUT_PATH": "/tmp/x"}) and bench.under_a_profiler({"ROCPROFILER_LIBRARY_CTOR": "1"})
